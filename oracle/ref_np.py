@@ -1,0 +1,567 @@
+"""NumPy/SciPy float64 restatement of the xVIO EKF-update hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing outside tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product path
+(x_multi_agent_amd/) never does.
+
+PARITY UNPINNED: the reference (jpl-x/x_multi_agent @ v1) ships no tests, no
+golden vectors, and cannot be built here (needs Eigen3, OpenCV, Boost -- none
+installed, no network).  This file is one of two independent restatements
+(the other is oracle/xk_oracle.c); their mutual agreement plus the
+mathematical invariants in tests/ is what stands in for reference fixtures.
+
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  The third-party arithmetic the reference calls into is
+restated from its published definition:
+  * Eigen3 (unpinned, CMakeLists.txt:181): HouseholderQR, .inverse(),
+    Quaternion::toRotationMatrix, AngleAxis -> numpy.linalg.{qr,inv}
+  * OpenCV >= 3.3.1 calib3d cv::triangulatePoints (CMakeLists.txt:101) ->
+    null vector of the 4x4 DLT system via numpy.linalg.svd
+  * Boost.Math >= 1.71 quantile(chi_squared) (CMakeLists.txt:117) ->
+    scipy.stats.chi2.ppf
+"""
+import numpy as np
+from scipy.stats import chi2 as _chi2
+
+K_CORE = 15  # kSizeCoreErr, include/x/common/types.h:45
+GRAV = np.array([0.0, 0.0, -9.81])  # hard-coded, msckf_update.cpp:393
+
+
+# ----------------------------------------------------------------------------
+# helpers (include/x/vio/tools.h:57-84, Eigen semantics)
+# ----------------------------------------------------------------------------
+def skew(v):
+    """x::Skew, include/x/vio/tools.h:57-65."""
+    x, y, z = v
+    return np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
+
+
+def quat_to_rot(q_xyzw):
+    """q.normalized().toRotationMatrix() for q stored (x,y,z,w).
+
+    Maps camera -> world (msckf_update.cpp:339-340, state.cpp:190,194)."""
+    q = np.asarray(q_xyzw, dtype=np.float64)
+    q = q / np.sqrt(np.dot(q, q))
+    x, y, z, w = q
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([
+        [1 - (tyy + tzz), txy - twz, txz + twy],
+        [txy + twz, 1 - (txx + tzz), tyz - twx],
+        [txz - twy, tyz + twx, 1 - (txx + tyy)],
+    ])
+
+
+def chi2inv(p, dof):
+    """boost::math::quantile(chi_squared(dof), p)."""
+    return float(_chi2.ppf(p, dof))
+
+
+# ----------------------------------------------------------------------------
+# Triangulation (src/x/vision/triangulation.cpp)
+# ----------------------------------------------------------------------------
+def pose2proj(rot, pos):
+    """triangulation.cpp:208-216: [R | -R p] with R = world->camera."""
+    return np.hstack([rot, (-rot @ pos).reshape(3, 1)])
+
+
+def triangulate_dlt(obs1, obs2, proj1, proj2):
+    """triangulation.cpp:81-100 + cv::triangulatePoints (DLT null vector)."""
+    a = np.empty((4, 4))
+    a[0] = obs1[0] * proj1[2] - proj1[0]
+    a[1] = obs1[1] * proj1[2] - proj1[1]
+    a[2] = obs2[0] * proj2[2] - proj2[0]
+    a[3] = obs2[1] * proj2[2] - proj2[1]
+    _, _, vt = np.linalg.svd(a)
+    x = vt[3]
+    return x[:3] / x[3]
+
+
+def triangulate_gn(quats_xyzw, poss, obs, max_iter=10, term=1e-5):
+    """triangulation.cpp:48-79 (ctor) + :102-206 (triangulateGN).
+
+    quats/poss/obs all have the same length (the track's poses).  Returns
+    (alpha, beta, rho) anchored in the LAST pose, and the iteration count."""
+    n = len(poss)
+    rots = [quat_to_rot(q).T for q in quats_xyzw]  # world -> camera, :70
+    projs = [pose2proj(rots[i], np.asarray(poss[i], float)) for i in range(n)]
+    i2 = n - 1
+    i1 = i2 - len(obs) + 1  # == 0
+    pt = triangulate_dlt(obs[i1], obs[i2], projs[i1], projs[i2])
+    pc2 = projs[i2] @ np.append(pt, 1.0)
+    alpha, beta, rho = pc2[0] / pc2[2], pc2[1] / pc2[2], 1.0 / pc2[2]
+    rot_a, p_a = rots[i2], np.asarray(poss[i2], float)
+    r_norm_last, r_norm, it = 1000.0, 100.0, 0
+    while r_norm_last - r_norm > term:  # :149
+        it += 1
+        if it > max_iter:
+            break
+        r = np.zeros(2 * n)
+        j = np.zeros((2 * n, 3))
+        for i in range(i1, i2 + 1):
+            rot = rots[i]
+            drot = rot @ rot_a.T
+            dpos = rot @ p_a - rot @ np.asarray(poss[i], float)
+            k = i - i1
+            h_i = drot @ np.array([alpha, beta, 1.0]) + rho * dpos
+            h = np.array([h_i[0] / h_i[2], h_i[1] / h_i[2]])
+            r[2 * k:2 * k + 2] = np.asarray(obs[k]) - h
+            j0 = np.column_stack([drot[:, 0], drot[:, 1], dpos])
+            j1 = np.array([[-1.0 / h_i[2], 0.0, h_i[0] / h_i[2] ** 2],
+                           [0.0, -1.0 / h_i[2], h_i[1] / h_i[2] ** 2]])
+            j[2 * k:2 * k + 2] = j1 @ j0
+        delta = np.linalg.inv(j.T @ j) @ j.T @ r  # :193-194
+        alpha, beta, rho = alpha - delta[0], beta - delta[1], rho - delta[2]
+        r_norm_last, r_norm = r_norm, np.linalg.norm(r)
+    return np.array([alpha, beta, rho]), it
+
+
+def global_feature_position(ivd, q_last, p_last):
+    """msckf_update.cpp:283-304."""
+    a, b, rho = ivd
+    return (1.0 / rho) * quat_to_rot(q_last) @ np.array([a, b, 1.0]) + np.asarray(p_last, float)
+
+
+# ----------------------------------------------------------------------------
+# MSCKF per-track measurement (src/x/vio/msckf_update.cpp:306-492)
+# ----------------------------------------------------------------------------
+def msckf_track_jacobians(obs, C_q_G, G_p_C, n_poses_max, G_p_f, n_cols):
+    """Observation loop of processOneTrack, msckf_update.cpp:328-417.
+
+    Returns (jac_j [2L x n_cols], Hf_j [2L x 3], res_j [2L]) or None if a
+    non-finite camera-frame point is met (:349-357)."""
+    L = len(obs)
+    n_poses = len(G_p_C)
+    jac = np.zeros((2 * L, n_cols))
+    hf = np.zeros((2 * L, 3))
+    res = np.zeros(2 * L)
+    for i in range(L):
+        pos = n_poses - L + i  # :329-331
+        R = quat_to_rot(C_q_G[pos])
+        p = np.asarray(G_p_C[pos], float)
+        c = R.T @ (G_p_f - p)
+        if not np.all(c == c):
+            return None
+        res[2 * i] = obs[i][0] - c[0] / c[2]
+        res[2 * i + 1] = obs[i][1] - c[1] / c[2]
+        Ji = np.array([[1.0 / c[2], 0.0, -c[0] / c[2] ** 2],
+                       [0.0, 1.0 / c[2], -c[1] / c[2] ** 2]])
+        Jp = -Ji @ R.T
+        Ja = Ji @ skew(c)
+        # observability constraint, :393-406
+        u = (R @ GRAV).reshape(3, 1)
+        Jp = Jp - Jp @ u @ np.linalg.inv(u.T @ u) @ u.T
+        u = (skew(G_p_f - p) @ GRAV).reshape(3, 1)
+        Ja = Ja - Ja @ u @ np.linalg.inv(u.T @ u) @ u.T
+        hf[2 * i:2 * i + 2] = -Jp  # :409
+        col = K_CORE + 3 * pos
+        jac[2 * i:2 * i + 2, col:col + 3] = Jp
+        col += 3 * n_poses_max
+        jac[2 * i:2 * i + 2, col:col + 3] = Ja
+    return jac, hf, res
+
+
+def left_nullspace(hf):
+    """msckf_update.cpp:423-427: Q = householderQr(Hf).householderQ(); A_up =
+    Q[:, :3], A = Q[:, 3:].  (Basis is implementation-defined)"""
+    q, _ = np.linalg.qr(hf, mode="complete")
+    return q[:, :3], q[:, 3:]
+
+
+def msckf_process_one_track(obs, P, C_q_G, G_p_C, n_poses_max, var_img, G_p_f):
+    """processOneTrack single-agent branch, msckf_update.cpp:306-492.
+
+    Returns dict(valid, inlier, gamma, chi, jac0, res0, A_up_jac, A_up_hf,
+    A_up_res)."""
+    n = P.shape[1]
+    out = msckf_track_jacobians(obs, C_q_G, G_p_C, n_poses_max, G_p_f, n)
+    if out is None:
+        return dict(valid=False, inlier=False, gamma=np.nan)
+    jac, hf, res = out
+    a_up, a = left_nullspace(hf)
+    res0 = a.T @ res
+    jac0 = a.T @ jac
+    L = len(obs)
+    d = 2 * L - 3
+    s = jac0 @ P @ jac0.T + var_img * np.eye(d)  # :457
+    gamma = float(res0 @ np.linalg.inv(s) @ res0)
+    chi = chi2inv(0.95, 2 * L - 3)  # :459-461
+    return dict(valid=True, inlier=gamma < chi, gamma=gamma, chi=chi,
+                jac0=jac0, res0=res0,
+                up_jac=a_up.T @ jac, up_hf=a_up.T @ hf, up_res=a_up.T @ res)
+
+
+def msckf_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img):
+    """MsckfUpdate ctor, single-agent, msckf_update.cpp:27-63 + :65-173.
+
+    tracks: list of (L_k x 2) arrays of normalised observations; a length-L
+    track observes the LAST L poses of the window lists.
+    Returns (jac [rows x n], res [rows], cov_diag [rows], info) with rows
+    pre-sized for all tracks and trailing zero rows for rejected ones (Q1)."""
+    n_trks = len(tracks)
+    n_obs = sum(len(t) for t in tracks)
+    rows = 2 * n_obs - 3 * n_trks
+    n = P.shape[1]
+    jac = np.zeros((rows, n))
+    cov_diag = np.ones(rows)
+    res = np.zeros(rows)
+    var_img = sigma_img * sigma_img
+    row_h = 0
+    inlier = np.zeros(n_trks, dtype=np.int32)
+    gamma = np.full(n_trks, np.nan)
+    feats = np.zeros((n_trks, 3))
+    gn_iters = np.zeros(n_trks, dtype=np.int32)
+    for k, trk in enumerate(tracks):
+        L = len(trk)
+        q_l = C_q_G[len(C_q_G) - L:]
+        p_l = G_p_C[len(G_p_C) - L:]
+        ivd, it = triangulate_gn(q_l, p_l, trk)
+        gn_iters[k] = it
+        gpf = global_feature_position(ivd, q_l[-1], p_l[-1])
+        feats[k] = gpf
+        o = msckf_process_one_track(trk, P, C_q_G, G_p_C, n_poses_max, var_img, gpf)
+        gamma[k] = o["gamma"]
+        if o["valid"] and o["inlier"]:
+            d = 2 * L - 3
+            jac[row_h:row_h + d] = o["jac0"]
+            res[row_h:row_h + d] = o["res0"]
+            cov_diag[row_h:row_h + d] = var_img
+            row_h += d
+            inlier[k] = 1
+    return jac, res, cov_diag, dict(inlier=inlier, gamma=gamma, feats=feats,
+                                    gn_iters=gn_iters, rows_used=row_h)
+
+
+# ----------------------------------------------------------------------------
+# SLAM measurement (src/x/vio/slam_update.cpp:25-214)
+# ----------------------------------------------------------------------------
+def slam_process_one_track(track_size, z_last, j, C_q_G, G_p_C, feat, anchor_idxs, P,
+                           n_poses_max, var_img):
+    """SlamUpdate::processOneTrack, slam_update.cpp:49-214."""
+    n = P.shape[1]
+    h = np.zeros((2, n))
+    alpha, beta, rho = feat[3 * j:3 * j + 3]
+    a = anchor_idxs[j]
+    Ra = quat_to_rot(C_q_G[a])
+    pa = np.asarray(G_p_C[a], float)
+    gpf = (1.0 / rho) * Ra @ np.array([alpha, beta, 1.0]) + pa
+    Rn = quat_to_rot(C_q_G[-1])
+    pn = np.asarray(G_p_C[-1], float)
+    c = Rn.T @ (gpf - pn)
+    res = np.array([z_last[0] - c[0] / c[2], z_last[1] - c[1] / c[2]])
+    pos = len(C_q_G) - 1
+    fcol = K_CORE + (2 * n_poses_max + j) * 3
+    if a == pos:  # :120-131
+        h[0, fcol] = 1.0
+        h[1, fcol + 1] = 1.0
+    else:
+        Ji = np.array([[1.0 / c[2], 0.0, -c[0] / c[2] ** 2],
+                       [0.0, 1.0 / c[2], -c[1] / c[2] ** 2]])
+        J_att = Ji @ skew(c)
+        J_pos = -Ji @ Rn.T
+        J_anchor_att = -1.0 / rho * Ji @ Rn.T @ Ra @ skew([alpha, beta, 1.0])
+        J_anchor_pos = -J_pos
+        mat = np.eye(3)
+        mat[0, 2], mat[1, 2], mat[2, 2] = -alpha / rho, -beta / rho, -1.0 / rho
+        Hf = 1.0 / rho * Ji @ Rn.T @ Ra @ mat
+        col = K_CORE + 3 * pos
+        h[:, col:col + 3] = J_pos
+        h[:, col + 3 * n_poses_max:col + 3 * n_poses_max + 3] = J_att
+        col = K_CORE + 3 * a
+        h[:, col:col + 3] = J_anchor_pos
+        h[:, col + 3 * n_poses_max:col + 3 * n_poses_max + 3] = J_anchor_att
+        h[:, fcol:fcol + 3] = Hf
+    s = h @ P @ h.T + var_img * np.eye(2)
+    gamma = float(res @ np.linalg.inv(s) @ res)
+    chi = chi2inv(0.9, 2 * track_size)  # :196-197
+    return h, res, gamma, gamma < chi
+
+
+def slam_update(track_sizes, z_last, C_q_G, G_p_C, feat, anchor_idxs, P, n_poses_max, sigma_img):
+    """SlamUpdate ctor, slam_update.cpp:25-47."""
+    m = len(track_sizes)
+    n = P.shape[1]
+    jac = np.zeros((2 * m, n))
+    res = np.zeros(2 * m)
+    cov_diag = np.ones(2 * m)
+    var_img = sigma_img ** 2
+    row = 0
+    inl = np.zeros(m, dtype=np.int32)
+    gam = np.zeros(m)
+    for j in range(m):
+        h, r, g, ok = slam_process_one_track(track_sizes[j], z_last[j], j, C_q_G, G_p_C, feat,
+                                             anchor_idxs, P, n_poses_max, var_img)
+        gam[j] = g
+        if ok:
+            jac[row:row + 2] = h
+            res[row:row + 2] = r
+            cov_diag[row:row + 2] = var_img
+            row += 2
+            inl[j] = 1
+    return jac, res, cov_diag, dict(inlier=inl, gamma=gam)
+
+
+# ----------------------------------------------------------------------------
+# QR compression + Kalman update (vio_updater.cpp:487-512, updater.cpp:117-161)
+# ----------------------------------------------------------------------------
+def apply_qr_decomposition(h, res, r_diag, sigma_img):
+    """VioUpdater::applyQRDecomposition, vio_updater.cpp:487-512.
+
+    r_diag is the measurement-noise DIAGONAL (the reference densifies it to
+    rows x rows at vio_updater.cpp:417; result-identical).  Returns
+    (h, res, r_diag, did_qr)."""
+    rows, cols = h.shape
+    if rows > cols + 1:
+        hres = np.hstack([h, res.reshape(-1, 1)])
+        thz = np.linalg.qr(hres, mode="r")
+        return (thz[:cols, :cols].copy(), thz[:cols, cols].copy(),
+                np.full(cols, sigma_img ** 2), True)
+    return h, res, r_diag, False
+
+
+def apply_update(P, H, res, r_diag, correction_total=None, cov_update=True):
+    """Updater::applyUpdate, updater.cpp:117-141 (covariance + correction;
+    State::correct is separate).  Returns (P_new, correction)."""
+    n = P.shape[0]
+    if correction_total is None:
+        correction_total = np.zeros(n)
+    S = H @ P @ H.T + np.diag(r_diag)
+    K = P @ H.T @ np.linalg.inv(S)
+    corr = K @ (res + H @ correction_total) - correction_total
+    if cov_update:
+        Pn = (np.eye(n) - K @ H) @ P
+        Pn = 0.5 * (Pn + Pn.T)
+    else:
+        Pn = P.copy()
+    return Pn, corr
+
+
+def apply_ci(ci_P, H, res, S):
+    """Updater::applyCI, updater.cpp:144-161.  Returns (P_new, correction)."""
+    n = ci_P.shape[0]
+    K = ci_P @ H.T @ np.linalg.inv(S)
+    corr = K @ res
+    Pn = (np.eye(n) - K @ H) @ ci_P
+    return 0.5 * (Pn + Pn.T), corr
+
+
+def error_quat(dtheta):
+    """State::errorQuatFromSmallAngles, state.cpp:273-283 -> (x,y,z,w)."""
+    nrm = np.sqrt(np.dot(dtheta, dtheta))
+    if nrm == 0.0:
+        return np.array([0.0, 0.0, 0.0, 1.0])
+    ax = dtheta / nrm
+    s = np.sin(0.5 * nrm)
+    return np.array([ax[0] * s, ax[1] * s, ax[2] * s, np.cos(0.5 * nrm)])
+
+
+def quat_mul(a, b):
+    """Hamilton product, both (x,y,z,w) (Eigen operator*)."""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by + ay * bw + az * bx - ax * bz,
+        aw * bz + az * bw + ax * by - ay * bx,
+        aw * bw - ax * bx - ay * by - az * bz,
+    ])
+
+
+def state_correct(state, corr):
+    """State::correct, state.cpp:197-249.  state: dict with p,v,q(xyzw),b_w,
+    b_a,p_array(3N),q_array(4N xyzw),f_array(3M).  Returns a new dict."""
+    s = {k: np.array(v, dtype=np.float64, copy=True) for k, v in state.items()}
+    npa = s["p_array"].size
+    nf = s["f_array"].size
+    s["p"] += corr[0:3]
+    s["v"] += corr[3:6]
+    s["b_w"] += corr[9:12]
+    s["b_a"] += corr[12:15]
+    s["p_array"] += corr[K_CORE:K_CORE + npa]
+    s["f_array"] += corr[K_CORE + 2 * npa:K_CORE + 2 * npa + nf]
+    q = quat_mul(s["q"], error_quat(corr[6:9]))
+    s["q"] = q / np.sqrt(np.dot(q, q))
+    dth = corr[K_CORE + npa:K_CORE + 2 * npa]
+    for i in range(npa // 3):
+        qi = quat_mul(s["q_array"][4 * i:4 * i + 4], error_quat(dth[3 * i:3 * i + 3]))
+        s["q_array"][4 * i:4 * i + 4] = qi / np.sqrt(np.dot(qi, qi))
+    return s
+
+
+def visual_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img, slam=None):
+    """constructUpdate + applyUpdate for MSCKF (+ optional SLAM) rows,
+    vio_updater.cpp:267-423 + updater.cpp:99-110 with iekf_iter = 1.
+
+    slam: None or dict(track_sizes, z_last, feat, anchor_idxs).
+    Returns dict(P, correction, inlier, gamma, h, res, did_qr, ...)."""
+    jac, res, cov, info = msckf_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img)
+    out = dict(msckf=info)
+    if slam is not None:
+        js, rs, cs, sinfo = slam_update(slam["track_sizes"], slam["z_last"], C_q_G, G_p_C,
+                                        slam["feat"], slam["anchor_idxs"], P, n_poses_max,
+                                        sigma_img)
+        jac = np.vstack([jac, js])
+        res = np.concatenate([res, rs])
+        cov = np.concatenate([cov, cs])
+        out["slam"] = sinfo
+    out["h_stack"], out["res_stack"] = jac, res
+    h, r, cv, did = apply_qr_decomposition(jac, res, cov, sigma_img)
+    out.update(h=h, res=r, r_diag=cv, did_qr=did)
+    if h.size > 0:
+        Pn, corr = apply_update(P, h, r, cv)
+    else:
+        Pn, corr = P.copy(), np.zeros(P.shape[0])
+    out.update(P=Pn, correction=corr)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# Covariance intersection (src/x/ekf/ci.cpp:49-127, fixed-weight branches)
+# ----------------------------------------------------------------------------
+def _check_w(w):
+    if w > 1.0 or w == 0 or w < -1:
+        raise RuntimeError("The CI weights must be lower than 1.0 and larger 0.0")
+    if w < 0.0:
+        raise NotImplementedError("NLopt weight optimisation (ci.cpp:143-190) is out of scope")
+
+
+def fuse_ci_msckf(cov_a, H_curr, other_covs, Hs, w_other):
+    """CovarianceIntersection::fuseCI (k agents), ci.cpp:49-92."""
+    _check_w(w_other)
+    k = len(Hs)
+    w0 = 1.0 - k * w_other
+    S = (1.0 / w0) * H_curr @ cov_a @ H_curr.T
+    for Pi, Hi in zip(other_covs, Hs):
+        S = S + (1.0 / w_other) * Hi @ Pi @ Hi.T
+    return S, 1.0 / w0
+
+
+def fuse_ci_slam(cov_a, H_a, cov_b, H_b, w_other):
+    """CovarianceIntersection::fuseCI (pairwise), ci.cpp:94-127."""
+    _check_w(w_other)
+    Pa = H_a @ cov_a @ H_a.T
+    Pb = H_b @ cov_b @ H_b.T
+    return (1.0 / (1.0 - w_other)) * Pa + (1.0 / w_other) * Pb, 1.0 / (1.0 - w_other)
+
+
+def multi_slam_match(C_q_G, G_p_C, feat, anchor_idx, feature_id, P, n_poses_max,
+                     o_C_q_G, o_G_p_C, o_feat, o_anchor_idx, o_feature_id, o_P,
+                     o_n_poses_max, sigma_landmark, ci_slam_w):
+    """MultiSlamUpdate::processOneMatch, multi_slam_update.cpp:61-246.
+
+    Returns dict(inlier, gamma, H, res, S, P_j) (lists entries if inlier)."""
+    if anchor_idx < 0:
+        raise RuntimeError("anchor_idx < 0")
+    n, no = P.shape[1], o_P.shape[1]
+    var_l = sigma_landmark ** 2
+
+    def one(Cq, Gp, f, a, fid, npm, ncols, sign):
+        al, be, rho = f[3 * fid:3 * fid + 3]
+        if sign > 0 and rho == 0:
+            raise RuntimeError("rho = 0")
+        Ra = quat_to_rot(Cq[a])
+        gpf = (1.0 / rho) * Ra @ np.array([al, be, 1.0]) + np.asarray(Gp[a], float)
+        J_att = -(1.0 / rho) * Ra @ skew([al, be, 1.0])
+        mat = np.eye(3)
+        mat[0, 2], mat[1, 2], mat[2, 2] = -al / rho, -be / rho, -1.0 / rho
+        Hf = (1.0 / rho) * Ra @ mat
+        h = np.zeros((3, ncols))
+        col = K_CORE + 3 * a
+        h[:, col:col + 3] = sign * np.eye(3)
+        h[:, col + 3 * npm:col + 3 * npm + 3] = sign * J_att
+        col = K_CORE + (2 * npm + fid) * 3
+        h[:, col:col + 3] = sign * Hf
+        return gpf, h
+
+    gpf, h = one(C_q_G, G_p_C, feat, anchor_idx, feature_id, n_poses_max, n, +1.0)
+    ogpf, oh = one(o_C_q_G, o_G_p_C, o_feat, o_anchor_idx, o_feature_id, o_n_poses_max, no, -1.0)
+    res = -gpf + ogpf  # :131
+    S0 = h @ P @ h.T + oh @ o_P @ oh.T + var_l * np.eye(3)
+    gamma = float(res @ np.linalg.inv(S0) @ res)
+    chi = chi2inv(0.9, 3)  # :216-218
+    out = dict(inlier=gamma < chi, gamma=gamma, H=h, res=res)
+    if out["inlier"]:
+        S, w_res = fuse_ci_slam(P, h, o_P, oh, ci_slam_w)
+        S = S + var_l * np.eye(3)
+        Pj = P.copy()
+        for col in (K_CORE + 3 * anchor_idx, K_CORE + 3 * anchor_idx + 3 * n_poses_max,
+                    K_CORE + (2 * n_poses_max + feature_id) * 3):
+            Pj[col:col + 3, col:col + 3] *= w_res  # :229-239 (diag blocks only, Q7)
+        out.update(S=S, P_j=Pj, w_result=w_res)
+    return out
+
+
+def msckf_ci_track(trk, C_q_G, G_p_C, P, n_poses_max, sigma_img, matches, ci_msckf_w):
+    """MSCKF-MSCKF CI block of preProcessOneTrack, msckf_update.cpp:96-279.
+
+    matches: list of dict(obs [L_i x 2], q_list, p_list, P, n_poses_max) for
+    the agents that observed this same landmark (ground-truth association).
+    Returns dict(self=<single-agent result>, ci=None | dict(S,P_j,H,res))."""
+    var_img = sigma_img ** 2
+    L = len(trk)
+    # concatenated lists, matched agents FIRST then self (:113-149)
+    q_all, p_all, o_all = [], [], []
+    for m in matches:
+        Li = len(m["obs"])
+        q_all += list(m["q_list"][len(m["q_list"]) - Li:])
+        p_all += list(m["p_list"][len(m["p_list"]) - Li:])
+        o_all += list(m["obs"])
+    q_all += list(C_q_G[len(C_q_G) - L:])
+    p_all += list(G_p_C[len(G_p_C) - L:])
+    o_all += list(trk)
+    ivd, _ = triangulate_gn(q_all, p_all, o_all)
+    gpf = global_feature_position(ivd, q_all[-1], p_all[-1])
+    own = msckf_process_one_track(trk, P, C_q_G, G_p_C, n_poses_max, var_img, gpf)
+    out = dict(self=own, gpf=gpf, ci=None)
+    if not (own["valid"] and own["inlier"] and matches):
+        return out
+    k = len(matches)
+    sizes = [P.shape[1]] + [m["P"].shape[1] for m in matches]
+    jx = np.zeros((3 * (k + 1), sum(sizes)))
+    jf = np.zeros((3 * (k + 1), 3))
+    rp = np.zeros(3 * (k + 1))
+    jx[0:3, 0:sizes[0]] = own["up_jac"]
+    jf[0:3] = own["up_hf"]
+    rp[0:3] = own["up_res"]
+    col = sizes[0]
+    for i, m in enumerate(matches):
+        o = msckf_process_one_track(m["obs"], m["P"], m["q_list"], m["p_list"],
+                                    m["n_poses_max"], var_img, gpf)
+        if not o["valid"]:
+            # reference returns early leaving zero rows (:349-357); keep zeros
+            col += sizes[i + 1]
+            continue
+        r0 = 3 * (i + 1)
+        jx[r0:r0 + 3, col:col + sizes[i + 1]] = o["up_jac"]
+        jf[r0:r0 + 3] = o["up_hf"]
+        rp[r0:r0 + 3] = o["up_res"]
+        col += sizes[i + 1]
+    _, a = left_nullspace(jf)  # nullSpaceProjection, :494-501
+    jx = a.T @ jx
+    rp = a.T @ rp
+    h_j = jx[:, :sizes[0]]
+    Hs, col = [], sizes[0]
+    S = h_j @ P @ h_j.T
+    for i, m in enumerate(matches):
+        Hs.append(jx[:, col:col + sizes[i + 1]])
+        col += sizes[i + 1]
+        S = S + Hs[i] @ m["P"] @ Hs[i].T
+    S = S + var_img * np.eye(S.shape[0])
+    gamma = float(rp @ np.linalg.inv(S) @ rp)
+    chi = chi2inv(0.95, 2 * len(o_all) - 3)  # :245-247
+    out["ci_gamma"] = gamma
+    if gamma < chi:
+        S, w_res = fuse_ci_msckf(P, h_j, [m["P"] for m in matches], Hs, ci_msckf_w)
+        S = S + var_img * np.eye(S.shape[0])  # :255 (Q8)
+        Pj = P.copy()
+        n_poses = len(C_q_G)
+        for i in range(L):
+            pos = n_poses - L + i
+            c = K_CORE + 3 * pos
+            Pj[c:c + 3, c:c + 3] *= w_res
+            c += 3 * n_poses_max
+            Pj[c:c + 3, c:c + 3] *= w_res
+        out["ci"] = dict(S=S, P_j=Pj, H=h_j, res=rp, w_result=w_res)
+    return out

@@ -1,0 +1,267 @@
+"""Deterministic synthetic workloads for the xVIO EKF-update path.
+
+Sliding window of N camera poses on a circle (radius 5 m, 1 m/s, 30 Hz
+frames), K MSCKF landmarks seen in every window frame (+ M persistent SLAM
+features), ideal pinhole observations + N(0, sigma_img^2), window estimate =
+truth minus an error drawn from the prior P, and a prior P grown by a small
+clone-and-propagate covariance recursion so that consecutive clones are
+strongly correlated, as in a running filter.
+
+The PRNG is a counter-mode splitmix64 (vectorised, platform independent) with
+Box-Muller normals, so the same seed gives the same bits everywhere.
+Seed convention: 0x5EED0000 + 1000*config + agent_id.
+"""
+import numpy as np
+
+K_CORE = 15
+_M64 = (1 << 64) - 1
+
+
+class SplitMix:
+    """Counter-mode splitmix64: value i = mix(seed + (i+1)*golden)."""
+
+    def __init__(self, seed):
+        self.seed = np.uint64(seed & _M64)
+        self.ctr = 0
+
+    def u64(self, n):
+        with np.errstate(over="ignore"):
+            i = np.arange(self.ctr + 1, self.ctr + n + 1, dtype=np.uint64)
+            z = self.seed + i * np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        self.ctr += n
+        return z
+
+    def uniform(self, n):
+        return (self.u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def normal(self, n):
+        m = (n + 1) // 2
+        u1 = 1.0 - self.uniform(m)  # (0,1]
+        u2 = self.uniform(m)
+        r = np.sqrt(-2.0 * np.log(u1))
+        out = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])
+        return out[:n]
+
+
+def seed_for(config, agent_id=0):
+    return 0x5EED0000 + 1000 * int(config) + int(agent_id)
+
+
+def _rot_to_quat_xyzw(R):
+    """Rotation matrix (camera->world) to unit quaternion (x,y,z,w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        w, x, y, z = 0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        w, x, y, z = (R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        w, x, y, z = (R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        w, x, y, z = (R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s
+    q = np.array([x, y, z, w])
+    if w < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _quat_to_rot(q):
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _small_rot(dth):
+    a = np.linalg.norm(dth)
+    if a == 0:
+        return np.eye(3)
+    k = dth / a
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+
+def true_poses(n_frames, phase0=0.3, agent_offset=0.0):
+    """Camera on a circle looking radially outward; returns (R_list cam->world, p_list)."""
+    radius, speed, fps = 5.0, 1.0, 30.0
+    Rs, ps = [], []
+    for i in range(n_frames):
+        t = i / fps
+        th = phase0 + agent_offset + speed * t / radius
+        p = np.array([radius * np.cos(th), radius * np.sin(th), 1.5 + 0.05 * np.sin(2.0 * t)])
+        zc = np.array([np.cos(th), np.sin(th), 0.0])
+        xc = np.array([np.sin(th), -np.cos(th), 0.0])
+        yc = np.cross(zc, xc)
+        R = np.column_stack([xc, yc, zc])
+        R = R @ _small_rot(np.array([0.02 * np.sin(3.0 * t), 0.015 * np.cos(2.5 * t), 0.01 * np.sin(1.7 * t)]))
+        Rs.append(R)
+        ps.append(p)
+    return Rs, ps
+
+
+def prior_covariance(n_poses_max, n_feat, rng, kind="filter", scale=1.0):
+    """SPD prior over n = 15 + 6N + 3M error states.
+
+    kind="filter": clone-and-propagate recursion (realistic cross terms);
+    kind="stress": sigma^2 (B B^T + I) with random B."""
+    N, M = n_poses_max, n_feat
+    n = K_CORE + 6 * N + 3 * M
+    if kind == "stress":
+        B = rng.normal(n * n).reshape(n, n)
+        return (1e-4 * scale) * (B @ B.T / n + np.eye(n))
+    P = np.zeros((n, n))
+    sig = np.array([0.02] * 3 + [0.02] * 3 + [0.004] * 3 + [2e-4] * 3 + [2e-3] * 3) * np.sqrt(scale)
+    P[:15, :15] = np.diag(sig ** 2)
+    dt = 1.0 / 30.0
+    F = np.eye(15)
+    F[0:3, 3:6] = dt * np.eye(3)
+    A = rng.normal(9).reshape(3, 3)
+    F[3:6, 6:9] = dt * 3.0 * (A - A.T)          # -R [a]x dt (skew, order 10 m/s^2 * dt)
+    F[3:6, 12:15] = -dt * np.eye(3)
+    F[6:9, 9:12] = -dt * np.eye(3)
+    q = np.array([1e-8] * 3 + [2e-5] * 3 + [4e-7] * 3 + [1e-10] * 3 + [1e-8] * 3) * scale
+    for i in range(N):
+        # propagate core block and its cross terms with the clones so far
+        nv = K_CORE + 6 * N
+        P[:15, :nv] = F @ P[:15, :nv]
+        P[:nv, :15] = P[:nv, :15] @ F.T
+        P[:15, :15] += np.diag(q)
+        # clone pose i (position <- core p, attitude <- core theta)
+        cp, ca = K_CORE + 3 * i, K_CORE + 3 * N + 3 * i
+        for dst, src in ((cp, 0), (ca, 6)):
+            P[dst:dst + 3, :] = P[src:src + 3, :]
+            P[:, dst:dst + 3] = P[:, src:src + 3]
+            P[dst:dst + 3, dst:dst + 3] = P[src:src + 3, src:src + 3]
+        P = 0.5 * (P + P.T)
+    if M:
+        nx = K_CORE + 6 * N
+        C = 0.05 * rng.normal(3 * M * nx).reshape(3 * M, nx)
+        Pxx = P[:nx, :nx]
+        D = np.diag(np.tile(np.array([2e-3, 2e-3, 5e-3]) ** 2, M)) * scale
+        P[nx:, :nx] = C @ Pxx
+        P[:nx, nx:] = (C @ Pxx).T
+        P[nx:, nx:] = C @ Pxx @ C.T + D
+    # tiny jitter keeps it strictly PD (clone of a clone is otherwise singular)
+    P += 1e-12 * scale * np.eye(n)
+    return 0.5 * (P + P.T)
+
+
+def _sample_error(P, rng):
+    """Draw e ~ N(0, P) via eigen-decomposition (P may be near-singular)."""
+    w, V = np.linalg.eigh(P)
+    w = np.clip(w, 0.0, None)
+    return V @ (np.sqrt(w) * rng.normal(P.shape[0]))
+
+
+def make_scenario(n_poses_max, n_msckf, n_slam=0, seed=0, sigma_img=1.0 / 500.0,
+                  n_poses=None, track_len=None, outlier_frac=0.05, prior_kind="filter",
+                  prior_scale=1.0, agent_offset=0.0, landmarks=None):
+    """Build one visual-update problem.
+
+    Returns a dict of plain numpy arrays:
+      C_q_G [n_poses,4] xyzw, G_p_C [n_poses,3]  -- estimated window lists
+      trk_off [K+1] int32, obs_xy [sum L_k, 2]   -- ragged MSCKF tracks
+      P [n,n] prior, n_poses_max, sigma_img
+      slam_* (if n_slam): feat [3M], anchor_idxs [M], z_last [M,2], track_sizes [M]
+      landmarks_true [K+M,3]
+    """
+    rng = SplitMix(seed)
+    N = n_poses_max
+    npz = N if n_poses is None else n_poses
+    K, M = n_msckf, n_slam
+    n = K_CORE + 6 * N + 3 * M
+    Rs, ps = true_poses(npz, agent_offset=agent_offset)
+    mid = npz // 2
+    # landmarks in the mid camera's field of view, 4..20 m deep
+    if landmarks is None:
+        u = rng.uniform(3 * (K + M)).reshape(K + M, 3)
+        depth = 4.0 + 16.0 * u[:, 2]
+        pc = np.column_stack([(u[:, 0] - 0.5) * depth, (u[:, 1] - 0.5) * 0.8 * depth, depth])
+        lm = (Rs[mid] @ pc.T).T + ps[mid]
+    else:
+        lm = np.asarray(landmarks, float)
+        rng.uniform(3 * (K + M))  # keep the stream position independent of the branch
+    P = prior_covariance(N, M, rng, kind=prior_kind, scale=prior_scale)
+    err = _sample_error(P, rng)
+    # estimated window = truth (-) error   (true = est (+) err)
+    q_est = np.zeros((npz, 4))
+    p_est = np.zeros((npz, 3))
+    for i in range(npz):
+        dp = err[K_CORE + 3 * i:K_CORE + 3 * i + 3]
+        dth = err[K_CORE + 3 * N + 3 * i:K_CORE + 3 * N + 3 * i + 3]
+        p_est[i] = ps[i] - dp
+        q_est[i] = _rot_to_quat_xyzw(Rs[i] @ _small_rot(dth).T)
+    # MSCKF tracks: last L_k poses
+    if track_len is None:
+        lens = np.full(K, npz, dtype=np.int64)
+    elif np.isscalar(track_len):
+        lens = np.full(K, int(track_len), dtype=np.int64)
+    else:
+        lo, hi = track_len
+        lens = lo + (rng.uniform(K) * (hi - lo + 1)).astype(np.int64)
+        lens = np.clip(lens, lo, hi)
+    trk_off = np.zeros(K + 1, dtype=np.int32)
+    trk_off[1:] = np.cumsum(2 * 0 + lens)
+    obs = np.zeros((int(trk_off[-1]), 2))
+    noise = rng.normal(2 * obs.shape[0]).reshape(-1, 2) * sigma_img
+    bad = rng.uniform(K) < outlier_frac
+    bad_mag = 15.0 + 30.0 * rng.uniform(K)
+    for k in range(K):
+        L = int(lens[k])
+        for i in range(L):
+            pos = npz - L + i
+            c = Rs[pos].T @ (lm[k] - ps[pos])
+            obs[trk_off[k] + i] = c[:2] / c[2]
+        if bad[k]:
+            # gross mismatch on the second half of the track
+            noise[trk_off[k] + L // 2:trk_off[k] + L] += bad_mag[k] * sigma_img
+    obs += noise
+    out = dict(C_q_G=q_est, G_p_C=p_est, trk_off=trk_off, obs_xy=obs, P=P,
+               n_poses_max=N, n_poses=npz, sigma_img=float(sigma_img), n=n,
+               landmarks_true=lm, seed=int(seed), R_true=np.array(Rs), p_true=np.array(ps))
+    if M:
+        # SLAM features: inverse-depth in an anchor pose, estimate = truth - error
+        anchors = (rng.uniform(M) * npz).astype(np.int32)
+        anchors = np.clip(anchors, 0, npz - 1)
+        feat = np.zeros(3 * M)
+        z_last = np.zeros((M, 2))
+        zn = rng.normal(2 * M).reshape(M, 2) * sigma_img
+        for j in range(M):
+            a = int(anchors[j])
+            c = Rs[a].T @ (lm[K + j] - ps[a])
+            true_ivd = np.array([c[0] / c[2], c[1] / c[2], 1.0 / c[2]])
+            feat[3 * j:3 * j + 3] = true_ivd - err[K_CORE + 6 * N + 3 * j:K_CORE + 6 * N + 3 * j + 3]
+            cl = Rs[-1].T @ (lm[K + j] - ps[-1])
+            z_last[j] = cl[:2] / cl[2] + zn[j]
+        out.update(slam_feat=feat, slam_anchor_idxs=anchors, slam_z_last=z_last,
+                   slam_track_sizes=np.full(M, npz, dtype=np.int32))
+    return out
+
+
+def tracks_as_list(sc):
+    """Ragged obs -> list of [L_k,2] arrays (oracle-side convenience)."""
+    off = sc["trk_off"]
+    return [sc["obs_xy"][off[k]:off[k + 1]] for k in range(len(off) - 1)]
+
+
+CONFIGS = {
+    # BASELINE.json configs: (n_poses_max, n_msckf, n_slam)
+    1: (10, 50, 0),
+    2: (30, 200, 50),
+    3: (50, 800, 0),
+    4: (30, 400, 0),
+    5: (30, 400, 0),
+}
+
+
+def make_config(cfg, agent_id=0, **kw):
+    N, K, M = CONFIGS[cfg]
+    return make_scenario(N, K, M, seed=seed_for(cfg, agent_id), **kw)
