@@ -1,0 +1,198 @@
+/*
+ * xk.h -- C ABI of the MI355X-native xVIO EKF-update engine.
+ *
+ * This is the drop-in boundary for ONE path of jpl-x/x_multi_agent: the
+ * visual EKF update (MSCKF build -> QR compression -> Kalman update) and the
+ * covariance-intersection fusion step.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - all matrices are column-major IEEE doubles with an explicit leading
+ *     dimension (Eigen::MatrixXd::data() can be passed directly);
+ *   - quaternions are (x,y,z,w) as stored in State::q_array_
+ *     (src/x/ekf/state.cpp:235-240);
+ *   - error-state column map (include/x/common/types.h:39-47,
+ *     msckf_update.cpp:412-416): [0,15) core, 15+3i position of window pose
+ *     i, 15+3N+3i attitude of pose i, 15+6N+3j SLAM feature j;
+ *   - the caller owns every host buffer; the library never keeps a host
+ *     pointer after a call returns; device memory belongs to the handle;
+ *   - one handle per agent / x::Ekf; calls on one handle are serialised by
+ *     the caller (as Updater::update is in the reference, ekf.cpp:186-205),
+ *     distinct handles are independent;
+ *   - every call is synchronous unless its name ends in _async;
+ *   - return value is an xk_status; nothing aborts, nothing throws.
+ */
+#ifndef XK_H_
+#define XK_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xk_handle xk_handle;
+
+typedef enum {
+  XK_OK = 0,
+  XK_EINVAL = 1,    /* bad dims / CI weights (ci.cpp:59-62,98-101 throw) */
+  XK_ESINGULAR = 2, /* innovation covariance not SPD */
+  XK_ENAN = 3,
+  XK_EDEVICE = 4,   /* HIP runtime error; see xk_last_error */
+  XK_ENOMEM = 5,
+  XK_ECAPACITY = 6  /* problem larger than the handle was created for */
+} xk_status;
+
+#define XK_CORE 15 /* kSizeCoreErr, include/x/common/types.h:45 */
+
+/* ---- lifetime -------------------------------------------------------- */
+
+/* Creates the per-agent engine on HIP device `device`.  Capacities:
+ * n_poses_max = sliding-window length N (Params::n_poses_max,
+ * include/x/vio/types.h), n_feat_max = SLAM feature slots M, k_max = MSCKF
+ * tracks per update.  n = 15 + 6N + 3M. */
+int xk_create(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out);
+int xk_destroy(xk_handle *h);
+const char *xk_strerror(int status);
+const char *xk_last_error(const xk_handle *h);
+int xk_version(void);
+/* HIP stream the handle launches on (void* = hipStream_t), for callers that
+ * want to order their own device work or time with events. */
+void *xk_stream(xk_handle *h);
+
+/* ---- staged (device-resident) visual update -------------------------- */
+
+/* Stage the inputs of one visual update in HBM.  Replaces the arguments of
+ * the MsckfUpdate / SlamUpdate constructors as called from
+ * VioUpdater::constructUpdate (src/x/vio/vio_updater.cpp:279-305,338-346):
+ *   C_q_G [n_poses x 4] xyzw, G_p_C [n_poses x 3]   window lists
+ *       (StateManager::convertCamera{Attitudes,Positions}ToList,
+ *        src/x/vio/state_manager.cpp:539-584), row per pose;
+ *   trk_off [K+1], obs_xy [trk_off[K] x 2]          MSCKF tracks, normalised
+ *       image coordinates (Feature::getX/getY); a length-L track observes the
+ *       LAST L window poses (msckf_update.cpp:329-331);
+ *   P [n x n], ldp                                  prior covariance
+ *       (Matrix P = state.getCovariance(), vio_updater.cpp:284);
+ *   SLAM (M may be 0): feat [3M] inverse-depth states, anchor_idxs [M],
+ *       track_sizes [M] (only used for the chi-square dof,
+ *       slam_update.cpp:196), z_last [M x 2] newest observation. */
+int xk_stage_window(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses);
+int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *obs_xy, int K);
+int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor_idxs, const int *track_sizes,
+                  const double *z_last, int M);
+int xk_upload_P(xk_handle *h, const double *P, int ldp, int n);
+int xk_download_P(xk_handle *h, double *P, int ldp, int n);
+
+/* Per-feature build on the staged inputs: triangulation (triangulation.cpp:
+ * 48-206), Jacobians + observability constraint + left-nullspace projection +
+ * chi-square gate (msckf_update.cpp:65-173,283-492), SLAM rows
+ * (slam_update.cpp:49-214).  Leaves the projected rows [H0|res0]
+ * device-resident.  Outputs (host, optional = NULL): inlier/gamma per track. */
+int xk_msckf_build(xk_handle *h, double sigma_img, int *inlier_msckf, double *gamma_msckf,
+                   int *inlier_slam, double *gamma_slam);
+
+/* Householder TSQR of the device-resident stacked [H|res]; replaces
+ * VioUpdater::applyQRDecomposition (vio_updater.cpp:487-512).  Optional host
+ * outputs: T_H (n x n, ldt; upper-trapezoidal, zero core columns) and z (n).
+ * T_H^T T_H and T_H^T z equal the reference's up to rounding; the rows
+ * themselves differ by an orthogonal factor. */
+int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z);
+
+/* Kalman gain + covariance/state-correction on the compressed system with
+ * R = sigma_img^2 I; replaces Updater::applyUpdate (src/x/ekf/updater.cpp:
+ * 117-141): S = HPH^T+R, K = PH^T S^-1, corr = K(res + H corr_tot) - corr_tot,
+ * P = (I-KH)P, P = (P+P^T)/2.  P stays on the device (xk_download_P);
+ * correction (n) is returned to the host because State::correct
+ * (state.cpp:197-249) runs there.  corr_total may be NULL (= 0). */
+int xk_apply_update(xk_handle *h, const double *corr_total, int cov_update, double *correction);
+
+/* xk_msckf_build + xk_qr_compress + xk_apply_update in one call on the staged
+ * inputs, no host round trips in between (a5..a12 of SURVEY 8a). */
+int xk_visual_update_staged(xk_handle *h, double sigma_img, double *correction, int *inlier_msckf,
+                            double *gamma_msckf, int *inlier_slam, double *gamma_slam);
+
+/* Convenience: stage + update + download in one call (host buffers in/out;
+ * PCIe inclusive).  P is updated in place. */
+int xk_visual_update(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses,
+                     const int *trk_off, const double *obs_xy, int K, const double *feat,
+                     const int *anchor_idxs, const int *track_sizes, const double *z_last, int M,
+                     double *P, int ldp, int n, double sigma_img, double *correction,
+                     int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam);
+
+/* ---- dense (unfused) Kalman algebra, reference signatures ------------ */
+
+/* Updater::applyUpdate(state, H, res, R, correction_total, cov_update) with
+ * arbitrary dense H (m x n) and diagonal R (updater.cpp:117-141).  P in/out
+ * on the host; correction_total (n) in/out (updater.cpp:140). */
+int xk_apply_update_dense(xk_handle *h, double *P, int ldp, int n, const double *H, int ldh, int m,
+                          const double *res, const double *r_diag, double *correction_total,
+                          int cov_update, double *correction);
+
+/* Updater::applyCI(state, ci_P, H, res, S) (updater.cpp:144-161):
+ * K = ci_P H^T S^-1, corr = K res, P_out = sym((I-KH) ci_P). */
+int xk_apply_ci(xk_handle *h, double *P_out, int ldp, const double *ci_P, int ldc, int n,
+                const double *H, int ldh, int m, const double *res, const double *S, int lds,
+                double *correction);
+
+/* ---- covariance intersection (fixed weights) ------------------------- */
+
+/* CovarianceIntersection::fuseCI, k-agent MSCKF form (src/x/ekf/ci.cpp:49-92):
+ * S = (1/w0) H P H^T + sum_i (1/w) H_i P_i H_i^T, w0 = 1 - k w,
+ * *w_result = 1/w0.  w outside (0,1] -> XK_EINVAL (the reference throws for
+ * w>1, w==0, w<-1; the NLopt branch -1<=w<0 is out of scope). */
+int xk_fuse_ci_msckf(xk_handle *h, const double *P, int ldp, int n, const double *H, int ldh, int m,
+                     int k, const double *const *Ps, const int *ns, const double *const *Hs,
+                     double w_other, double *S, int lds, double *w_result);
+
+/* Pairwise SLAM form (ci.cpp:94-127): S = P_a/(1-w) + P_b/w in measurement
+ * space, *w_result = 1/(1-w). */
+int xk_fuse_ci_slam(xk_handle *h, const double *Pa, int lda, int na, const double *Ha, int ldha,
+                    const double *Pb, int ldb, int nb, const double *Hb, int ldhb, int m,
+                    double w_other, double *S, int lds, double *w_result);
+
+/* MultiSlamUpdate::processOneMatch (src/x/vio/multi_slam_update.cpp:61-246):
+ * 3-row landmark-difference residual between own SLAM feature `feature_id`
+ * and the other agent's `o_feature_id`, chi2_3(0.9) gate, pairwise CI, and
+ * the 3 diagonal 3x3 blocks of P_j scaled by w_result.  Outputs valid iff
+ * *inlier: H (3 x n), res (3), S (3x3), P_j (n x n). */
+int xk_multi_slam_match(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses,
+                        const double *feat, int anchor_idx, int feature_id, const double *P, int ldp,
+                        int n, int n_poses_max, const double *o_C_q_G, const double *o_G_p_C,
+                        int o_n_poses, const double *o_feat, int o_anchor_idx, int o_feature_id,
+                        const double *o_P, int ldop, int no, int o_n_poses_max, double sigma_landmark,
+                        double ci_slam_w, int *inlier, double *gamma, double *H, int ldh, double *res,
+                        double *S, double *P_j, int ldpj);
+
+/* ---- inter-agent payload (SimpleState, include/x/ekf/simple_state.h:33-35,
+ * assembled at src/x/vio/vio.cpp:447-450) ------------------------------ */
+
+/* Size in doubles of the fixed all-double payload for (N, M): hdr[8] dyn[16]
+ * pos[3N] att[4N] feat[3M] anchors[M] cov[n*n]. */
+long xk_payload_doubles(int n_poses_max, int n_feat_max);
+/* Device pointer to this agent's outgoing payload, packed from the staged
+ * window/SLAM state and the CURRENT device-resident P; RCCL sends it in
+ * place.  dyn (16) = p,v,q xyzw,b_w,b_a (State::getDynamicStates,
+ * state.cpp:87-99) comes from the host. */
+int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, const double *dyn16,
+                    double **d_payload);
+
+/* ---- measurement ----------------------------------------------------- */
+
+#define XK_NSTAGE 6
+/* stage order: 0 msckf_feature, 1 slam_rows, 2 tsqr_leaf, 3 tsqr_merge,
+ * 4 kalman_gemm (all xk_gemm_f64 launches of the update), 5 kalman_chol_misc */
+typedef struct {
+  float total_ms;               /* one staged update, HIP events on the handle's stream */
+  float stage_ms[XK_NSTAGE];    /* per update, summed over the stage's launches */
+  int stage_launches[XK_NSTAGE];
+  char stage_name[XK_NSTAGE][32];
+  int n, c1, k_tracks, rows_stacked, n_leaf, n_levels;
+} xk_timing;
+
+/* Runs `steps` staged visual updates back to back on the handle's stream
+ * (each from the same staged prior; results of the last one stay resident)
+ * and reports HIP-event timings averaged per update. */
+int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_timing *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XK_H_ */

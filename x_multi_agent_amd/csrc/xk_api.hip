@@ -1,0 +1,898 @@
+// xk_api.hip -- C ABI (include/xk.h) of the MI355X-native xVIO EKF-update engine.
+// Host-side orchestration only: every number in a result is produced by the
+// HIP kernels in xk_feature.hip.h / xk_linalg.hip.h / xk_ci.hip.h.
+#include "../../include/xk.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "xk_chi2_table.h"
+#include "xk_feature.hip.h"
+#include "xk_linalg.hip.h"
+#include "xk_ci.hip.h"
+
+#define XK_VERSION_NUM 100
+
+struct xk_handle {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[16];
+  // capacities
+  int N, Mmax, Kmax, n, na, C1, C1P, DB, NBT, ntiles_max, nleaf_max, qr_threads;
+  // staged problem
+  int n_poses, K, M;
+  size_t obs_cap;
+  double *d_q, *d_p, *d_obs, *d_feat, *d_zlast;
+  int *d_trk_off, *d_anchor, *d_tsz;
+  double *d_P, *d_Pout;
+  double *d_chi95, *d_chi90;
+  double *d_A;
+  int *d_tile_rows;
+  int *d_inl, *d_inl_s, *d_gn;
+  double *d_gam, *d_gam_s, *d_gpf;
+  double *d_R;
+  int nleaf, nlevels;   // of the last compression
+  bool have_rows, have_R;
+  double sigma_img;
+  // update workspace
+  int CM, LDA;
+  double *d_Maug, *d_X, *d_Linv, *d_corr, *d_ct, *d_tmpH, *d_tmpS, *d_tmpP, *d_rdiag, *d_tmpz;
+  int *d_status;
+  // CI / payload
+  double *d_payload;
+  double *d_ci;  // scratch for the CI kernels
+  // host pinned staging
+  double *h_pin;
+  size_t h_pin_doubles;
+  int *h_pin_i;
+  char err[256];
+};
+
+static int fail(xk_handle *h, int code, const char *what, hipError_t e = hipSuccess) {
+  if (h) {
+    if (e != hipSuccess) snprintf(h->err, sizeof(h->err), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(h->err, sizeof(h->err), "%s", what);
+  }
+  return code;
+}
+#define HIPCHK(h, call)                                                   \
+  do {                                                                    \
+    hipError_t e_ = (call);                                               \
+    if (e_ != hipSuccess) return fail((h), XK_EDEVICE, #call, e_);        \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+extern "C" const char *xk_strerror(int s) {
+  switch (s) {
+    case XK_OK: return "ok";
+    case XK_EINVAL: return "invalid argument";
+    case XK_ESINGULAR: return "innovation covariance not positive definite";
+    case XK_ENAN: return "non-finite value";
+    case XK_EDEVICE: return "HIP runtime error";
+    case XK_ENOMEM: return "out of memory";
+    case XK_ECAPACITY: return "problem exceeds handle capacity";
+  }
+  return "unknown status";
+}
+extern "C" const char *xk_last_error(const xk_handle *h) { return h ? h->err : "null handle"; }
+extern "C" int xk_version(void) { return XK_VERSION_NUM; }
+extern "C" void *xk_stream(xk_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t count) {
+  return hipMalloc((void **)p, sizeof(T) * (count ? count : 1));
+}
+
+extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out) {
+  if (!out || n_poses_max < 2 || n_poses_max > 64 || n_feat_max < 0 || k_max < 0) return XK_EINVAL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XK_EDEVICE;
+  if (device < 0 || device >= ndev) return XK_EINVAL;
+  xk_handle *h = (xk_handle *)calloc(1, sizeof(xk_handle));
+  if (!h) return XK_ENOMEM;
+  h->device = device;
+  h->N = n_poses_max;
+  h->Mmax = n_feat_max;
+  h->Kmax = k_max;
+  h->n = XK_CORE + 6 * n_poses_max + 3 * n_feat_max;
+  h->na = h->n - XK_CORE;
+  h->C1 = h->na + 1;
+  h->qr_threads = round_up(h->C1, 64);
+  if (h->qr_threads > 512) { free(h); return XK_ECAPACITY; }
+  h->C1P = h->qr_threads;
+  const int dmax = 2 * n_poses_max - 3;
+  h->NBT = dmax <= 20 ? 20 : dmax <= 40 ? 40 : dmax <= 60 ? 60 : dmax <= 100 ? 100 : 60;
+  h->DB = round_up(dmax, 4);
+  const int slam_tiles = (2 * n_feat_max + h->DB - 1) / h->DB;
+  h->ntiles_max = k_max + slam_tiles;
+  h->nleaf_max = 256;
+  h->CM = round_up(h->n + 1, 16);
+  h->LDA = h->CM + round_up(h->n + 1, 16);
+  HIPCHK(h, hipSetDevice(device));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
+  const size_t nn = (size_t)h->n * h->n;
+  h->obs_cap = (size_t)k_max * n_poses_max;
+  HIPCHK(h, dalloc(&h->d_q, 4 * (size_t)n_poses_max));
+  HIPCHK(h, dalloc(&h->d_p, 3 * (size_t)n_poses_max));
+  HIPCHK(h, dalloc(&h->d_obs, 2 * h->obs_cap));
+  HIPCHK(h, dalloc(&h->d_trk_off, (size_t)k_max + 1));
+  HIPCHK(h, dalloc(&h->d_feat, 3 * (size_t)n_feat_max));
+  HIPCHK(h, dalloc(&h->d_zlast, 2 * (size_t)n_feat_max));
+  HIPCHK(h, dalloc(&h->d_anchor, (size_t)n_feat_max));
+  HIPCHK(h, dalloc(&h->d_tsz, (size_t)n_feat_max));
+  HIPCHK(h, dalloc(&h->d_P, nn));
+  HIPCHK(h, dalloc(&h->d_Pout, nn));
+  HIPCHK(h, dalloc(&h->d_chi95, (size_t)XK_CHI2_LEN));
+  HIPCHK(h, dalloc(&h->d_chi90, (size_t)XK_CHI2_LEN));
+  HIPCHK(h, hipMemcpy(h->d_chi95, XK_CHI2_095, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
+  HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
+  HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
+  HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
+  HIPCHK(h, dalloc(&h->d_inl_s, (size_t)n_feat_max));
+  HIPCHK(h, dalloc(&h->d_gn, (size_t)k_max));
+  HIPCHK(h, dalloc(&h->d_gam, (size_t)k_max));
+  HIPCHK(h, dalloc(&h->d_gam_s, (size_t)n_feat_max));
+  HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
+  HIPCHK(h, dalloc(&h->d_R, (size_t)h->nleaf_max * h->C1P * h->C1P));
+  HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
+  HIPCHK(h, dalloc(&h->d_X, (size_t)h->CM * h->LDA));
+  HIPCHK(h, dalloc(&h->d_Linv, (size_t)XK_CHOL_NB * XK_CHOL_NB));
+  HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n));
+  HIPCHK(h, dalloc(&h->d_ct, (size_t)h->n));
+  HIPCHK(h, dalloc(&h->d_tmpH, (size_t)h->CM * h->n));
+  HIPCHK(h, dalloc(&h->d_tmpS, (size_t)h->CM * h->CM));
+  HIPCHK(h, dalloc(&h->d_tmpP, nn));
+  HIPCHK(h, dalloc(&h->d_rdiag, (size_t)h->CM));
+  HIPCHK(h, dalloc(&h->d_tmpz, (size_t)h->CM));
+  HIPCHK(h, dalloc(&h->d_status, (size_t)4));
+  HIPCHK(h, dalloc(&h->d_payload, (size_t)xk_payload_doubles(n_poses_max, n_feat_max)));
+  HIPCHK(h, dalloc(&h->d_ci, (size_t)4 * nn + 64 * (size_t)h->n + 1024));
+  h->h_pin_doubles = nn + 8 * (size_t)h->n + 4 * (size_t)k_max + 4 * (size_t)n_feat_max + 1024;
+  HIPCHK(h, hipHostMalloc((void **)&h->h_pin, sizeof(double) * h->h_pin_doubles));
+  HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 64)));
+  HIPCHK(h, hipMemset(h->d_status, 0, sizeof(int) * 4));
+  HIPCHK(h, hipMemset(h->d_tile_rows, 0, sizeof(int) * (size_t)h->ntiles_max));
+  h->sigma_img = 0.0;
+  *out = h;
+  return XK_OK;
+}
+
+extern "C" int xk_destroy(xk_handle *h) {
+  if (!h) return XK_OK;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  void *ptrs[] = {h->d_q, h->d_p, h->d_obs, h->d_trk_off, h->d_feat, h->d_zlast, h->d_anchor, h->d_tsz,
+                  h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_inl, h->d_inl_s,
+                  h->d_gn, h->d_gam, h->d_gam_s, h->d_gpf, h->d_R, h->d_Maug, h->d_X, h->d_Linv, h->d_corr,
+                  h->d_ct, h->d_tmpH, h->d_tmpS, h->d_tmpP, h->d_rdiag, h->d_tmpz, h->d_status, h->d_payload,
+                  h->d_ci};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  if (h->h_pin) hipHostFree(h->h_pin);
+  if (h->h_pin_i) hipHostFree(h->h_pin_i);
+  for (auto &e : h->ev)
+    if (e) hipEventDestroy(e);
+  if (h->stream) hipStreamDestroy(h->stream);
+  free(h);
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// staging
+// ---------------------------------------------------------------------------
+extern "C" int xk_stage_window(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses) {
+  if (!h || !C_q_G || !G_p_C) return XK_EINVAL;
+  if (n_poses < 2 || n_poses > h->N) return fail(h, XK_ECAPACITY, "n_poses outside [2, n_poses_max]");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->d_q, C_q_G, sizeof(double) * 4 * n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_p, G_p_C, sizeof(double) * 3 * n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->n_poses = n_poses;
+  h->have_rows = h->have_R = false;
+  return XK_OK;
+}
+
+extern "C" int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *obs_xy, int K) {
+  if (!h || K < 0 || (K > 0 && (!trk_off || !obs_xy))) return XK_EINVAL;
+  if (K > h->Kmax) return fail(h, XK_ECAPACITY, "K > k_max");
+  if (K > 0) {
+    if (trk_off[0] != 0) return fail(h, XK_EINVAL, "trk_off[0] != 0");
+    for (int k = 0; k < K; ++k) {
+      const int L = trk_off[k + 1] - trk_off[k];
+      if (L < 2 || L > h->N) return fail(h, XK_EINVAL, "track length outside [2, n_poses_max]");
+    }
+    if ((size_t)trk_off[K] > h->obs_cap) return fail(h, XK_ECAPACITY, "too many observations");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_trk_off, trk_off, sizeof(int) * (K + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_obs, obs_xy, sizeof(double) * 2 * trk_off[K], hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  h->K = K;
+  h->have_rows = h->have_R = false;
+  // remember the longest track for validation against n_poses at build time
+  int lmax = 0;
+  for (int k = 0; k < K; ++k) lmax = std::max(lmax, trk_off[k + 1] - trk_off[k]);
+  h->h_pin_i[0] = lmax;
+  return XK_OK;
+}
+
+extern "C" int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor_idxs, const int *track_sizes,
+                             const double *z_last, int M) {
+  if (!h || M < 0 || (M > 0 && (!feat || !anchor_idxs || !track_sizes || !z_last))) return XK_EINVAL;
+  if (M > h->Mmax) return fail(h, XK_ECAPACITY, "M > n_feat_max");
+  if (M > 0) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_feat, feat, sizeof(double) * 3 * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_anchor, anchor_idxs, sizeof(int) * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tsz, track_sizes, sizeof(int) * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_zlast, z_last, sizeof(double) * 2 * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  h->M = M;
+  h->have_rows = h->have_R = false;
+  return XK_OK;
+}
+
+extern "C" int xk_upload_P(xk_handle *h, const double *P, int ldp, int n) {
+  if (!h || !P || n != h->n || ldp < n) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_P, sizeof(double) * n, P, sizeof(double) * ldp, sizeof(double) * n, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return XK_OK;
+}
+
+extern "C" int xk_download_P(xk_handle *h, double *P, int ldp, int n) {
+  if (!h || !P || n != h->n || ldp < n) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(P, sizeof(double) * ldp, h->d_P, sizeof(double) * n, sizeof(double) * n, n,
+                             hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// launch helpers (all asynchronous on h->stream)
+// ---------------------------------------------------------------------------
+static int launch_build(xk_handle *h, double sigma_img) {
+  if (h->n_poses < 2) return fail(h, XK_EINVAL, "window not staged");
+  if (h->K > 0 && h->h_pin_i[0] > h->n_poses) return fail(h, XK_EINVAL, "track longer than the staged window");
+  const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
+  if (h->K > 0) {
+    XkFeatArgs a;
+    a.q = h->d_q; a.p = h->d_p; a.n_poses = h->n_poses; a.n_poses_max = h->N;
+    a.trk_off = h->d_trk_off; a.obs = h->d_obs; a.K = h->K;
+    a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
+    a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
+    a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
+    const size_t lds = xk_feature_lds_bytes(h->n_poses);
+    hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
+  }
+  if (h->M > 0) {
+    XkSlamArgs s;
+    s.q = h->d_q; s.p = h->d_p; s.n_poses = h->n_poses; s.n_poses_max = h->N;
+    s.feat = h->d_feat; s.anchor_idxs = h->d_anchor; s.track_sizes = h->d_tsz; s.z_last = h->d_zlast; s.M = h->M;
+    s.P = h->d_P; s.n = h->n; s.var_img = sigma_img * sigma_img; s.chi90 = h->d_chi90; s.chi_len = XK_CHI2_LEN;
+    s.A = h->d_A + (size_t)h->K * h->DB * h->C1P; s.DB = h->DB; s.C1P = h->C1P; s.na = h->na;
+    s.inlier = h->d_inl_s; s.gamma = h->d_gam_s;
+    hipLaunchKernelGGL(xk_slam_rows, dim3(h->M), dim3(64), 0, h->stream, s);
+    // rows per SLAM tile (gated-out features leave zero rows, as in the reference)
+    std::vector<int> tr(slam_tiles);
+    for (int t = 0; t < slam_tiles; ++t) tr[t] = std::min(h->DB, 2 * h->M - t * h->DB);
+    for (int t = 0; t < slam_tiles; ++t) h->h_pin_i[8 + t] = tr[t];
+    if (hipMemcpyAsync(h->d_tile_rows + h->K, h->h_pin_i + 8, sizeof(int) * slam_tiles, hipMemcpyHostToDevice,
+                       h->stream) != hipSuccess)
+      return fail(h, XK_EDEVICE, "tile_rows upload");
+  }
+  h->sigma_img = sigma_img;
+  h->have_rows = true;
+  h->have_R = false;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "build launch", e);
+  return XK_OK;
+}
+
+template <int NB, int MAXT>
+static void launch_tsqr_t(xk_handle *h, XkQrArgs &a, int *levels, hipEvent_t mid) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_leaf<NB, MAXT>), dim3(a.nleaf), dim3(h->qr_threads), 0, h->stream, a);
+  if (mid) hipEventRecord(mid, h->stream);
+  int lv = 0;
+  for (int s = 1; s < a.nleaf; s *= 2) {
+    a.stride = s;
+    const int grid = (a.nleaf + 2 * s - 1) / (2 * s);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_merge<NB, MAXT>), dim3(grid), dim3(h->qr_threads), 0, h->stream, a);
+    ++lv;
+  }
+  *levels = lv;
+}
+
+static int pick_nleaf(xk_handle *h, int ntiles) {
+  const char *env = getenv("XK_NLEAF");
+  int nl;
+  if (env && atoi(env) > 0) nl = atoi(env);
+  else {
+    nl = 1;
+    while (nl * 2 * 3 <= ntiles && nl * 2 <= h->nleaf_max) nl *= 2;  // >= 3 tiles per leaf
+  }
+  if (nl > h->nleaf_max) nl = h->nleaf_max;
+  if (nl > ntiles) nl = ntiles > 0 ? ntiles : 1;
+  return nl;
+}
+
+static int launch_tsqr(xk_handle *h, hipEvent_t mid = nullptr) {
+  if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
+  const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
+  XkQrArgs a;
+  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = h->K + slam_tiles;
+  a.DB = h->DB; a.C1P = h->C1P; a.C1 = h->C1; a.R = h->d_R; a.stride = 1;
+  a.nleaf = pick_nleaf(h, a.ntiles);
+  int lv = 0;
+  if (h->qr_threads <= 256) {  // one wave per SIMD: up to 512 VGPRs for the register-resident row block
+    switch (h->NBT) {
+      case 20: launch_tsqr_t<20, 256>(h, a, &lv, mid); break;
+      case 40: launch_tsqr_t<40, 256>(h, a, &lv, mid); break;
+      case 100: launch_tsqr_t<100, 256>(h, a, &lv, mid); break;
+      default: launch_tsqr_t<60, 256>(h, a, &lv, mid); break;
+    }
+  } else {  // two waves per SIMD: 256 VGPRs, row blocks of at most 60 (taller tiles take two passes)
+    switch (h->NBT) {
+      case 20: launch_tsqr_t<20, 512>(h, a, &lv, mid); break;
+      case 40: launch_tsqr_t<40, 512>(h, a, &lv, mid); break;
+      default: launch_tsqr_t<60, 512>(h, a, &lv, mid); break;
+    }
+  }
+  h->nleaf = a.nleaf;
+  h->nlevels = lv;
+  h->have_R = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "tsqr launch", e);
+  return XK_OK;
+}
+
+static void gemm(xk_handle *h, const XkGemmArgs &g) {
+  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  if (tiles <= 0) return;
+  hipLaunchKernelGGL(xk_gemm_f64, dim3((tiles + 3) / 4), dim3(256), 0, h->stream, g);
+}
+
+struct UpdateSpec {
+  const double *T;   // c x kdim measurement matrix over state columns [col0, col0+kdim)
+  long str, stc;
+  int c, kdim, col0;
+  const double *z;   // residual (device), stride sz
+  long sz;
+  const double *rdiag;  // device vector (c) or null -> rscalar
+  double rscalar;
+  const double *S;   // externally supplied innovation covariance (device, row stride ss, col stride 1)... or null
+  long ssr, ssc;
+  const double *Pin;  // n x n col-major
+  double *Pout;       // n x n col-major (may equal neither Pin)
+  const double *ct;   // device corr_total or null
+  int cov_update;
+};
+
+// Kalman algebra on the device (updater.cpp:117-141 / :144-161).  ev (optional)
+// = {before, after-gemm-part...} is not used here; stage split is timed by the caller.
+static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum = nullptr) {
+  (void)gemm_ms_accum;
+  const int c = u.c, n = h->n, LDA = h->LDA;
+  if (c <= 0 || c > h->CM) return fail(h, XK_ECAPACITY, "measurement rows exceed workspace");
+  XkGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  // W = T * Pin[col0:col0+kdim, :]                      (H P)
+  g.A = u.T; g.sar = u.str; g.sac = u.stc;
+  g.B = u.Pin + u.col0; g.sbr = 1; g.sbc = n;
+  g.C = h->d_Maug + c; g.scr = LDA; g.scc = 1;
+  g.D = g.C; g.sdr = LDA; g.sdc = 1;
+  g.M = c; g.N = n; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 0;
+  gemm(h, g);
+  if (u.S) {
+    XkCopyArgs cp{u.S, h->d_Maug, c, c, u.ssr, u.ssc, (long)LDA, 1};
+    hipLaunchKernelGGL(xk_copy2d, dim3((c * c + 255) / 256), dim3(256), 0, h->stream, cp);
+  } else {
+    // S = W[:, col0:col0+kdim] * T^T + R               (H P H^T + R)
+    memset(&g, 0, sizeof(g));
+    g.A = h->d_Maug + c + u.col0; g.sar = LDA; g.sac = 1;
+    g.B = u.T; g.sbr = u.stc; g.sbc = u.str;
+    g.C = h->d_Maug; g.scr = LDA; g.scc = 1;
+    g.D = g.C; g.sdr = LDA; g.sdc = 1;
+    g.M = c; g.N = c; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 1;
+    g.diag = u.rdiag; g.diag_scalar = u.rscalar;
+    gemm(h, g);
+  }
+  // z' = res + H corr_tot
+  {
+    XkZArgs z{u.T, u.str, u.stc, c, u.kdim, u.col0, u.z, u.sz, u.ct, h->d_Maug + c + n, (long)LDA};
+    hipLaunchKernelGGL(xk_zprime, dim3((c + 63) / 64), dim3(64), 0, h->stream, z);
+  }
+  // blocked Cholesky with the right-hand sides carried along
+  const int ncols = c + n + 1;
+  for (int kb = 0; kb < c; kb += XK_CHOL_NB) {
+    const int nb = std::min(XK_CHOL_NB, c - kb);
+    XkCholDiagArgs d{h->d_Maug, LDA, kb, nb, h->d_Linv, h->d_status};
+    hipLaunchKernelGGL(xk_chol_diag, dim3(1), dim3(64), 0, h->stream, d);
+    const int rest = ncols - (kb + nb);
+    memset(&g, 0, sizeof(g));
+    g.A = h->d_Linv; g.sar = XK_CHOL_NB; g.sac = 1;
+    g.B = h->d_Maug + (size_t)kb * LDA + kb + nb; g.sbr = LDA; g.sbc = 1;
+    g.C = h->d_X + (size_t)kb * LDA + kb + nb; g.scr = LDA; g.scc = 1;
+    g.D = g.C; g.sdr = LDA; g.sdc = 1;
+    g.M = nb; g.N = rest; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.mode = 0;
+    gemm(h, g);
+    const int mrem = c - kb - nb;
+    if (mrem > 0) {
+      memset(&g, 0, sizeof(g));
+      g.A = h->d_X + (size_t)kb * LDA + kb + nb; g.sar = 1; g.sac = LDA;
+      g.B = g.A; g.sbr = LDA; g.sbc = 1;
+      g.C = h->d_Maug + (size_t)(kb + nb) * LDA + kb + nb; g.scr = LDA; g.scc = 1;
+      g.D = g.C; g.sdr = LDA; g.sdc = 1;
+      g.M = mrem; g.N = rest; g.K = nb; g.alpha = -1.0; g.beta = 1.0; g.mode = 0;
+      gemm(h, g);
+    }
+  }
+  // P+ = sym(P - X^T X),  X = L^-1 W                   (I-KH)P, (P+P^T)/2
+  if (u.cov_update) {
+    memset(&g, 0, sizeof(g));
+    g.A = h->d_X + c; g.sar = 1; g.sac = LDA;
+    g.B = h->d_X + c; g.sbr = LDA; g.sbc = 1;
+    g.D = u.Pin; g.sdr = 1; g.sdc = n;
+    g.C = u.Pout; g.scr = 1; g.scc = n;
+    g.M = n; g.N = n; g.K = c; g.alpha = -1.0; g.beta = 1.0; g.mode = 2;
+    gemm(h, g);
+  } else if (u.Pout != u.Pin) {
+    hipMemcpyAsync(u.Pout, u.Pin, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream);
+  }
+  XkCorrArgs cr{h->d_X, LDA, c, n, c, c + n, u.ct, h->d_corr};
+  hipLaunchKernelGGL(xk_corr, dim3((n + 63) / 64), dim3(64), 0, h->stream, cr);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "update launch", e);
+  return XK_OK;
+}
+
+static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_update) {
+  UpdateSpec u;
+  memset(&u, 0, sizeof(u));
+  u.T = h->d_R; u.str = h->C1P; u.stc = 1;      // R[0], rows 0..na-1, active columns
+  u.c = h->na; u.kdim = h->na; u.col0 = XK_CORE;
+  u.z = h->d_R + h->na; u.sz = h->C1P;           // residual column
+  u.rdiag = nullptr; u.rscalar = h->sigma_img * h->sigma_img;  // vio_updater.cpp:508-509
+  u.Pin = h->d_P; u.Pout = h->d_Pout; u.ct = d_ct; u.cov_update = cov_update;
+  return u;
+}
+
+static int read_status(xk_handle *h) {
+  int st = 0;
+  HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[4], h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  st = h->h_pin_i[4];
+  if (st != 0) {
+    hipMemsetAsync(h->d_status, 0, sizeof(int), h->stream);
+    hipStreamSynchronize(h->stream);
+    return fail(h, st, "innovation covariance not positive definite");
+  }
+  return XK_OK;
+}
+
+static int fetch_flags(xk_handle *h, int *inl, double *gam, int *inls, double *gams) {
+  if (h->K > 0 && inl) HIPCHK(h, hipMemcpyAsync(inl, h->d_inl, sizeof(int) * h->K, hipMemcpyDeviceToHost, h->stream));
+  if (h->K > 0 && gam) HIPCHK(h, hipMemcpyAsync(gam, h->d_gam, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->stream));
+  if (h->M > 0 && inls) HIPCHK(h, hipMemcpyAsync(inls, h->d_inl_s, sizeof(int) * h->M, hipMemcpyDeviceToHost, h->stream));
+  if (h->M > 0 && gams) HIPCHK(h, hipMemcpyAsync(gams, h->d_gam_s, sizeof(double) * h->M, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// public staged API
+// ---------------------------------------------------------------------------
+extern "C" int xk_msckf_build(xk_handle *h, double sigma_img, int *inlier_msckf, double *gamma_msckf,
+                              int *inlier_slam, double *gamma_slam) {
+  if (!h || !(sigma_img > 0.0)) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = launch_build(h, sigma_img);
+  if (rc != XK_OK) return rc;
+  return fetch_flags(h, inlier_msckf, gamma_msckf, inlier_slam, gamma_slam);
+}
+
+extern "C" int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z) {
+  if (!h) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = launch_tsqr(h);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (T_H || z) {
+    if (T_H && ldt < h->n) return XK_EINVAL;
+    std::vector<double> R((size_t)h->C1 * h->C1P);
+    HIPCHK(h, hipMemcpy(R.data(), h->d_R, sizeof(double) * R.size(), hipMemcpyDeviceToHost));
+    if (T_H) {
+      for (int j = 0; j < h->n; ++j)
+        for (int i = 0; i < h->n; ++i) T_H[i + (size_t)j * ldt] = 0.0;
+      // rows 0..na-1 of the triangle, placed at rows 0.. with the core columns zero
+      for (int i = 0; i < h->na; ++i)
+        for (int j = i; j < h->na; ++j) T_H[i + (size_t)(XK_CORE + j) * ldt] = R[(size_t)i * h->C1P + j];
+    }
+    if (z) {
+      for (int i = 0; i < h->n; ++i) z[i] = 0.0;
+      for (int i = 0; i < h->na; ++i) z[i] = R[(size_t)i * h->C1P + h->na];
+    }
+  }
+  return XK_OK;
+}
+
+extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_update, double *correction) {
+  if (!h || !correction) return XK_EINVAL;
+  if (!h->have_R) return fail(h, XK_EINVAL, "xk_qr_compress has not run on the staged inputs");
+  HIPCHK(h, hipSetDevice(h->device));
+  const double *dct = nullptr;
+  if (corr_total) {
+    HIPCHK(h, hipMemcpyAsync(h->d_ct, corr_total, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    dct = h->d_ct;
+  }
+  UpdateSpec u = compressed_spec(h, dct, cov_update);
+  int rc = launch_update(h, u);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+  rc = read_status(h);
+  if (rc != XK_OK) return rc;
+  std::swap(h->d_P, h->d_Pout);  // posterior becomes the resident covariance
+  h->have_rows = h->have_R = false;
+  return XK_OK;
+}
+
+extern "C" int xk_visual_update_staged(xk_handle *h, double sigma_img, double *correction, int *inlier_msckf,
+                                       double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
+  if (!h || !correction || !(sigma_img > 0.0)) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->K == 0 && h->M == 0) {  // h.size() == 0 -> no update (updater.cpp:106)
+    for (int i = 0; i < h->n; ++i) correction[i] = 0.0;
+    return XK_OK;
+  }
+  int rc = launch_build(h, sigma_img);
+  if (rc != XK_OK) return rc;
+  rc = launch_tsqr(h);
+  if (rc != XK_OK) return rc;
+  UpdateSpec u = compressed_spec(h, nullptr, 1);
+  rc = launch_update(h, u);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+  rc = fetch_flags(h, inlier_msckf, gamma_msckf, inlier_slam, gamma_slam);
+  if (rc != XK_OK) return rc;
+  rc = read_status(h);
+  if (rc != XK_OK) return rc;
+  std::swap(h->d_P, h->d_Pout);
+  h->have_rows = h->have_R = false;
+  return XK_OK;
+}
+
+extern "C" int xk_visual_update(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses,
+                                const int *trk_off, const double *obs_xy, int K, const double *feat,
+                                const int *anchor_idxs, const int *track_sizes, const double *z_last, int M,
+                                double *P, int ldp, int n, double sigma_img, double *correction,
+                                int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
+  int rc;
+  if ((rc = xk_stage_window(h, C_q_G, G_p_C, n_poses)) != XK_OK) return rc;
+  if ((rc = xk_stage_tracks(h, trk_off, obs_xy, K)) != XK_OK) return rc;
+  if ((rc = xk_stage_slam(h, feat, anchor_idxs, track_sizes, z_last, M)) != XK_OK) return rc;
+  if ((rc = xk_upload_P(h, P, ldp, n)) != XK_OK) return rc;
+  if ((rc = xk_visual_update_staged(h, sigma_img, correction, inlier_msckf, gamma_msckf, inlier_slam,
+                                    gamma_slam)) != XK_OK)
+    return rc;
+  return xk_download_P(h, P, ldp, n);
+}
+
+// ---------------------------------------------------------------------------
+// dense (unfused) Kalman algebra
+// ---------------------------------------------------------------------------
+extern "C" int xk_apply_update_dense(xk_handle *h, double *P, int ldp, int n, const double *H, int ldh, int m,
+                                     const double *res, const double *r_diag, double *correction_total,
+                                     int cov_update, double *correction) {
+  if (!h || !P || !H || !res || !r_diag || !correction || n != h->n || ldp < n || ldh < m || m <= 0) return XK_EINVAL;
+  if (m > h->CM) return fail(h, XK_ECAPACITY, "m exceeds the dense workspace (n+1 rows); compress first");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, P, sizeof(double) * ldp, sizeof(double) * n, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, H, sizeof(double) * ldh, sizeof(double) * m, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_tmpz, res, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_rdiag, r_diag, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+  const double *dct = nullptr;
+  if (correction_total) {
+    HIPCHK(h, hipMemcpyAsync(h->d_ct, correction_total, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    dct = h->d_ct;
+  }
+  UpdateSpec u;
+  memset(&u, 0, sizeof(u));
+  u.T = h->d_tmpH; u.str = 1; u.stc = m;  // column-major m x n
+  u.c = m; u.kdim = n; u.col0 = 0;
+  u.z = h->d_tmpz; u.sz = 1; u.rdiag = h->d_rdiag;
+  u.Pin = h->d_tmpP; u.Pout = h->d_Pout; u.ct = dct; u.cov_update = cov_update;
+  int rc = launch_update(h, u);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(P, sizeof(double) * ldp, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n,
+                             hipMemcpyDeviceToHost, h->stream));
+  rc = read_status(h);
+  if (rc != XK_OK) return rc;
+  if (correction_total)
+    for (int i = 0; i < n; ++i) correction_total[i] += correction[i];  // updater.cpp:140
+  return XK_OK;
+}
+
+extern "C" int xk_apply_ci(xk_handle *h, double *P_out, int ldp, const double *ci_P, int ldc, int n,
+                           const double *H, int ldh, int m, const double *res, const double *S, int lds,
+                           double *correction) {
+  if (!h || !P_out || !ci_P || !H || !res || !S || !correction || n != h->n || ldp < n || ldc < n || ldh < m ||
+      lds < m || m <= 0)
+    return XK_EINVAL;
+  if (m > h->CM) return fail(h, XK_ECAPACITY, "m exceeds the dense workspace");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, ci_P, sizeof(double) * ldc, sizeof(double) * n, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, H, sizeof(double) * ldh, sizeof(double) * m, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpS, sizeof(double) * m, S, sizeof(double) * lds, sizeof(double) * m, m,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_tmpz, res, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+  UpdateSpec u;
+  memset(&u, 0, sizeof(u));
+  u.T = h->d_tmpH; u.str = 1; u.stc = m;
+  u.c = m; u.kdim = n; u.col0 = 0;
+  u.z = h->d_tmpz; u.sz = 1;
+  u.S = h->d_tmpS; u.ssr = 1; u.ssc = m;
+  u.Pin = h->d_tmpP; u.Pout = h->d_Pout; u.ct = nullptr; u.cov_update = 1;
+  int rc = launch_update(h, u);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(P_out, sizeof(double) * ldp, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n,
+                             hipMemcpyDeviceToHost, h->stream));
+  return read_status(h);
+}
+
+// ---------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------
+extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_timing *out) {
+  if (!h || !out || steps <= 0 || warmup < 0) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  memset(out, 0, sizeof(*out));
+  const char *names[XK_NSTAGE] = {"xk_msckf_feature", "xk_slam_rows", "xk_tsqr_leaf", "xk_tsqr_merge",
+                                  "xk_kalman_update", "(unused)"};
+  for (int s = 0; s < XK_NSTAGE; ++s) snprintf(out->stage_name[s], sizeof(out->stage_name[s]), "%s", names[s]);
+  double acc[XK_NSTAGE] = {0, 0, 0, 0, 0, 0}, tot = 0;
+  for (int it = 0; it < warmup + steps; ++it) {
+    HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    int rc = launch_build(h, sigma_img);
+    if (rc != XK_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    rc = launch_tsqr(h, h->ev[2]);
+    if (rc != XK_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    UpdateSpec u = compressed_spec(h, nullptr, 1);
+    rc = launch_update(h, u);
+    if (rc != XK_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (it >= warmup) {
+      float ms;
+      hipEventElapsedTime(&ms, h->ev[0], h->ev[1]); acc[0] += ms;
+      hipEventElapsedTime(&ms, h->ev[1], h->ev[2]); acc[2] += ms;
+      hipEventElapsedTime(&ms, h->ev[2], h->ev[3]); acc[3] += ms;
+      hipEventElapsedTime(&ms, h->ev[3], h->ev[4]); acc[4] += ms;
+      hipEventElapsedTime(&ms, h->ev[0], h->ev[4]); tot += ms;
+    }
+  }
+  int rc = read_status(h);
+  if (rc != XK_OK) return rc;
+  for (int s = 0; s < XK_NSTAGE; ++s) out->stage_ms[s] = (float)(acc[s] / steps);
+  out->total_ms = (float)(tot / steps);
+  out->stage_launches[0] = (h->K > 0) + (h->M > 0);
+  out->stage_launches[2] = 1;
+  out->stage_launches[3] = h->nlevels;
+  const int nblk = (h->na + XK_CHOL_NB - 1) / XK_CHOL_NB;
+  out->stage_launches[4] = 4 + 3 * nblk;
+  out->n = h->n; out->c1 = h->C1; out->k_tracks = h->K; out->n_leaf = h->nleaf; out->n_levels = h->nlevels;
+  // stacked rows actually folded (inlier rows)
+  {
+    const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
+    std::vector<int> tr(h->K + slam_tiles);
+    HIPCHK(h, hipMemcpy(tr.data(), h->d_tile_rows, sizeof(int) * tr.size(), hipMemcpyDeviceToHost));
+    int rows = 0;
+    for (int v : tr) rows += v;
+    out->rows_stacked = rows;
+  }
+  // leave the posterior of the last step in d_Pout; the staged prior stays in d_P
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// covariance intersection (fixed weights)
+// ---------------------------------------------------------------------------
+static int check_w(double w) {  // ci.cpp:59-62,98-101 throw; -1<=w<0 is the NLopt branch (out of scope)
+  if (w > 1.0 || w == 0 || w < -1) return XK_EINVAL;
+  if (w < 0.0) return XK_EINVAL;
+  return XK_OK;
+}
+
+// S (device, m x m row-major ld m in d_tmpS) (+)= alpha * Hd (m x nn col-major) * Pd (nn x nn) * Hd^T
+static void hpht_accum(xk_handle *h, const double *Hd, const double *Pd, int m, int nn, double alpha, bool first) {
+  XkGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = Hd; g.sar = 1; g.sac = m;
+  g.B = Pd; g.sbr = 1; g.sbc = nn;
+  g.C = h->d_Maug; g.scr = nn; g.scc = 1; g.D = g.C; g.sdr = nn; g.sdc = 1;
+  g.M = m; g.N = nn; g.K = nn; g.alpha = 1.0; g.beta = 0.0;
+  gemm(h, g);  // W = H P  (m x nn, row-major ld nn)
+  memset(&g, 0, sizeof(g));
+  g.A = h->d_Maug; g.sar = nn; g.sac = 1;
+  g.B = Hd; g.sbr = m; g.sbc = 1;  // B[k][j] = H[j][k]
+  g.C = h->d_tmpS; g.scr = 1; g.scc = m; g.D = g.C; g.sdr = 1; g.sdc = m;
+  g.M = m; g.N = m; g.K = nn; g.alpha = alpha; g.beta = first ? 0.0 : 1.0;
+  gemm(h, g);
+}
+
+extern "C" int xk_fuse_ci_msckf(xk_handle *h, const double *P, int ldp, int n, const double *H, int ldh, int m,
+                                int k, const double *const *Ps, const int *ns, const double *const *Hs,
+                                double w_other, double *S, int lds, double *w_result) {
+  if (!h || !P || !H || !S || !w_result || k < 0 || m <= 0 || ldp < n || ldh < m || lds < m) return XK_EINVAL;
+  if (check_w(w_other) != XK_OK) return fail(h, XK_EINVAL, "The CI weights must be lower than 1.0 and larger 0.0");
+  if (n > h->n || m > h->CM) return fail(h, XK_ECAPACITY, "fuse_ci dims exceed workspace");
+  HIPCHK(h, hipSetDevice(h->device));
+  const double w0 = 1.0 - (double)k * w_other;
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, P, sizeof(double) * ldp, sizeof(double) * n, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, H, sizeof(double) * ldh, sizeof(double) * m, n,
+                             hipMemcpyHostToDevice, h->stream));
+  hpht_accum(h, h->d_tmpH, h->d_tmpP, m, n, 1.0 / w0, true);
+  for (int i = 0; i < k; ++i) {
+    if (ns[i] > h->n) return fail(h, XK_ECAPACITY, "other agent's state larger than workspace");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tmpP, Ps[i], sizeof(double) * (size_t)ns[i] * ns[i], hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tmpH, Hs[i], sizeof(double) * (size_t)m * ns[i], hipMemcpyHostToDevice, h->stream));
+    hpht_accum(h, h->d_tmpH, h->d_tmpP, m, ns[i], 1.0 / w_other, false);
+  }
+  HIPCHK(h, hipMemcpy2DAsync(S, sizeof(double) * lds, h->d_tmpS, sizeof(double) * m, sizeof(double) * m, m,
+                             hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *w_result = 1.0 / w0;
+  return XK_OK;
+}
+
+extern "C" int xk_fuse_ci_slam(xk_handle *h, const double *Pa, int lda, int na, const double *Ha, int ldha,
+                               const double *Pb, int ldb, int nb, const double *Hb, int ldhb, int m,
+                               double w_other, double *S, int lds, double *w_result) {
+  if (!h || !Pa || !Ha || !Pb || !Hb || !S || !w_result || m <= 0 || lda < na || ldb < nb || ldha < m || ldhb < m ||
+      lds < m)
+    return XK_EINVAL;
+  if (check_w(w_other) != XK_OK)
+    return fail(h, XK_EINVAL, "The CI weights must be lower than 1.0 and larger than 0.0");
+  if (na > h->n || nb > h->n || m > h->CM) return fail(h, XK_ECAPACITY, "fuse_ci dims exceed workspace");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * na, Pa, sizeof(double) * lda, sizeof(double) * na, na,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, Ha, sizeof(double) * ldha, sizeof(double) * m, na,
+                             hipMemcpyHostToDevice, h->stream));
+  hpht_accum(h, h->d_tmpH, h->d_tmpP, m, na, 1.0 / (1.0 - w_other), true);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * nb, Pb, sizeof(double) * ldb, sizeof(double) * nb, nb,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, Hb, sizeof(double) * ldhb, sizeof(double) * m, nb,
+                             hipMemcpyHostToDevice, h->stream));
+  hpht_accum(h, h->d_tmpH, h->d_tmpP, m, nb, 1.0 / w_other, false);
+  HIPCHK(h, hipMemcpy2DAsync(S, sizeof(double) * lds, h->d_tmpS, sizeof(double) * m, sizeof(double) * m, m,
+                             hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *w_result = 1.0 / (1.0 - w_other);
+  return XK_OK;
+}
+
+extern "C" int xk_multi_slam_match(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses,
+                                   const double *feat, int anchor_idx, int feature_id, const double *P, int ldp,
+                                   int n, int n_poses_max, const double *o_C_q_G, const double *o_G_p_C,
+                                   int o_n_poses, const double *o_feat, int o_anchor_idx, int o_feature_id,
+                                   const double *o_P, int ldop, int no, int o_n_poses_max, double sigma_landmark,
+                                   double ci_slam_w, int *inlier, double *gamma, double *H, int ldh, double *res,
+                                   double *S, double *P_j, int ldpj) {
+  if (!h || !C_q_G || !G_p_C || !feat || !P || !o_C_q_G || !o_G_p_C || !o_feat || !o_P || !inlier || !gamma || !H ||
+      !res || !S || !P_j)
+    return XK_EINVAL;
+  if (anchor_idx < 0) return fail(h, XK_EINVAL, "anchor_idx < 0");       // throws, multi_slam_update.cpp:83-85
+  if (n != h->n || ldp < n || ldop < no || ldh < 3 || ldpj < n) return XK_EINVAL;
+  const int Mf = (n - XK_CORE - 6 * n_poses_max) / 3, oMf = (no - XK_CORE - 6 * o_n_poses_max) / 3;
+  if (feature_id < 0 || feature_id >= Mf || o_feature_id < 0 || o_feature_id >= oMf || anchor_idx >= n_poses ||
+      o_anchor_idx < 0 || o_anchor_idx >= o_n_poses)
+    return XK_EINVAL;
+  if (feat[3 * feature_id + 2] == 0) return fail(h, XK_EINVAL, "rho = 0");  // throws, :86-88
+  if (check_w(ci_slam_w) != XK_OK)
+    return fail(h, XK_EINVAL, "The CI weights must be lower than 1.0 and larger than 0.0");
+  if (no > h->n || n_poses > h->N || o_n_poses > h->N) return fail(h, XK_ECAPACITY, "match dims exceed workspace");
+  HIPCHK(h, hipSetDevice(h->device));
+  // scratch layout in d_ci
+  double *d = h->d_ci;
+  double *dq = d, *dp = dq + 4 * h->N, *df = dp + 3 * h->N, *doq = df + 3 * (Mf > 0 ? Mf : 1);
+  double *dop = doq + 4 * h->N, *dof = dop + 3 * h->N, *dH = dof + 3 * (oMf > 0 ? oMf : 1);
+  double *dout = dH + 3 * (size_t)n, *dcols_f = dout + 16;
+  int *dcols = (int *)dcols_f;
+  HIPCHK(h, hipMemcpyAsync(dq, C_q_G, sizeof(double) * 4 * n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dp, G_p_C, sizeof(double) * 3 * n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(df, feat, sizeof(double) * 3 * Mf, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(doq, o_C_q_G, sizeof(double) * 4 * o_n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dop, o_G_p_C, sizeof(double) * 3 * o_n_poses, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dof, o_feat, sizeof(double) * 3 * oMf, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, P, sizeof(double) * ldp, sizeof(double) * n, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_Maug, sizeof(double) * no, o_P, sizeof(double) * ldop, sizeof(double) * no, no,
+                             hipMemcpyHostToDevice, h->stream));
+  XkSlamMatchArgs a;
+  a.q = dq; a.p = dp; a.feat = df; a.P = h->d_tmpP; a.anchor = anchor_idx; a.fid = feature_id; a.n = n; a.npm = n_poses_max;
+  a.oq = doq; a.op = dop; a.ofeat = dof; a.oP = h->d_Maug; a.oanchor = o_anchor_idx; a.ofid = o_feature_id; a.no = no;
+  a.onpm = o_n_poses_max;
+  a.var_l = sigma_landmark * sigma_landmark; a.w = ci_slam_w; a.chi = XK_CHI2_090[3];
+  a.H = dH; a.out = dout; a.cols = dcols;
+  hipLaunchKernelGGL(xk_slam_match, dim3(1), dim3(64), 0, h->stream, a);
+  XkScaleArgs sc{h->d_tmpP, h->d_Pout, n, 3, dcols, dout + 14};
+  hipLaunchKernelGGL(xk_scale_blocks, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, sc);
+  double hout[16];
+  HIPCHK(h, hipMemcpyAsync(hout, dout, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(H, sizeof(double) * ldh, dH, sizeof(double) * 3, sizeof(double) * 3, n,
+                             hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 3; ++i) res[i] = hout[i];
+  *gamma = hout[12];
+  *inlier = hout[13] != 0.0;
+  if (*inlier) {
+    for (int i = 0; i < 9; ++i) S[i] = hout[3 + i];
+    HIPCHK(h, hipMemcpy2DAsync(P_j, sizeof(double) * ldpj, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n,
+                               hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// inter-agent payload
+// ---------------------------------------------------------------------------
+extern "C" long xk_payload_doubles(int N, int M) {
+  const long n = XK_CORE + 6L * N + 3L * M;
+  return 8 + 16 + 3L * N + 4L * N + 3L * M + M + n * n;
+}
+
+__global__ void xk_pack_small(const double *hdr_dyn /*24*/, const double *p, const double *q, int n_poses,
+                              const double *feat, const int *anchors, int Mcur, int N, int M, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o_pos = 24, o_att = o_pos + 3 * N, o_feat = o_att + 4 * N, o_anc = o_feat + 3 * M, o_cov = o_anc + M;
+  if (i >= o_cov) return;
+  double v = 0.0;
+  if (i < 24) v = hdr_dyn[i];
+  else if (i < o_att) { const int t = i - o_pos; v = (t < 3 * n_poses) ? p[t] : 0.0; }
+  else if (i < o_feat) { const int t = i - o_att; v = (t < 4 * n_poses) ? q[t] : 0.0; }
+  else if (i < o_anc) { const int t = i - o_feat; v = (t < 3 * Mcur) ? feat[t] : 0.0; }
+  else { const int t = i - o_anc; v = (t < Mcur) ? (double)anchors[t] : -1.0; }
+  out[i] = v;
+}
+
+extern "C" int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, const double *dyn16,
+                               double **d_payload) {
+  if (!h || !dyn16 || !d_payload) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  double *hd = h->h_pin;
+  hd[0] = agent_id; hd[1] = timestamp; hd[2] = h->N; hd[3] = h->Mmax; hd[4] = h->n; hd[5] = h->n_poses;
+  hd[6] = 0.0; hd[7] = 0.0;
+  for (int i = 0; i < 16; ++i) hd[8 + i] = dyn16[i];
+  HIPCHK(h, hipMemcpyAsync(h->d_ci, hd, sizeof(double) * 24, hipMemcpyHostToDevice, h->stream));
+  const int small = 24 + 7 * h->N + 4 * h->Mmax;
+  hipLaunchKernelGGL(xk_pack_small, dim3((small + 255) / 256), dim3(256), 0, h->stream, h->d_ci, h->d_p, h->d_q,
+                     h->n_poses, h->d_feat, h->d_anchor, h->M, h->N, h->Mmax, h->d_payload);
+  HIPCHK(h, hipMemcpyAsync(h->d_payload + small, h->d_P, sizeof(double) * (size_t)h->n * h->n,
+                           hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *d_payload = h->d_payload;
+  return XK_OK;
+}

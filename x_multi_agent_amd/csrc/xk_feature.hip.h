@@ -1,0 +1,695 @@
+// xk_feature.hip.h -- per-feature MSCKF build and SLAM-row kernels (gfx950).
+//
+// One workgroup per MSCKF track (a5..a9 of SURVEY 8a):
+//   triangulation   src/x/vision/triangulation.cpp:48-206
+//   Jacobians + observability constraint   src/x/vio/msckf_update.cpp:328-417
+//   left-nullspace projection               msckf_update.cpp:423-432
+//   chi-square gate                         msckf_update.cpp:452-463
+// Output per inlier track: the d = 2L-3 projected rows [H0 | res0] over the
+// ACTIVE columns (state columns 15.., the 15 core columns are identically
+// zero, msckf_update.cpp:412-416) as one row-major tile for the TSQR.
+//
+// What is exploited that the reference does not: J is block-sparse (one 2x3
+// position block and one 2x3 attitude block per observation), so
+//   J P J^T      is built from 6x6 blocks of P (never the dense d x n product),
+//   A^T(.)A      is applied as three Householder reflectors on both sides,
+//   A^T J        is formed column by column from the reflectors (WY form).
+// All arithmetic is IEEE double; the results differ from the reference only
+// by summation order (basis choice of A is immaterial).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define XK_CORE 15
+#define XK_FEAT_THREADS 256
+
+struct XkFeatArgs {
+  const double *q;   // [n_poses][4] xyzw
+  const double *p;   // [n_poses][3]
+  int n_poses, n_poses_max;
+  const int *trk_off;  // [K+1]
+  const double *obs;   // [sum L][2]
+  int K;
+  const double *P;  // n x n column-major, ld = n
+  int n;
+  double var_img;
+  const double *chi95;  // chi-square 0.95 quantile, indexed by dof
+  double *A;            // tiles [ntiles][DB][C1P] row-major
+  int DB, C1P, na;      // na active columns, residual in column na
+  int *tile_rows;       // rows of tile k that hold data (0 = skip)
+  int *inlier;
+  double *gamma;
+  double *gpf;       // [K][3] triangulated landmark, world frame
+  int *gn_iters;     // [K]
+};
+
+__device__ __forceinline__ void xk_quat_to_rot(const double *q, double *r /*row-major 3x3*/) {
+  // q.normalized().toRotationMatrix(), camera -> world (msckf_update.cpp:339)
+  const double nn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double x = q[0] / nn, y = q[1] / nn, z = q[2] / nn, w = q[3] / nn;
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  r[0] = 1 - (tyy + tzz); r[1] = txy - twz;       r[2] = txz + twy;
+  r[3] = txy + twz;       r[4] = 1 - (txx + tzz); r[5] = tyz - twx;
+  r[6] = txz - twy;       r[7] = tyz + twx;       r[8] = 1 - (txx + tyy);
+}
+
+__device__ __forceinline__ double xk_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Smallest right singular vector of a 4x4 (row-major) by one-sided Jacobi;
+// stands in for cv::SVD inside cv::triangulatePoints (triangulation.cpp:93).
+__device__ inline void xk_null4(double a[4][4], double x[4]) {
+  double v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0.0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 4; ++q) {
+        double al = 0, be = 0, ga = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          al += a[i][p] * a[i][p];
+          be += a[i][q] * a[i][q];
+          ga += a[i][p] * a[i][q];
+        }
+        const double lim = sqrt(al * be);
+        if (fabs(ga) > 1e-300 && fabs(ga) > 1e-17 * lim) {
+          off = fmax(off, fabs(ga) / (lim > 0 ? lim : 1.0));
+          const double zeta = (be - al) / (2.0 * ga);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const double ap = a[i][p], aq = a[i][q];
+            a[i][p] = c * ap - s * aq;
+            a[i][q] = s * ap + c * aq;
+            const double vp = v[i][p], vq = v[i][q];
+            v[i][p] = c * vp - s * vq;
+            v[i][q] = s * vp + c * vq;
+          }
+        }
+      }
+    if (off < 1e-16) break;
+  }
+  double bn = 1e300;
+  x[0] = x[1] = x[2] = x[3] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double nn = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nn += a[i][j] * a[i][j];
+    if (nn < bn) {
+      bn = nn;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = v[i][j];
+    }
+  }
+}
+
+// Solve the symmetric 3x3 system G d = b by LU with partial pivoting
+// (Eigen's dynamic .inverse() at triangulation.cpp:193-194 is PartialPivLU).
+__device__ inline bool xk_solve3(const double G[6] /*00 01 02 11 12 22*/, const double b[3], double d[3]) {
+  double m[3][4] = {{G[0], G[1], G[2], b[0]}, {G[1], G[3], G[4], b[1]}, {G[2], G[4], G[5], b[2]}};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int piv = k;
+    double mx = fabs(m[k][k]);
+    for (int i = k + 1; i < 3; ++i)
+      if (fabs(m[i][k]) > mx) { mx = fabs(m[i][k]); piv = i; }
+    if (!(mx > 0.0)) return false;
+    if (piv != k)
+      for (int j = 0; j < 4; ++j) { double t = m[k][j]; m[k][j] = m[piv][j]; m[piv][j] = t; }
+    for (int i = k + 1; i < 3; ++i) {
+      const double f = m[i][k] / m[k][k];
+      for (int j = k; j < 4; ++j) m[i][j] -= f * m[k][j];
+    }
+  }
+  d[2] = m[2][3] / m[2][2];
+  d[1] = (m[1][3] - m[1][2] * d[2]) / m[1][1];
+  d[0] = (m[0][3] - m[0][1] * d[1] - m[0][2] * d[2]) / m[0][0];
+  return true;
+}
+
+// One observation's contribution to the Gauss-Newton normal equations
+// (triangulation.cpp:158-190).
+__device__ __forceinline__ void xk_gn_accum(const double (&dr)[3][3], const double (&dp)[3], double ox,
+                                            double oy, double alpha, double beta, double rho,
+                                            double (&acc)[10]) {
+  const double hx = dr[0][0] * alpha + dr[0][1] * beta + dr[0][2] + rho * dp[0];
+  const double hy = dr[1][0] * alpha + dr[1][1] * beta + dr[1][2] + rho * dp[1];
+  const double hz = dr[2][0] * alpha + dr[2][1] * beta + dr[2][2] + rho * dp[2];
+  const double rx = ox - hx / hz, ry = oy - hy / hz;
+  const double j1a = -1.0 / hz, j1c = hx / (hz * hz), j1d = hy / (hz * hz);
+  double jr0[3], jr1[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double j00 = (c < 2) ? dr[0][c] : dp[0];
+    const double j01 = (c < 2) ? dr[1][c] : dp[1];
+    const double j02 = (c < 2) ? dr[2][c] : dp[2];
+    jr0[c] = j1a * j00 + j1c * j02;
+    jr1[c] = j1a * j01 + j1d * j02;
+  }
+  acc[0] += jr0[0] * jr0[0] + jr1[0] * jr1[0];
+  acc[1] += jr0[0] * jr0[1] + jr1[0] * jr1[1];
+  acc[2] += jr0[0] * jr0[2] + jr1[0] * jr1[2];
+  acc[3] += jr0[1] * jr0[1] + jr1[1] * jr1[1];
+  acc[4] += jr0[1] * jr0[2] + jr1[1] * jr1[2];
+  acc[5] += jr0[2] * jr0[2] + jr1[2] * jr1[2];
+  acc[6] += jr0[0] * rx + jr1[0] * ry;
+  acc[7] += jr0[1] * rx + jr1[1] * ry;
+  acc[8] += jr0[2] * rx + jr1[2] * ry;
+  acc[9] += rx * rx + ry * ry;
+}
+
+// LDS size in bytes for n_poses window poses.
+static inline size_t xk_feature_lds_bytes(int n_poses) {
+  const int L = n_poses, m2 = 2 * L, ldm = m2 + 1;
+  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32);
+}
+
+__global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, k = blockIdx.x;
+  const int np = a.n_poses, Lmax = np;
+  const int ldm = 2 * Lmax + 1;
+  double *rot = sm;              // [np][9] camera->world, row-major
+  double *pos = rot + 9 * np;    // [np][3]
+  double *Jp = pos + 3 * np;     // [L][2][3] post-OC position blocks
+  double *Ja = Jp + 6 * Lmax;    // [L][2][3] post-OC attitude blocks
+  double *res = Ja + 6 * Lmax;   // [2L]
+  double *V = res + 2 * Lmax;    // [3][2L] Hf, then the three reflectors
+  double *Mm = V + 6 * Lmax;     // [(2L+1)][ldm] gate matrix (+ appended residual row)
+  double *scal = Mm + (size_t)(2 * Lmax + 1) * ldm;  // 32 scalars
+  // scal: 0..2 tau, 3 g01, 4 g02, 5 g12, 6..8 gpf, 9 valid, 10 bad, 11 inlier, 12 gamma
+
+  const int off = a.trk_off[k], L = a.trk_off[k + 1] - off, m2 = 2 * L, d = m2 - 3, p0 = np - L;
+
+  for (int i = tid; i < np; i += XK_FEAT_THREADS) {
+    xk_quat_to_rot(a.q + 4 * i, rot + 9 * i);
+    pos[3 * i] = a.p[3 * i];
+    pos[3 * i + 1] = a.p[3 * i + 1];
+    pos[3 * i + 2] = a.p[3 * i + 2];
+  }
+  if (tid == 0) { scal[9] = 1.0; scal[10] = 0.0; }
+  __syncthreads();
+
+  // ---- triangulation: DLT + Gauss-Newton, wave 0 (triangulation.cpp:102-206)
+  if (tid < 64) {
+    const int lane = tid;
+    const double *Ra = rot + 9 * (p0 + L - 1), *pa = pos + 3 * (p0 + L - 1);
+    const double *R1 = rot + 9 * p0, *p1 = pos + 3 * p0;
+    double alpha, beta, rho;
+    {
+      // projection matrices [R^T | -R^T p] of first and last pose (:208-216)
+      double A4[4][4], X[4];
+      double P1[3][4], P2[3][4];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double t1 = 0, t2 = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          P1[r][c] = R1[3 * c + r];
+          P2[r][c] = Ra[3 * c + r];
+          t1 -= R1[3 * c + r] * p1[c];
+          t2 -= Ra[3 * c + r] * pa[c];
+        }
+        P1[r][3] = t1;
+        P2[r][3] = t2;
+      }
+      const double o1x = a.obs[2 * (size_t)off], o1y = a.obs[2 * (size_t)off + 1];
+      const double o2x = a.obs[2 * (size_t)(off + L - 1)], o2y = a.obs[2 * (size_t)(off + L - 1) + 1];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        A4[0][c] = o1x * P1[2][c] - P1[0][c];
+        A4[1][c] = o1y * P1[2][c] - P1[1][c];
+        A4[2][c] = o2x * P2[2][c] - P2[0][c];
+        A4[3][c] = o2y * P2[2][c] - P2[1][c];
+      }
+      xk_null4(A4, X);
+      const double wx = X[0] / X[3], wy = X[1] / X[3], wz = X[2] / X[3];
+      double pc[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) pc[r] = P2[r][0] * wx + P2[r][1] * wy + P2[r][2] * wz + P2[r][3];
+      alpha = pc[0] / pc[2];
+      beta = pc[1] / pc[2];
+      rho = 1.0 / pc[2];
+    }
+    // per-lane observation geometry (lanes >= L contribute zeros)
+    double drot[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, dpos[3] = {0, 0, 0}, ox = 0, oy = 0;
+    // tracks longer than 64 are handled by a second observation per lane
+    double drot2[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, dpos2[3] = {0, 0, 0}, ox2 = 0, oy2 = 0;
+    const bool act = lane < L, act2 = lane + 64 < L;
+    if (act) {
+      const double *Ri = rot + 9 * (p0 + lane), *pi = pos + 3 * (p0 + lane);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          drot[r][c] = Ri[r] * Ra[c] + Ri[3 + r] * Ra[3 + c] + Ri[6 + r] * Ra[6 + c];  // rot_i rot_a^T
+        dpos[r] = (Ri[r] * pa[0] + Ri[3 + r] * pa[1] + Ri[6 + r] * pa[2]) -
+                  (Ri[r] * pi[0] + Ri[3 + r] * pi[1] + Ri[6 + r] * pi[2]);
+      }
+      ox = a.obs[2 * (size_t)(off + lane)];
+      oy = a.obs[2 * (size_t)(off + lane) + 1];
+    }
+    if (act2) {
+      const double *Ri = rot + 9 * (p0 + lane + 64), *pi = pos + 3 * (p0 + lane + 64);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          drot2[r][c] = Ri[r] * Ra[c] + Ri[3 + r] * Ra[3 + c] + Ri[6 + r] * Ra[6 + c];
+        dpos2[r] = (Ri[r] * pa[0] + Ri[3 + r] * pa[1] + Ri[6 + r] * pa[2]) -
+                   (Ri[r] * pi[0] + Ri[3 + r] * pi[1] + Ri[6 + r] * pi[2]);
+      }
+      ox2 = a.obs[2 * (size_t)(off + lane + 64)];
+      oy2 = a.obs[2 * (size_t)(off + lane + 64) + 1];
+    }
+    double r_norm_last = 1000.0, r_norm = 100.0;
+    int iter = 0;
+    bool ok = true;
+    while (r_norm_last - r_norm > 1e-5) {  // term, vio_updater.cpp:290 / msckf_update.h:93-96
+      iter++;
+      if (iter > 10) break;
+      double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // JtJ(00 01 02 11 12 22) Jtr(3) rr
+      if (act) xk_gn_accum(drot, dpos, ox, oy, alpha, beta, rho, acc);
+      if (act2) xk_gn_accum(drot2, dpos2, ox2, oy2, alpha, beta, rho, acc);
+#pragma unroll
+      for (int c = 0; c < 10; ++c) acc[c] = xk_wave_sum(acc[c]);
+      double dl[3];
+      if (!xk_solve3(acc, acc + 6, dl)) { ok = false; break; }
+      alpha -= dl[0];
+      beta -= dl[1];
+      rho -= dl[2];
+      r_norm_last = r_norm;
+      r_norm = sqrt(acc[9]);
+    }
+    if (lane == 0) {
+      // getGlobalFeaturePosition, msckf_update.cpp:283-304
+      for (int r = 0; r < 3; ++r)
+        scal[6 + r] = (1.0 / rho) * (Ra[3 * r] * alpha + Ra[3 * r + 1] * beta + Ra[3 * r + 2]) + pa[r];
+      if (!ok) scal[6] = nan("");
+      a.gn_iters[k] = iter;
+    }
+  }
+  __syncthreads();
+  const double gx = scal[6], gy = scal[7], gz = scal[8];
+  if (tid < 3) a.gpf[3 * (size_t)k + tid] = scal[6 + tid];
+
+  // ---- per-observation Jacobians (msckf_update.cpp:328-417)
+  for (int i = tid; i < L; i += XK_FEAT_THREADS) {
+    const double *R = rot + 9 * (p0 + i), *pp = pos + 3 * (p0 + i);
+    const double dx = gx - pp[0], dy = gy - pp[1], dz = gz - pp[2];
+    const double cx = R[0] * dx + R[3] * dy + R[6] * dz;
+    const double cy = R[1] * dx + R[4] * dy + R[7] * dz;
+    const double cz = R[2] * dx + R[5] * dy + R[8] * dz;
+    if (!(cx == cx && cy == cy && cz == cz)) scal[9] = 0.0;  // :349-357
+    const double ox = a.obs[2 * (size_t)(off + i)], oy = a.obs[2 * (size_t)(off + i) + 1];
+    res[2 * i] = ox - cx / cz;
+    res[2 * i + 1] = oy - cy / cz;
+    const double Ji[2][3] = {{1.0 / cz, 0.0, -cx / (cz * cz)}, {0.0, 1.0 / cz, -cy / (cz * cz)}};
+    double jp[2][3], ja[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)  // -Ji R^T
+        jp[r][c] = -(Ji[r][0] * R[3 * c] + Ji[r][1] * R[3 * c + 1] + Ji[r][2] * R[3 * c + 2]);
+      // Ji * Skew(c)
+      ja[r][0] = Ji[r][1] * cz - Ji[r][2] * cy;
+      ja[r][1] = -Ji[r][0] * cz + Ji[r][2] * cx;
+      ja[r][2] = Ji[r][0] * cy - Ji[r][1] * cx;
+    }
+    // observability constraint, g = (0,0,-9.81) (:393-406)
+    {
+      const double g = -9.81;
+      double u[3] = {R[2] * g, R[5] * g, R[8] * g};  // R g
+      double uu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double t = (jp[r][0] * u[0] + jp[r][1] * u[1] + jp[r][2] * u[2]) * (1.0 / uu);
+        jp[r][0] -= t * u[0];
+        jp[r][1] -= t * u[1];
+        jp[r][2] -= t * u[2];
+      }
+      // Skew(G_p_f - G_p_C) g
+      u[0] = dy * g;
+      u[1] = -dx * g;
+      u[2] = 0.0;
+      uu = u[0] * u[0] + u[1] * u[1];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const double t = (ja[r][0] * u[0] + ja[r][1] * u[1]) * (1.0 / uu);
+        ja[r][0] -= t * u[0];
+        ja[r][1] -= t * u[1];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Jp[6 * i + 3 * r + c] = jp[r][c];
+        Ja[6 * i + 3 * r + c] = ja[r][c];
+        V[c * m2 + 2 * i + r] = -jp[r][c];  // Hf block, :409
+      }
+  }
+  __syncthreads();
+
+  // ---- Householder QR of Hf (2L x 3) -> three reflectors (:423)
+  if (tid < 64) {
+    const int lane = tid;
+    for (int kk = 0; kk < 3; ++kk) {
+      double *col = V + kk * m2;
+      double tail = 0.0;
+      for (int r = lane; r < m2; r += 64)
+        if (r > kk) tail += col[r] * col[r];
+      tail = xk_wave_sum(tail);
+      const double c0 = col[kk];
+      double tau, bet, sc;
+      if (tail <= 2.2250738585072014e-308) { tau = 0.0; bet = c0; sc = 0.0; }
+      else {
+        bet = sqrt(c0 * c0 + tail);
+        if (c0 >= 0) bet = -bet;
+        tau = (bet - c0) / bet;
+        sc = 1.0 / (c0 - bet);
+      }
+      for (int r = lane; r < m2; r += 64)
+        if (r > kk) col[r] *= sc;
+      for (int c2 = kk + 1; c2 < 3; ++c2) {
+        double *cc = V + c2 * m2;
+        double w = 0.0;
+        for (int r = lane; r < m2; r += 64)
+          if (r > kk) w += col[r] * cc[r];
+        w = tau * (xk_wave_sum(w) + cc[kk]);
+        for (int r = lane; r < m2; r += 64)
+          if (r > kk) cc[r] -= w * col[r];
+        if (lane == 0) cc[kk] -= w;
+      }
+      if (lane == 0) scal[kk] = tau;
+    }
+    // make the reflectors explicit: v_k[k] = 1, v_k[r<k] = 0
+    if (lane == 0) {
+      V[0] = 1.0;
+      V[m2] = 0.0; V[m2 + 1] = 1.0;
+      V[2 * m2] = 0.0; V[2 * m2 + 1] = 0.0; V[2 * m2 + 2] = 1.0;
+    }
+    // Gram terms for the WY application
+    double g01 = 0, g02 = 0, g12 = 0;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < m2; r += 64) {
+      const double v0 = (r == 0) ? 1.0 : V[r];
+      const double v1 = (r < 1) ? 0.0 : (r == 1 ? 1.0 : V[m2 + r]);
+      const double v2 = (r < 2) ? 0.0 : (r == 2 ? 1.0 : V[2 * m2 + r]);
+      g01 += v0 * v1;
+      g02 += v0 * v2;
+      g12 += v1 * v2;
+    }
+    g01 = xk_wave_sum(g01);
+    g02 = xk_wave_sum(g02);
+    g12 = xk_wave_sum(g12);
+    if (lane == 0) { scal[3] = g01; scal[4] = g02; scal[5] = g12; }
+  }
+  __syncthreads();
+  const double tau0 = scal[0], tau1 = scal[1], tau2 = scal[2];
+  const double g01 = scal[3], g02 = scal[4], g12 = scal[5];
+
+  // ---- gate matrix M = J P J^T + sigma^2 I from 6x6 blocks of P (:452-457)
+  {
+    const int n = a.n;
+    const double *P = a.P;
+    for (int idx = tid; idx < L * L; idx += XK_FEAT_THREADS) {
+      const int ia = idx / L, ib = idx - ia * L;
+      if (ia > ib) continue;
+      const int cpa = XK_CORE + 3 * (p0 + ia), caa = cpa + 3 * a.n_poses_max;
+      const int cpb = XK_CORE + 3 * (p0 + ib), cab = cpb + 3 * a.n_poses_max;
+      const double *jpa = Jp + 6 * ia, *jaa = Ja + 6 * ia, *jpb = Jp + 6 * ib, *jab = Ja + 6 * ib;
+      double t1[2][3], t2[2][3];  // rows of J_a times P[.., pos_b cols] / P[.., att_b cols]
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double *pc1 = P + (size_t)(cpb + c) * n, *pc2 = P + (size_t)(cab + c) * n;
+        const double p00 = pc1[cpa], p01 = pc1[cpa + 1], p02 = pc1[cpa + 2];
+        const double p10 = pc1[caa], p11 = pc1[caa + 1], p12 = pc1[caa + 2];
+        const double q00 = pc2[cpa], q01 = pc2[cpa + 1], q02 = pc2[cpa + 2];
+        const double q10 = pc2[caa], q11 = pc2[caa + 1], q12 = pc2[caa + 2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          t1[r][c] = jpa[3 * r] * p00 + jpa[3 * r + 1] * p01 + jpa[3 * r + 2] * p02 + jaa[3 * r] * p10 +
+                     jaa[3 * r + 1] * p11 + jaa[3 * r + 2] * p12;
+          t2[r][c] = jpa[3 * r] * q00 + jpa[3 * r + 1] * q01 + jpa[3 * r + 2] * q02 + jaa[3 * r] * q10 +
+                     jaa[3 * r + 1] * q11 + jaa[3 * r + 2] * q12;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          double v = t1[r][0] * jpb[3 * s] + t1[r][1] * jpb[3 * s + 1] + t1[r][2] * jpb[3 * s + 2] +
+                     t2[r][0] * jab[3 * s] + t2[r][1] * jab[3 * s + 1] + t2[r][2] * jab[3 * s + 2];
+          if (ia == ib && r == s) v += a.var_img;
+          if (ia == ib && r > s) continue;  // keep the diagonal block symmetric: use upper entry
+          Mm[(size_t)(2 * ia + r) * ldm + 2 * ib + s] = v;
+          Mm[(size_t)(2 * ib + s) * ldm + 2 * ia + r] = v;
+        }
+    }
+  }
+  // residual r' = Q^T res  (wave 0), overlapped with the M build
+  if (tid < 64) {
+    const int lane = tid;
+    for (int kk = 0; kk < 3; ++kk) {
+      const double tk = scal[kk];
+      double w = 0.0;
+      for (int r = lane; r < m2; r += 64)
+        if (r >= kk) w += V[kk * m2 + r] * res[r];
+      w = tk * xk_wave_sum(w);
+      for (int r = lane; r < m2; r += 64)
+        if (r >= kk) res[r] -= w * V[kk * m2 + r];
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+
+  // ---- M <- Q^T M Q, three reflectors from the left, then from the right
+  for (int kk = 0; kk < 3; ++kk) {
+    const double tk = scal[kk];
+    const double *v = V + kk * m2;
+    if (tid < m2) {
+      double w = 0.0;
+      for (int i = kk; i < m2; ++i) w += v[i] * Mm[(size_t)i * ldm + tid];
+      w *= tk;
+      for (int i = kk; i < m2; ++i) Mm[(size_t)i * ldm + tid] -= w * v[i];
+    }
+    __syncthreads();
+  }
+  for (int kk = 0; kk < 3; ++kk) {
+    const double tk = scal[kk];
+    const double *v = V + kk * m2;
+    if (tid < m2) {
+      double *row = Mm + (size_t)tid * ldm;
+      double w = 0.0;
+      for (int j = kk; j < m2; ++j) w += row[j] * v[j];
+      w *= tk;
+      for (int j = kk; j < m2; ++j) row[j] -= w * v[j];
+    }
+    __syncthreads();
+  }
+  // appended row: y = L^-1 r0 falls out of the factorisation
+  for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)m2 * ldm + 3 + j] = res[3 + j];
+  __syncthreads();
+
+  // ---- Cholesky of S = M[3:,3:] (d x d) with the residual as row d (:457-458)
+#define XK_S(i, j) Mm[(size_t)(3 + (i)) * ldm + 3 + (j)]
+  for (int kk = 0; kk < d; ++kk) {
+    const double piv = XK_S(kk, kk);
+    if (!(piv > 0.0)) {
+      if (tid == 0) scal[10] = 1.0;
+      break;  // uniform: every thread reads the same pivot
+    }
+    const double inv = 1.0 / sqrt(piv);
+    __syncthreads();
+    for (int i = kk + 1 + tid; i <= d; i += XK_FEAT_THREADS) XK_S(i, kk) *= inv;
+    __syncthreads();
+    const int cnt = d - kk;  // rows kk+1..d
+    for (int idx = tid; idx < cnt * cnt; idx += XK_FEAT_THREADS) {
+      const int ii = idx / cnt, jj = idx - ii * cnt;
+      if (jj > ii || jj >= cnt - 1) continue;
+      XK_S(kk + 1 + ii, kk + 1 + jj) -= XK_S(kk + 1 + ii, kk) * XK_S(kk + 1 + jj, kk);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid < 64) {
+    double g = 0.0;
+    for (int j = tid; j < d; j += 64) g += XK_S(d, j) * XK_S(d, j);
+    g = xk_wave_sum(g);
+    if (tid == 0) {
+      const bool valid = scal[9] != 0.0 && gx == gx;
+      const bool bad = scal[10] != 0.0;
+      const double gam = (valid && !bad) ? g : (valid ? INFINITY : nan(""));
+      const bool inl = valid && !bad && (g < a.chi95[d]);  // :459-463
+      scal[11] = inl ? 1.0 : 0.0;
+      a.gamma[k] = gam;
+      a.inlier[k] = inl ? 1 : 0;
+      a.tile_rows[k] = inl ? d : 0;
+    }
+  }
+#undef XK_S
+  __syncthreads();
+  if (scal[11] == 0.0) return;
+
+  // ---- tile write: rows 3.. of Q^T [J | res] over the active columns (:431-432,468-479)
+  double *tile = a.A + (size_t)k * a.DB * a.C1P;
+  const int N3 = 3 * a.n_poses_max;
+  for (int c = tid; c < a.C1P; c += XK_FEAT_THREADS) {
+    if (c == a.na) {
+      for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = res[r];
+      continue;
+    }
+    int i = -1, comp = 0;
+    const double *blk = nullptr;
+    if (c < N3) { i = c / 3 - p0; comp = c % 3; blk = Jp; }
+    else if (c < 2 * N3) { i = (c - N3) / 3 - p0; comp = (c - N3) % 3; blk = Ja; }
+    if (c >= a.na || i < 0 || i >= L) {
+      for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = 0.0;
+      continue;
+    }
+    const double x0 = blk[6 * i + comp], x1 = blk[6 * i + 3 + comp];
+    const int r0 = 2 * i;
+    const double a0 = V[r0] * x0 + V[r0 + 1] * x1;
+    const double a1 = V[m2 + r0] * x0 + V[m2 + r0 + 1] * x1;
+    const double a2 = V[2 * m2 + r0] * x0 + V[2 * m2 + r0 + 1] * x1;
+    const double w0 = tau0 * a0;
+    const double w1 = tau1 * (a1 - w0 * g01);
+    const double w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
+    for (int r = 3; r < m2; ++r) {
+      double v = -w0 * V[r] - w1 * V[m2 + r] - w2 * V[2 * m2 + r];
+      if (r == r0) v += x0;
+      if (r == r0 + 1) v += x1;
+      tile[(size_t)(r - 3) * a.C1P + c] = v;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// SLAM rows (src/x/vio/slam_update.cpp:49-214): one 64-thread workgroup per
+// persistent feature; two rows at slot 2j of the SLAM tiles (zero if gated out).
+// ----------------------------------------------------------------------------
+struct XkSlamArgs {
+  const double *q, *p;
+  int n_poses, n_poses_max;
+  const double *feat;      // [3M]
+  const int *anchor_idxs;  // [M]
+  const int *track_sizes;  // [M]
+  const double *z_last;    // [M][2]
+  int M;
+  const double *P;
+  int n;
+  double var_img;
+  const double *chi90;  // chi-square 0.9 quantile by dof
+  int chi_len;
+  double *A;  // tile base of the FIRST slam tile
+  int DB, C1P, na;
+  int *inlier;
+  double *gamma;
+};
+
+__global__ __launch_bounds__(64) void xk_slam_rows(XkSlamArgs a) {
+  __shared__ double hv[2][15];  // values of the up-to-15 nonzero columns
+  __shared__ int hc[15];        // their ACTIVE column indices (-1 unused)
+  __shared__ double rs[2];
+  __shared__ int ok;
+  const int j = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) {
+    for (int c = 0; c < 15; ++c) { hc[c] = -1; hv[0][c] = hv[1][c] = 0.0; }
+    const double al = a.feat[3 * j], be = a.feat[3 * j + 1], rho = a.feat[3 * j + 2];
+    const int an = a.anchor_idxs[j], pos = a.n_poses - 1, N3 = 3 * a.n_poses_max;
+    double Ra[9], Rn[9];
+    xk_quat_to_rot(a.q + 4 * an, Ra);
+    xk_quat_to_rot(a.q + 4 * pos, Rn);
+    double gp[3], dl[3], c[3];
+    for (int r = 0; r < 3; ++r) gp[r] = 1.0 / rho * (Ra[3 * r] * al + Ra[3 * r + 1] * be + Ra[3 * r + 2]) + a.p[3 * an + r];
+    for (int r = 0; r < 3; ++r) dl[r] = gp[r] - a.p[3 * pos + r];
+    for (int r = 0; r < 3; ++r) c[r] = Rn[r] * dl[0] + Rn[3 + r] * dl[1] + Rn[6 + r] * dl[2];
+    rs[0] = a.z_last[2 * j] - c[0] / c[2];
+    rs[1] = a.z_last[2 * j + 1] - c[1] / c[2];
+    const int fcol = 2 * N3 + 3 * j;  // active index of the feature columns
+    if (an == pos) {  // :120-131
+      hc[12] = fcol; hc[13] = fcol + 1; hc[14] = fcol + 2;
+      hv[0][12] = 1.0; hv[1][13] = 1.0;
+    } else {
+      const double Ji[2][3] = {{1.0 / c[2], 0.0, -c[0] / (c[2] * c[2])}, {0.0, 1.0 / c[2], -c[1] / (c[2] * c[2])}};
+      double RtRa[9], RS[9], RM[9];
+      for (int x = 0; x < 3; ++x)
+        for (int y = 0; y < 3; ++y) RtRa[3 * x + y] = Rn[x] * Ra[y] + Rn[3 + x] * Ra[3 + y] + Rn[6 + x] * Ra[6 + y];
+      const double sk[9] = {0, -1.0, be, 1.0, 0, -al, -be, al, 0};  // Skew(alpha,beta,1)
+      const double mat[9] = {1, 0, -al / rho, 0, 1, -be / rho, 0, 0, -1.0 / rho};
+      for (int x = 0; x < 3; ++x)
+        for (int y = 0; y < 3; ++y) {
+          RS[3 * x + y] = RtRa[3 * x] * sk[y] + RtRa[3 * x + 1] * sk[3 + y] + RtRa[3 * x + 2] * sk[6 + y];
+          RM[3 * x + y] = RtRa[3 * x] * mat[y] + RtRa[3 * x + 1] * mat[3 + y] + RtRa[3 * x + 2] * mat[6 + y];
+        }
+      for (int y = 0; y < 3; ++y) {
+        hc[y] = 3 * pos + y;           // J_position
+        hc[3 + y] = N3 + 3 * pos + y;  // J_attitude
+        hc[6 + y] = 3 * an + y;        // J_anchor_pos
+        hc[9 + y] = N3 + 3 * an + y;   // J_anchor_att
+        hc[12 + y] = fcol + y;         // Hf
+      }
+      for (int x = 0; x < 2; ++x) {
+        const double sc[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+        for (int y = 0; y < 3; ++y) {
+          const double jpos = -(Ji[x][0] * Rn[3 * y] + Ji[x][1] * Rn[3 * y + 1] + Ji[x][2] * Rn[3 * y + 2]);
+          hv[x][y] = jpos;
+          hv[x][3 + y] = Ji[x][0] * sc[0][y] + Ji[x][1] * sc[1][y] + Ji[x][2] * sc[2][y];
+          hv[x][6 + y] = -jpos;
+          hv[x][9 + y] = -1.0 / rho * (Ji[x][0] * RS[y] + Ji[x][1] * RS[3 + y] + Ji[x][2] * RS[6 + y]);
+          hv[x][12 + y] = 1.0 / rho * (Ji[x][0] * RM[y] + Ji[x][1] * RM[3 + y] + Ji[x][2] * RM[6 + y]);
+        }
+      }
+    }
+    // gate (:191-199): S = h P h^T + sigma^2 I over the nonzero columns
+    double S[2][2] = {{a.var_img, 0}, {0, a.var_img}};
+    for (int c1 = 0; c1 < 15; ++c1) {
+      if (hc[c1] < 0) continue;
+      for (int c2 = 0; c2 < 15; ++c2) {
+        if (hc[c2] < 0) continue;
+        const double pv = a.P[(size_t)(XK_CORE + hc[c1]) + (size_t)(XK_CORE + hc[c2]) * a.n];
+        for (int x = 0; x < 2; ++x)
+          for (int y = 0; y < 2; ++y) S[x][y] += hv[x][c1] * pv * hv[y][c2];
+      }
+    }
+    const double det = S[0][0] * S[1][1] - S[0][1] * S[1][0];
+    const double i00 = S[1][1] / det, i01 = -S[0][1] / det, i10 = -S[1][0] / det, i11 = S[0][0] / det;
+    const double g = rs[0] * (i00 * rs[0] + i01 * rs[1]) + rs[1] * (i10 * rs[0] + i11 * rs[1]);
+    const int dof = 2 * a.track_sizes[j];
+    const double chi = (dof < a.chi_len) ? a.chi90[dof] : INFINITY;
+    ok = (g < chi) ? 1 : 0;
+    a.gamma[j] = g;
+    a.inlier[j] = ok;
+  }
+  __syncthreads();
+  const int row = 2 * j;
+  double *r0 = a.A + ((size_t)(row / a.DB) * a.DB + (row % a.DB)) * a.C1P;
+  double *r1 = a.A + ((size_t)((row + 1) / a.DB) * a.DB + ((row + 1) % a.DB)) * a.C1P;
+  for (int c = lane; c < a.C1P; c += 64) {
+    double v0 = 0.0, v1 = 0.0;
+    if (ok) {
+      if (c == a.na) { v0 = rs[0]; v1 = rs[1]; }
+      else
+        for (int t = 0; t < 15; ++t)
+          if (hc[t] == c) { v0 = hv[0][t]; v1 = hv[1][t]; }  // later blocks overwrite earlier ones
+    }
+    r0[c] = v0;
+    r1[c] = v1;
+  }
+}

@@ -1,0 +1,321 @@
+// xk_linalg.hip.h -- Householder TSQR, fp64-MFMA GEMM and blocked Cholesky
+// kernels for the EKF update (gfx950).
+//
+//   TSQR            replaces VioUpdater::applyQRDecomposition
+//                   (src/x/vio/vio_updater.cpp:487-512)
+//   GEMM / Cholesky replace the Eigen products and S.inverse() of
+//                   Updater::applyUpdate / applyCI (src/x/ekf/updater.cpp:117-161)
+#pragma once
+#include <hip/hip_runtime.h>
+
+// ----------------------------------------------------------------------------
+// TSQR: structured Householder update  R <- qr([R; B])
+//
+// One thread owns one column.  A row block B (up to NB rows) lives in the
+// owning thread's registers; R lives in global memory (L2-resident), row k is
+// touched exactly once per pass, at step k, with a coalesced read/write.  At
+// step k the owner of column k publishes its column and the reflector scalars
+// through LDS; every thread to its right applies the reflector to its own
+// column.  The reflector of step k only involves R[k][k] and B[:,k]
+// (rows of R below k are zero), i.e. v = [1; scale * B[:,k]].
+// ----------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void xk_qr_pass(double (&b)[NB], double *__restrict__ Rg, int ldr, int C1,
+                                           int kstart, bool first, double *vbuf /*[2][NB]*/,
+                                           double *sc /*[2][2]*/) {
+  const int j = threadIdx.x;
+  for (int k = kstart; k < C1; ++k) {
+    const int pb = k & 1;
+    double rkj = 0.0;
+    if (!first && j >= k && j < C1) rkj = Rg[(size_t)k * ldr + j];
+    if (j == k) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        s += b[r] * b[r];
+        vbuf[pb * NB + r] = b[r];
+      }
+      double tau, scale, beta;
+      if (s <= 2.2250738585072014e-308) {
+        tau = 0.0; scale = 0.0; beta = rkj;
+      } else {
+        beta = sqrt(rkj * rkj + s);
+        if (rkj >= 0) beta = -beta;
+        tau = (beta - rkj) / beta;
+        scale = 1.0 / (rkj - beta);
+      }
+      sc[pb * 2] = tau;
+      sc[pb * 2 + 1] = scale;
+      if (first || tau != 0.0) Rg[(size_t)k * ldr + k] = beta;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) b[r] = 0.0;
+    }
+    __syncthreads();
+    const double tau = sc[pb * 2];
+    if (j > k && j < C1) {
+      if (tau != 0.0) {
+        const double scale = sc[pb * 2 + 1];
+        double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+        for (int r = 0; r + 1 < NB; r += 2) {
+          d0 += vbuf[pb * NB + r] * b[r];
+          d1 += vbuf[pb * NB + r + 1] * b[r + 1];
+        }
+        if (NB & 1) d0 += vbuf[pb * NB + NB - 1] * b[NB - 1];
+        const double w = tau * (rkj + scale * (d0 + d1));
+        Rg[(size_t)k * ldr + j] = rkj - w;
+        const double ws = w * scale;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) b[r] -= ws * vbuf[pb * NB + r];
+      } else if (first) {
+        Rg[(size_t)k * ldr + j] = 0.0;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+struct XkQrArgs {
+  const double *A;       // tiles [ntiles][DB][C1P] row-major
+  const int *tile_rows;  // valid rows per tile, 0 = skip
+  int ntiles, DB, C1P, C1;
+  double *R;  // [nleaf][C1P][C1P] row-major upper-triangular factors
+  int nleaf;
+  int stride;  // merge: R[g*2*stride] <- qr([R[g*2*stride]; R[g*2*stride+stride]])
+};
+
+// Leaf: workgroup g folds tiles g, g+nleaf, g+2*nleaf, ... into R[g].
+template <int NB, int MAXT>
+__global__ __launch_bounds__(MAXT) void xk_tsqr_leaf(XkQrArgs a) {
+  __shared__ double vbuf[2 * NB];
+  __shared__ double sc[4];
+  const int g = blockIdx.x, j = threadIdx.x;
+  double *Rg = a.R + (size_t)g * a.C1P * a.C1P;
+  bool first = true;
+  double b[NB];
+  for (int t = g; t < a.ntiles; t += a.nleaf) {
+    const int rows = a.tile_rows[t];
+    if (rows == 0) continue;
+    const double *tile = a.A + (size_t)t * a.DB * a.C1P;
+    for (int r0 = 0; r0 < rows; r0 += NB) {
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+        b[r] = (r0 + r < rows && j < a.C1) ? tile[(size_t)(r0 + r) * a.C1P + j] : 0.0;
+      xk_qr_pass<NB>(b, Rg, a.C1P, a.C1, 0, first, vbuf, sc);
+      first = false;
+    }
+  }
+  if (first)  // no data at all: define R = 0 so the merges stay well formed
+    for (int k = 0; k < a.C1; ++k)
+      if (j >= k && j < a.C1) Rg[(size_t)k * a.C1P + j] = 0.0;
+}
+
+// Merge: the source triangle is fed as row blocks; rows [r0, r0+NB) have
+// leading zeros up to column r0, so the pass starts at step r0.
+template <int NB, int MAXT>
+__global__ __launch_bounds__(MAXT) void xk_tsqr_merge(XkQrArgs a) {
+  __shared__ double vbuf[2 * NB];
+  __shared__ double sc[4];
+  const int g = blockIdx.x, j = threadIdx.x;
+  const int dst = g * 2 * a.stride, src = dst + a.stride;
+  if (src >= a.nleaf) return;
+  double *Rd = a.R + (size_t)dst * a.C1P * a.C1P;
+  const double *Rs = a.R + (size_t)src * a.C1P * a.C1P;
+  double b[NB];
+  for (int r0 = 0; r0 < a.C1; r0 += NB) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+      b[r] = (r0 + r < a.C1 && j >= r0 + r && j < a.C1) ? Rs[(size_t)(r0 + r) * a.C1P + j] : 0.0;
+    xk_qr_pass<NB>(b, Rd, a.C1P, a.C1, r0, false, vbuf, sc);
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Generic strided fp64 GEMM on v_mfma_f64_16x16x4_f64, one wave per 16x16
+// output tile, four waves per workgroup.  n <= ~350 here, so every operand is
+// L2-resident; operands are read straight into the MFMA fragment layout
+// (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; C/D: col =
+// lane&15, row = (lane>>4) + 4*reg -- the f64 map, not the f32 one).
+//
+//   mode 0: C = alpha*A*B + beta*D
+//   mode 1: as 0, plus diag[i] (or diag_scalar) added on the diagonal
+//   mode 2: C = 0.5*((D + alpha*AB) + (D + alpha*AB)^T)   (A*B symmetric)
+// ----------------------------------------------------------------------------
+typedef double xk_d4 __attribute__((ext_vector_type(4)));
+
+struct XkGemmArgs {
+  const double *A, *B, *D;
+  double *C;
+  int M, N, K;
+  long sar, sac, sbr, sbc, sdr, sdc, scr, scc;
+  double alpha, beta;
+  int mode;
+  const double *diag;
+  double diag_scalar;
+};
+
+__global__ __launch_bounds__(256) void xk_gemm_f64(XkGemmArgs g) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tiles_n = (g.N + 15) >> 4, tiles_m = (g.M + 15) >> 4;
+  const int t = blockIdx.x * 4 + wave;
+  if (t >= tiles_m * tiles_n) return;
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  const int li = lane & 15, lk = lane >> 4;
+  const int arow = tm * 16 + li, bcol = tn * 16 + li;
+  const bool aok = arow < g.M, bok = bcol < g.N;
+  const double *ap = g.A + (long)arow * g.sar, *bp = g.B + (long)bcol * g.sbc;
+  xk_d4 acc = {0.0, 0.0, 0.0, 0.0};
+  const int K4 = g.K & ~3;
+  int k0 = 0;
+  for (; k0 + 16 <= K4; k0 += 16) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 4 * u + lk;
+      av[u] = aok ? ap[(long)k * g.sac] : 0.0;
+      bv[u] = bok ? bp[(long)k * g.sbr] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  for (; k0 < g.K; k0 += 4) {
+    const int k = k0 + lk;
+    const double av = (aok && k < g.K) ? ap[(long)k * g.sac] : 0.0;
+    const double bv = (bok && k < g.K) ? bp[(long)k * g.sbr] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+  }
+  const int col = tn * 16 + li;
+  if (col >= g.N) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = tm * 16 + lk + 4 * r;
+    if (row >= g.M) continue;
+    double v = g.alpha * acc[r];
+    if (g.mode == 2) {
+      const double d1 = g.D[(long)row * g.sdr + (long)col * g.sdc];
+      const double d2 = g.D[(long)col * g.sdr + (long)row * g.sdc];
+      v = 0.5 * ((d1 + v) + (d2 + v));
+    } else {
+      if (g.beta != 0.0) v += g.beta * g.D[(long)row * g.sdr + (long)col * g.sdc];
+      if (g.mode == 1 && row == col) v += g.diag ? g.diag[row] : g.diag_scalar;
+    }
+    g.C[(long)row * g.scr + (long)col * g.scc] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Blocked Cholesky of the augmented row-major matrix  Maug = [S | W | z]
+// (c x (c + nrhs)).  Per block step kb:
+//   xk_chol_diag   : factor the nb x nb diagonal block S_kk = L L^T (LDS, one
+//                    workgroup) and write Linv = L^-1
+//   gemm           : X[kb:kb+nb, kb+nb:] = Linv * Maug[kb:kb+nb, kb+nb:]
+//   gemm           : Maug[kb+nb:, kb+nb:] -= X[kb:kb+nb, S cols]^T * X[kb:kb+nb, kb+nb:]
+// After the last step X[:, c:] = L^-1 [W | z].
+// ----------------------------------------------------------------------------
+#define XK_CHOL_NB 32
+
+struct XkCholDiagArgs {
+  const double *Maug;
+  int ld, kb, nb;
+  double *Linv;  // [XK_CHOL_NB][XK_CHOL_NB] row-major
+  int *status;   // set to 2 (XK_ESINGULAR) if a pivot is not positive
+};
+
+__global__ __launch_bounds__(64) void xk_chol_diag(XkCholDiagArgs a) {
+  __shared__ double L[XK_CHOL_NB][XK_CHOL_NB + 1];
+  __shared__ double Li[XK_CHOL_NB][XK_CHOL_NB + 1];
+  const int t = threadIdx.x, nb = a.nb;
+  for (int idx = t; idx < nb * nb; idx += 64) {
+    const int i = idx / nb, j = idx - i * nb;
+    // read the upper triangle (row-oriented updates keep it current), mirror
+    const int r = i < j ? i : j, c = i < j ? j : i;
+    L[i][j] = a.Maug[(size_t)(a.kb + r) * a.ld + a.kb + c];
+    Li[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < nb; ++k) {
+    const double piv = L[k][k];
+    if (!(piv > 0.0)) { bad = true; break; }
+    const double inv = 1.0 / sqrt(piv);
+    __syncthreads();
+    if (t >= k && t < nb) L[t][k] *= inv;  // includes the diagonal: L[k][k] = sqrt(piv)
+    __syncthreads();
+    // trailing update of the lower triangle
+    const int cnt = nb - k - 1;
+    for (int idx = t; idx < cnt * cnt; idx += 64) {
+      const int ii = idx / cnt, jj = idx - ii * cnt;
+      if (jj > ii) continue;
+      L[k + 1 + ii][k + 1 + jj] -= L[k + 1 + ii][k] * L[k + 1 + jj][k];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (t == 0) *a.status = 2;
+    // still emit a finite Linv so downstream kernels do not fault
+    for (int idx = t; idx < XK_CHOL_NB * XK_CHOL_NB; idx += 64) a.Linv[idx] = 0.0;
+    return;
+  }
+  // Linv = L^-1 by forward substitution, one column per thread
+  if (t < nb) {
+    for (int i = t; i < nb; ++i) {
+      double s = (i == t) ? 1.0 : 0.0;
+      for (int m = t; m < i; ++m) s -= L[i][m] * Li[m][t];
+      Li[i][t] = s / L[i][i];
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < XK_CHOL_NB * XK_CHOL_NB; idx += 64) {
+    const int i = idx / XK_CHOL_NB, j = idx - i * XK_CHOL_NB;
+    a.Linv[idx] = (i < nb && j < nb && j <= i) ? Li[i][j] : 0.0;
+  }
+}
+
+// corr[i] = sum_k X[k][xoff+i] * y[k] - ct[i]      (K z' - corr_tot, updater.cpp:126)
+struct XkCorrArgs {
+  const double *X;
+  int ld, c, n, xoff, yoff;
+  const double *ct;  // may be null
+  double *corr;
+};
+__global__ void xk_corr(XkCorrArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  double s = 0.0;
+  for (int k = 0; k < a.c; ++k) s += a.X[(size_t)k * a.ld + a.xoff + i] * a.X[(size_t)k * a.ld + a.yoff];
+  a.corr[i] = s - (a.ct ? a.ct[i] : 0.0);
+}
+
+// z'[k] = z[k] + sum_j T[k][j] * ct[col0 + j]     (res + H corr_tot, updater.cpp:126)
+struct XkZArgs {
+  const double *T;
+  long str, stc;
+  int c, kdim, col0;
+  const double *z;
+  long sz;
+  const double *ct;  // may be null
+  double *out;
+  long so;
+};
+__global__ void xk_zprime(XkZArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.c) return;
+  double s = a.z[(long)k * a.sz];
+  if (a.ct)
+    for (int j = 0; j < a.kdim; ++j) s += a.T[(long)k * a.str + (long)j * a.stc] * a.ct[a.col0 + j];
+  a.out[(long)k * a.so] = s;
+}
+
+// strided copy / scale helpers
+struct XkCopyArgs {
+  const double *src;
+  double *dst;
+  int rows, cols;
+  long ssr, ssc, dsr, dsc;
+};
+__global__ void xk_copy2d(XkCopyArgs a) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.rows * a.cols) return;
+  const int r = (int)(idx % a.rows), c = (int)(idx / a.rows);
+  a.dst[(long)r * a.dsr + (long)c * a.dsc] = a.src[(long)r * a.ssr + (long)c * a.ssc];
+}

@@ -1,0 +1,309 @@
+"""ctypes binding of libxk.so -- the C ABI declared in include/xk.h.
+
+This is plumbing for tests and bench.py; the product is the shared library.
+There is NO fallback: if libxk.so (the hand-written HIP kernels for gfx950) is
+missing or fails to load, importing this module's `lib()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxk.so")
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+XK_NSTAGE = 6
+STATUS = {0: "XK_OK", 1: "XK_EINVAL", 2: "XK_ESINGULAR", 3: "XK_ENAN", 4: "XK_EDEVICE", 5: "XK_ENOMEM",
+          6: "XK_ECAPACITY"}
+
+# every symbol include/xk.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "xk_create", "xk_destroy", "xk_strerror", "xk_last_error", "xk_version", "xk_stream",
+    "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
+    "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
+    "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match",
+    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged",
+]
+
+
+class XkTiming(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("stage_ms", C.c_float * XK_NSTAGE),
+                ("stage_launches", C.c_int * XK_NSTAGE), ("stage_name", (C.c_char * 32) * XK_NSTAGE),
+                ("n", C.c_int), ("c1", C.c_int), ("k_tracks", C.c_int), ("rows_stacked", C.c_int),
+                ("n_leaf", C.c_int), ("n_levels", C.c_int)]
+
+
+class XkError(RuntimeError):
+    def __init__(self, status, what, detail=""):
+        super().__init__(f"{what}: {STATUS.get(status, status)} {detail}".strip())
+        self.status = status
+
+
+def lib():
+    """Load libxk.so or raise -- never falls back to anything else."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `python -m x_multi_agent_amd.build` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.xk_strerror.restype = C.c_char_p
+        L.xk_last_error.restype = C.c_char_p
+        L.xk_last_error.argtypes = [C.c_void_p]
+        L.xk_stream.restype = C.c_void_p
+        L.xk_stream.argtypes = [C.c_void_p]
+        L.xk_payload_doubles.restype = C.c_long
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(c_ip)
+
+
+def _f(a):
+    a = np.asfortranarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_dp)
+
+
+class Engine:
+    """One xk_handle (= one agent / one x::Ekf)."""
+
+    def __init__(self, n_poses_max, n_feat_max, k_max, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        rc = self.L.xk_create(C.c_int(device), C.c_int(n_poses_max), C.c_int(n_feat_max), C.c_int(k_max),
+                              C.byref(self.h))
+        if rc != 0:
+            raise XkError(rc, "xk_create")
+        self.N, self.M, self.K = n_poses_max, n_feat_max, k_max
+        self.n = 15 + 6 * n_poses_max + 3 * n_feat_max
+
+    def close(self):
+        if self.h:
+            self.L.xk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise XkError(rc, what, (self.L.xk_last_error(self.h) or b"").decode())
+
+    # ---- staging -----------------------------------------------------
+    def stage(self, sc):
+        """Stage a synth.make_scenario dict in HBM."""
+        q, qp = _d(sc["C_q_G"])
+        p, pp = _d(sc["G_p_C"])
+        self._chk(self.L.xk_stage_window(self.h, qp, pp, C.c_int(len(p))), "xk_stage_window")
+        to, top = _i(sc["trk_off"])
+        ob, obp = _d(sc["obs_xy"])
+        self._chk(self.L.xk_stage_tracks(self.h, top, obp, C.c_int(len(to) - 1)), "xk_stage_tracks")
+        M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+        if M:
+            f, fp = _d(sc["slam_feat"])
+            a, ap = _i(sc["slam_anchor_idxs"])
+            ts, tsp = _i(sc["slam_track_sizes"])
+            z, zp = _d(sc["slam_z_last"])
+            self._chk(self.L.xk_stage_slam(self.h, fp, ap, tsp, zp, C.c_int(M)), "xk_stage_slam")
+        else:
+            self._chk(self.L.xk_stage_slam(self.h, None, None, None, None, C.c_int(0)), "xk_stage_slam")
+        self.upload_P(sc["P"])
+        self._K, self._M = len(to) - 1, M
+
+    def upload_P(self, P):
+        Pf, Pp = _f(P)
+        self._chk(self.L.xk_upload_P(self.h, Pp, C.c_int(self.n), C.c_int(self.n)), "xk_upload_P")
+
+    def download_P(self):
+        P = np.zeros((self.n, self.n), order="F")
+        self._chk(self.L.xk_download_P(self.h, P.ctypes.data_as(c_dp), C.c_int(self.n), C.c_int(self.n)),
+                  "xk_download_P")
+        return np.ascontiguousarray(P)
+
+    # ---- staged path -------------------------------------------------
+    def _flag_bufs(self):
+        K, M = max(self._K, 1), max(self._M, 1)
+        return (np.zeros(K, dtype=np.int32), np.zeros(K), np.zeros(M, dtype=np.int32), np.zeros(M))
+
+    def msckf_build(self, sigma_img):
+        inl, gam, inls, gams = self._flag_bufs()
+        self._chk(self.L.xk_msckf_build(self.h, C.c_double(sigma_img), inl.ctypes.data_as(c_ip),
+                                        gam.ctypes.data_as(c_dp), inls.ctypes.data_as(c_ip),
+                                        gams.ctypes.data_as(c_dp)), "xk_msckf_build")
+        return dict(inlier=inl[:self._K], gamma=gam[:self._K], inlier_slam=inls[:self._M],
+                    gamma_slam=gams[:self._M])
+
+    def qr_compress(self, want=True):
+        if not want:
+            self._chk(self.L.xk_qr_compress(self.h, None, C.c_int(0), None), "xk_qr_compress")
+            return None, None
+        T = np.zeros((self.n, self.n), order="F")
+        z = np.zeros(self.n)
+        self._chk(self.L.xk_qr_compress(self.h, T.ctypes.data_as(c_dp), C.c_int(self.n), z.ctypes.data_as(c_dp)),
+                  "xk_qr_compress")
+        return np.ascontiguousarray(T), z
+
+    def apply_update(self, corr_total=None, cov_update=True):
+        corr = np.zeros(self.n)
+        ctp = None
+        if corr_total is not None:
+            ct, ctp = _d(corr_total)
+        self._chk(self.L.xk_apply_update(self.h, ctp, C.c_int(int(cov_update)), corr.ctypes.data_as(c_dp)),
+                  "xk_apply_update")
+        return corr
+
+    def visual_update_staged(self, sigma_img):
+        corr = np.zeros(self.n)
+        inl, gam, inls, gams = self._flag_bufs()
+        self._chk(self.L.xk_visual_update_staged(self.h, C.c_double(sigma_img), corr.ctypes.data_as(c_dp),
+                                                 inl.ctypes.data_as(c_ip), gam.ctypes.data_as(c_dp),
+                                                 inls.ctypes.data_as(c_ip), gams.ctypes.data_as(c_dp)),
+                  "xk_visual_update_staged")
+        return dict(correction=corr, inlier=inl[:self._K], gamma=gam[:self._K], inlier_slam=inls[:self._M],
+                    gamma_slam=gams[:self._M])
+
+    def visual_update(self, sc):
+        """Host-buffer convenience call (PCIe inclusive); returns dict with posterior P."""
+        q, qp = _d(sc["C_q_G"])
+        p, pp = _d(sc["G_p_C"])
+        to, top = _i(sc["trk_off"])
+        ob, obp = _d(sc["obs_xy"])
+        K = len(to) - 1
+        M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+        if M:
+            f, fp = _d(sc["slam_feat"])
+            a, ap = _i(sc["slam_anchor_idxs"])
+            ts, tsp = _i(sc["slam_track_sizes"])
+            z, zp = _d(sc["slam_z_last"])
+        else:
+            fp = zp = None
+            ap = tsp = None
+        P = np.array(sc["P"], dtype=np.float64, order="F", copy=True)
+        corr = np.zeros(self.n)
+        self._K, self._M = K, M
+        inl, gam, inls, gams = self._flag_bufs()
+        self._chk(self.L.xk_visual_update(self.h, qp, pp, C.c_int(len(p)), top, obp, C.c_int(K), fp, ap, tsp, zp,
+                                          C.c_int(M), P.ctypes.data_as(c_dp), C.c_int(self.n), C.c_int(self.n),
+                                          C.c_double(sc["sigma_img"]), corr.ctypes.data_as(c_dp),
+                                          inl.ctypes.data_as(c_ip), gam.ctypes.data_as(c_dp),
+                                          inls.ctypes.data_as(c_ip), gams.ctypes.data_as(c_dp)),
+                  "xk_visual_update")
+        return dict(P=np.ascontiguousarray(P), correction=corr, inlier=inl[:K], gamma=gam[:K],
+                    inlier_slam=inls[:M], gamma_slam=gams[:M])
+
+    # ---- dense algebra -----------------------------------------------
+    def apply_update_dense(self, P, H, res, r_diag, correction_total=None, cov_update=True):
+        m = H.shape[0]
+        Pf = np.array(P, dtype=np.float64, order="F", copy=True)
+        Hf, Hp = _f(H)
+        r, rp = _d(res)
+        rd, rdp = _d(r_diag)
+        corr = np.zeros(self.n)
+        ct = None if correction_total is None else np.array(correction_total, dtype=np.float64)
+        ctp = None if ct is None else ct.ctypes.data_as(c_dp)
+        self._chk(self.L.xk_apply_update_dense(self.h, Pf.ctypes.data_as(c_dp), C.c_int(self.n), C.c_int(self.n),
+                                               Hp, C.c_int(m), C.c_int(m), rp, rdp, ctp,
+                                               C.c_int(int(cov_update)), corr.ctypes.data_as(c_dp)),
+                  "xk_apply_update_dense")
+        return np.ascontiguousarray(Pf), corr, ct
+
+    def apply_ci(self, ci_P, H, res, S):
+        m = H.shape[0]
+        Pf, Pp = _f(ci_P)
+        Hf, Hp = _f(H)
+        r, rp = _d(res)
+        Sf, Sp = _f(S)
+        Po = np.zeros((self.n, self.n), order="F")
+        corr = np.zeros(self.n)
+        self._chk(self.L.xk_apply_ci(self.h, Po.ctypes.data_as(c_dp), C.c_int(self.n), Pp, C.c_int(self.n),
+                                     C.c_int(self.n), Hp, C.c_int(m), C.c_int(m), rp, Sp, C.c_int(m),
+                                     corr.ctypes.data_as(c_dp)), "xk_apply_ci")
+        return np.ascontiguousarray(Po), corr
+
+    def fuse_ci_slam(self, Pa, Ha, Pb, Hb, w):
+        m = Ha.shape[0]
+        Paf, Pap = _f(Pa)
+        Haf, Hap = _f(Ha)
+        Pbf, Pbp = _f(Pb)
+        Hbf, Hbp = _f(Hb)
+        S = np.zeros((m, m), order="F")
+        wr = C.c_double()
+        self._chk(self.L.xk_fuse_ci_slam(self.h, Pap, C.c_int(Pa.shape[0]), C.c_int(Pa.shape[0]), Hap, C.c_int(m),
+                                         Pbp, C.c_int(Pb.shape[0]), C.c_int(Pb.shape[0]), Hbp, C.c_int(m),
+                                         C.c_int(m), C.c_double(w), S.ctypes.data_as(c_dp), C.c_int(m),
+                                         C.byref(wr)), "xk_fuse_ci_slam")
+        return np.ascontiguousarray(S), wr.value
+
+    def fuse_ci_msckf(self, P, H, Ps, Hs, w):
+        m = H.shape[0]
+        k = len(Ps)
+        Pf, Pp = _f(P)
+        Hf, Hp = _f(H)
+        keep = [_f(x) for x in Ps] + [_f(x) for x in Hs]
+        PsA = (c_dp * max(k, 1))(*[keep[i][1] for i in range(k)])
+        HsA = (c_dp * max(k, 1))(*[keep[k + i][1] for i in range(k)])
+        ns, nsp = _i([x.shape[0] for x in Ps] or [0])
+        S = np.zeros((m, m), order="F")
+        wr = C.c_double()
+        self._chk(self.L.xk_fuse_ci_msckf(self.h, Pp, C.c_int(P.shape[0]), C.c_int(P.shape[0]), Hp, C.c_int(m),
+                                          C.c_int(m), C.c_int(k), PsA, nsp, HsA, C.c_double(w),
+                                          S.ctypes.data_as(c_dp), C.c_int(m), C.byref(wr)), "xk_fuse_ci_msckf")
+        return np.ascontiguousarray(S), wr.value
+
+    def multi_slam_match(self, C_q_G, G_p_C, feat, anchor_idx, feature_id, P, n_poses_max, o_C_q_G, o_G_p_C,
+                         o_feat, o_anchor_idx, o_feature_id, o_P, o_n_poses_max, sigma_landmark, ci_slam_w):
+        n, no = P.shape[0], o_P.shape[0]
+        a = [_d(C_q_G), _d(G_p_C), _d(feat), _f(P), _d(o_C_q_G), _d(o_G_p_C), _d(o_feat), _f(o_P)]
+        inl = C.c_int()
+        gam = C.c_double()
+        H = np.zeros((3, n), order="F")
+        res = np.zeros(3)
+        S = np.zeros((3, 3), order="F")
+        Pj = np.zeros((n, n), order="F")
+        self._chk(self.L.xk_multi_slam_match(
+            self.h, a[0][1], a[1][1], C.c_int(len(a[1][0])), a[2][1], C.c_int(anchor_idx), C.c_int(feature_id),
+            a[3][1], C.c_int(n), C.c_int(n), C.c_int(n_poses_max), a[4][1], a[5][1], C.c_int(len(a[5][0])),
+            a[6][1], C.c_int(o_anchor_idx), C.c_int(o_feature_id), a[7][1], C.c_int(no), C.c_int(no),
+            C.c_int(o_n_poses_max), C.c_double(sigma_landmark), C.c_double(ci_slam_w), C.byref(inl),
+            C.byref(gam), H.ctypes.data_as(c_dp), C.c_int(3), res.ctypes.data_as(c_dp), S.ctypes.data_as(c_dp),
+            Pj.ctypes.data_as(c_dp), C.c_int(n)), "xk_multi_slam_match")
+        out = dict(inlier=bool(inl.value), gamma=gam.value, H=np.ascontiguousarray(H), res=res)
+        if out["inlier"]:
+            out.update(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj))
+        return out
+
+    # ---- measurement -------------------------------------------------
+    def bench_staged(self, sigma_img, warmup, steps):
+        t = XkTiming()
+        self._chk(self.L.xk_bench_staged(self.h, C.c_double(sigma_img), C.c_int(warmup), C.c_int(steps),
+                                         C.byref(t)), "xk_bench_staged")
+        return dict(total_ms=t.total_ms,
+                    stages={t.stage_name[s].value.decode(): dict(ms=t.stage_ms[s], launches=t.stage_launches[s])
+                            for s in range(XK_NSTAGE)},
+                    n=t.n, c1=t.c1, k_tracks=t.k_tracks, rows_stacked=t.rows_stacked, n_leaf=t.n_leaf,
+                    n_levels=t.n_levels)
+
+    def payload_doubles(self):
+        return int(self.L.xk_payload_doubles(C.c_int(self.N), C.c_int(self.M)))
+
+    def pack_payload(self, agent_id, timestamp, dyn16):
+        d, dp = _d(dyn16)
+        ptr = c_dp()
+        self._chk(self.L.xk_pack_payload(self.h, C.c_double(agent_id), C.c_double(timestamp), dp, C.byref(ptr)),
+                  "xk_pack_payload")
+        return C.cast(ptr, C.c_void_p).value
