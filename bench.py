@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- EKF visual updates/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 4]
+
+One process per GPU (the driver launches N>1 through torch.distributed.run);
+rank r is agent r with its own synthetic window/tracks/prior (seed
+0x5EED0000 + 1000*config + agent).  A step = one Updater::update()-equivalent
+visual update (per-feature build -> TSQR compression -> Kalman update) on
+inputs already resident in HBM; P stays on the device.  Every CI_EVERY steps
+the agents exchange their SimpleState payloads (state + full covariance) with
+one RCCL all-gather.  value = (N * K updates) / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline      fp64 compute roofline of the dominant stage (TSQR kernels),
+                timed with HIP events on the engine's stream
+  cpu_baseline  the C restatement of the reference path (oracle/xk_oracle.c),
+                single thread, timed on this box's host cores (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
+CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
+
+
+def alg_flops(N, K, M, rows=None):
+    """SURVEY.md 8(d) F_alg, split into (per-feature, QR, update)."""
+    L = N
+    d = 2 * L - 3
+    c = 6 * N + 3 * M + 1
+    n = 15 + 6 * N + 3 * M
+    r = K * d + 2 * M if rows is None else rows
+    feat = K * (12 * 2 * L * (6 * L + 1) + 144 * L * L + 48 * L * L + 2 * d * (2 * L) ** 2 + 2 * d * d * (2 * L) + d ** 3 / 3)
+    qr = 2.0 * r * c * c - (2.0 / 3.0) * c ** 3
+    upd = 7.0 * n ** 3
+    return feat, qr, upd
+
+
+def cpu_baseline(sc, budget_s=20.0):
+    """Time the as-written C restatement on one host core (bounded sample)."""
+    from oracle import c_oracle
+    so = "/tmp/libxk_oracle_native.so"
+    try:
+        c_oracle.build(march="native", out=so, force=True)
+        L = c_oracle.lib(so)
+        flags = "-O3 -march=native"
+    except Exception:
+        L = c_oracle.lib()
+        flags = "-O3 -march=x86-64-v3 (prebuilt)"
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        pinned = True
+    except Exception:
+        pinned = False
+    times = []
+    t_start = time.perf_counter()
+    for i in range(3 + 20):
+        t0 = time.perf_counter()
+        c_oracle.visual_update(sc, library=L)
+        dt = time.perf_counter() - t0
+        if i >= 3:
+            times.append(dt)
+        if time.perf_counter() - t_start > budget_s and len(times) >= 3:
+            break
+    try:
+        os.sched_setaffinity(0, set(range(os.cpu_count())))
+    except Exception:
+        pass
+    med = statistics.median(times)
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    M = len(sc.get("slam_anchor_idxs", []))
+    as_written_gf = 4.8e9 if (N, K, M) == (30, 400, 0) else None
+    return {"value": 1.0 / med, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": f"median of {len(times)} updates after 3 warm-ups, same inputs as the GPU run, "
+                      f"oracle/xk_oracle.c {flags}, pinned={pinned}",
+            "ms_per_update": 1e3 * med, "host_cpus": os.cpu_count(),
+            "approx_gflops": (as_written_gf / med / 1e9) if as_written_gf else None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    from x_multi_agent_amd import engine, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); no CPU fallback exists")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    N, K, M = synth.CONFIGS[args.config]
+    sc = synth.make_config(args.config, agent_id=rank)
+    eng = engine.Engine(N, M, K, device=local_rank)
+    eng.stage(sc)
+    sigma = sc["sigma_img"]
+
+    # CI payload exchange buffers (torch owns them so RCCL can use them directly)
+    pay_n = eng.payload_doubles()
+    send = torch.empty(pay_n, dtype=torch.float64, device=f"cuda:{local_rank}")
+    recv = torch.empty(pay_n * world, dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+    dyn16 = np.zeros(16)
+    dyn16[9] = 1.0
+
+    def exchange(step):
+        if world == 1:
+            return
+        eng.pack_payload_into(rank, float(step), dyn16, send.data_ptr())
+        dist.all_gather_into_tensor(recv, send)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed warmup (also validates the staged path end to end)
+    eng.run_steps(sigma, args.warmup)
+    exchange(0)
+    sync()
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.steps:
+        chunk = min(CI_EVERY, args.steps - done)
+        eng.run_steps(sigma, chunk)          # `chunk` sequential updates, device-resident
+        done += chunk
+        if done % CI_EVERY == 0:
+            exchange(done)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        # per-stage HIP-event timing of the same staged update (untimed region)
+        tm = eng.bench_staged(sigma, 2, min(20, max(5, args.steps)))
+        f_feat, f_qr, f_upd = alg_flops(N, K, M)
+        f_alg = f_feat + f_qr + f_upd
+        st = tm["stages"]
+        qr_ms = st["xk_tsqr_leaf"]["ms"] + st["xk_tsqr_merge"]["ms"]
+        dom = max(st.items(), key=lambda kv: kv[1]["ms"])
+        traffic = None
+        pmc = os.path.join(HERE, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("tsqr_bytes_per_update")
+            except Exception:
+                traffic = None
+        ach = f_qr / (qr_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
+                "kernel": "xk_tsqr_leaf+xk_tsqr_merge (Householder TSQR of the stacked [H|res])",
+                "alg_flops_per_update": f_qr, "stage_ms": qr_ms,
+                "launches_per_update": st["xk_tsqr_leaf"]["launches"] + st["xk_tsqr_merge"]["launches"],
+                "dominant_kernel_by_time": dom[0], "dominant_kernel_ms": dom[1]["ms"],
+                "dominant_kernel_launches": dom[1]["launches"],
+                "whole_update": {"alg_flops": f_alg, "ms": tm["total_ms"],
+                                 "achieved": f_alg / (tm["total_ms"] * 1e-3) / 1e12,
+                                 "frac": f_alg / (tm["total_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
+                "stages_ms": {k: v["ms"] for k, v in st.items() if v["launches"]},
+                "dtype_peak_note": "fp64 dense peak, vector = matrix = 78.6 TFLOP/s (AMD public MI355X spec)"}
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline(sc)
+        value = world * args.steps / dt
+        out = {"metric": "EKF updates/sec (window=30, 400 MSCKF feats)" if args.config in (4, 5)
+               else f"EKF updates/sec (config {args.config})",
+               "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: one agent per GPU, window N={N}, "
+                                      f"K={K} MSCKF tracks (L=N), M={M} SLAM features, n={15 + 6 * N + 3 * M}; "
+                                      f"CI payload all-gather every {CI_EVERY} updates",
+                          "n_poses_max": N, "k_msckf": K, "m_slam": M, "agents": world,
+                          "ci_every": CI_EVERY, "payload_bytes": 8 * pay_n},
+               "roofline": roof, "cpu_baseline": cpu,
+               "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

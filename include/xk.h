@@ -167,12 +167,14 @@ int xk_multi_slam_match(xk_handle *h, const double *C_q_G, const double *G_p_C, 
 /* Size in doubles of the fixed all-double payload for (N, M): hdr[8] dyn[16]
  * pos[3N] att[4N] feat[3M] anchors[M] cov[n*n]. */
 long xk_payload_doubles(int n_poses_max, int n_feat_max);
-/* Device pointer to this agent's outgoing payload, packed from the staged
- * window/SLAM state and the CURRENT device-resident P; RCCL sends it in
- * place.  dyn (16) = p,v,q xyzw,b_w,b_a (State::getDynamicStates,
+/* Packs this agent's outgoing payload from the staged window/SLAM state and
+ * the CURRENT device-resident P into d_dst (a DEVICE buffer of
+ * xk_payload_doubles doubles owned by the caller, e.g. the RCCL send buffer)
+ * or, if d_dst is NULL, into a buffer owned by the handle; *d_payload (if
+ * non-NULL) receives the device pointer used.  dyn (16) = p,v,q xyzw,b_w,b_a (State::getDynamicStates,
  * state.cpp:87-99) comes from the host. */
 int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, const double *dyn16,
-                    double **d_payload);
+                    double *d_dst, double **d_payload);
 
 /* ---- measurement ----------------------------------------------------- */
 
@@ -191,6 +193,11 @@ typedef struct {
  * (each from the same staged prior; results of the last one stay resident)
  * and reports HIP-event timings averaged per update. */
 int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_timing *out);
+
+/* Enqueues `steps` sequential staged visual updates (same staged prior, the
+ * posterior of the last one left in the handle's output buffer) and waits for
+ * them; nothing crosses PCIe.  This is the timed region of bench.py. */
+int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 
 #ifdef __cplusplus
 }

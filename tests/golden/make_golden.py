@@ -1,0 +1,103 @@
+"""Generates tests/golden/*.npz -- inputs and expected outputs for the xVIO
+EKF-update path.
+
+The reference (jpl-x/x_multi_agent) has no tests or fixtures of its own and
+cannot be built in this image (Eigen3/OpenCV/Boost absent), so these vectors
+come from the NumPy restatement oracle/ref_np.py (written from the reference
+sources line by line) -- PARITY UNPINNED, see DESIGN.md.  Only
+basis-independent quantities are stored: inlier masks, gamma,
+H^T H, H^T res, T^T T, T^T z, correction, posterior P.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from oracle import ref_np  # noqa: E402
+from x_multi_agent_amd import synth  # noqa: E402
+
+INPUT_KEYS = ["C_q_G", "G_p_C", "trk_off", "obs_xy", "P", "slam_feat", "slam_anchor_idxs", "slam_z_last",
+              "slam_track_sizes"]
+
+
+def visual_case(name, sc):
+    slam = None
+    if "slam_feat" in sc:
+        slam = dict(track_sizes=sc["slam_track_sizes"], z_last=sc["slam_z_last"], feat=sc["slam_feat"],
+                    anchor_idxs=sc["slam_anchor_idxs"])
+    out = ref_np.visual_update(synth.tracks_as_list(sc), sc["C_q_G"], sc["G_p_C"], sc["P"], sc["n_poses_max"],
+                               sc["sigma_img"], slam=slam)
+    H, r = out["h_stack"], out["res_stack"]
+    T, z = out["h"], out["res"]
+    d = {k: sc[k] for k in INPUT_KEYS if k in sc}
+    d.update(n_poses_max=sc["n_poses_max"], sigma_img=sc["sigma_img"],
+             exp_inlier=out["msckf"]["inlier"], exp_gamma=out["msckf"]["gamma"], exp_feats=out["msckf"]["feats"],
+             exp_gn_iters=out["msckf"]["gn_iters"], exp_HtH=H.T @ H, exp_Htr=H.T @ r, exp_TtT=T.T @ T,
+             exp_Ttz=T.T @ z, exp_did_qr=out["did_qr"], exp_correction=out["correction"], exp_P=out["P"])
+    if slam is not None:
+        d.update(exp_inlier_slam=out["slam"]["inlier"], exp_gamma_slam=out["slam"]["gamma"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(name, "n", sc["P"].shape[0], "inliers", int(out["msckf"]["inlier"].sum()), "/", len(out["msckf"]["inlier"]),
+          "did_qr", out["did_qr"])
+
+
+def ci_cases():
+    """SLAM-SLAM match + pairwise CI + applyCI, and k-agent MSCKF CI, between two agents."""
+    a = synth.make_scenario(6, 12, 4, seed=synth.seed_for(4, 0) + 7)
+    # second agent observes the same landmarks from a shifted arc
+    b = synth.make_scenario(6, 12, 4, seed=synth.seed_for(4, 1) + 7, agent_offset=0.05,
+                            landmarks=a["landmarks_true"])
+    d = {}
+    for tag, s in (("a", a), ("b", b)):
+        for k in INPUT_KEYS:
+            d[f"{tag}_{k}"] = s[k]
+    d.update(n_poses_max=6, sigma_img=a["sigma_img"], sigma_landmark=0.1, ci_slam_w=0.4, ci_msckf_w=0.2)
+    # SLAM feature j of a <-> j of b
+    for j in range(4):
+        m = ref_np.multi_slam_match(a["C_q_G"], a["G_p_C"], a["slam_feat"], int(a["slam_anchor_idxs"][j]), j,
+                                    a["P"], 6, b["C_q_G"], b["G_p_C"], b["slam_feat"],
+                                    int(b["slam_anchor_idxs"][j]), j, b["P"], 6, 0.1, 0.4)
+        d[f"ms{j}_inlier"] = m["inlier"]
+        d[f"ms{j}_gamma"] = m["gamma"]
+        d[f"ms{j}_H"] = m["H"]
+        d[f"ms{j}_res"] = m["res"]
+        if m["inlier"]:
+            Pn, corr = ref_np.apply_ci(m["P_j"], m["H"], m["res"], m["S"])
+            d[f"ms{j}_S"] = m["S"]
+            d[f"ms{j}_Pj"] = m["P_j"]
+            d[f"ms{j}_Ppost"] = Pn
+            d[f"ms{j}_corr"] = corr
+    # MSCKF-MSCKF CI on the first 4 tracks (same landmark ids in both agents)
+    ta, tb = synth.tracks_as_list(a), synth.tracks_as_list(b)
+    for j in range(4):
+        o = ref_np.msckf_ci_track(ta[j], a["C_q_G"], a["G_p_C"], a["P"], 6, a["sigma_img"],
+                                  [dict(obs=tb[j], q_list=b["C_q_G"], p_list=b["G_p_C"], P=b["P"], n_poses_max=6)],
+                                  0.2)
+        d[f"mc{j}_self_inlier"] = bool(o["self"]["valid"] and o["self"]["inlier"])
+        d[f"mc{j}_has_ci"] = o["ci"] is not None
+        if o["ci"] is not None:
+            c = o["ci"]
+            d[f"mc{j}_S"] = c["S"]
+            d[f"mc{j}_Pj"] = c["P_j"]
+            d[f"mc{j}_HtSiH"] = c["H"].T @ np.linalg.inv(c["S"]) @ c["H"]   # basis independent
+            d[f"mc{j}_HtSir"] = c["H"].T @ np.linalg.inv(c["S"]) @ c["res"]
+            Pn, corr = ref_np.apply_ci(c["P_j"], c["H"], c["res"], c["S"])
+            d[f"mc{j}_Ppost"] = Pn
+            d[f"mc{j}_corr"] = corr
+    np.savez_compressed(os.path.join(HERE, "ci_two_agents.npz"), **d)
+    print("ci_two_agents", [bool(d[f"ms{j}_inlier"]) for j in range(4)], [bool(d[f"mc{j}_has_ci"]) for j in range(4)])
+
+
+if __name__ == "__main__":
+    visual_case("cfg1_n10_k50", synth.make_config(1))
+    visual_case("slam_n8_k30_m6", synth.make_scenario(8, 30, 6, seed=77))
+    visual_case("ragged_n12_k40", synth.make_scenario(12, 40, 0, seed=78, track_len=(2, 12)))
+    visual_case("partial_window_n10_p7_k20_m3", synth.make_scenario(10, 20, 3, seed=79, n_poses=7))
+    visual_case("few_rows_n10_k3", synth.make_scenario(10, 3, 0, seed=80))   # rows <= cols+1: no-QR branch
+    visual_case("stress_prior_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress", prior_scale=0.01))
+    visual_case("all_outliers_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress"))
+    ci_cases()

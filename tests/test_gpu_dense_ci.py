@@ -1,0 +1,121 @@
+"""Dense Kalman algebra and covariance-intersection entry points of the C ABI vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN_DIR, rel
+from x_multi_agent_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    return synth.make_scenario(8, 24, 2, seed=321)
+
+
+def test_apply_update_dense_matches_reference_form(xk, oracle_c, sc):
+    """Updater::applyUpdate with arbitrary dense H and diagonal R, incl. the IEKF terms."""
+    rng = np.random.default_rng(5)
+    P = sc["P"]
+    n = P.shape[0]
+    eng = xk.Engine(8, 2, 4)
+    for m in (1, 7, n, n + 1):
+        H = rng.standard_normal((m, n)) * 0.3
+        r = rng.standard_normal(m) * 1e-2
+        R = 10.0 ** rng.uniform(-6, 0, size=m)
+        ct = 1e-3 * rng.standard_normal(n)
+        Pg, cg, ctg = eng.apply_update_dense(P, H, r, R, correction_total=ct, cov_update=True)
+        Po, co = oracle_c.apply_update(P, H, r, R, correction_total=ct)
+        assert rel(Pg, Po) <= 1e-9 and rel(cg, co) <= 1e-8, m
+        assert rel(ctg, ct + co) <= 1e-8
+        Pg2, cg2, _ = eng.apply_update_dense(P, H, r, R, cov_update=False)   # non-final IEKF iteration
+        assert np.array_equal(Pg2, P)
+    with pytest.raises(xk.XkError) as e:
+        eng.apply_update_dense(P, rng.standard_normal((2 * n + 40, n)), np.zeros(2 * n + 40), np.ones(2 * n + 40))
+    assert e.value.status == 6
+    eng.close()
+
+
+def test_apply_update_with_total_correction_on_compressed_system(xk, oracle_c, sc):
+    eng = xk.Engine(8, 2, 24)
+    eng.stage(sc)
+    eng.msckf_build(sc["sigma_img"])
+    T, z = eng.qr_compress()
+    ct = 1e-3 * np.random.default_rng(6).standard_normal(sc["P"].shape[0])
+    corr = eng.apply_update(corr_total=ct, cov_update=True)
+    P = eng.download_P()
+    Po, co = oracle_c.apply_update(sc["P"], T, z, np.full(T.shape[0], sc["sigma_img"] ** 2), correction_total=ct)
+    assert rel(P, Po) <= 1e-9 and rel(corr, co) <= 1e-8
+    eng.close()
+
+
+def test_apply_ci_and_fuse(xk, oracle_c, sc):
+    rng = np.random.default_rng(7)
+    P = sc["P"]
+    n = P.shape[0]
+    other = synth.make_scenario(6, 5, 1, seed=322)["P"]
+    eng = xk.Engine(8, 2, 4)
+    for k in (1, 3):
+        m = 3 * k
+        H = rng.standard_normal((m, n))
+        Hs = [rng.standard_normal((m, other.shape[0])) for _ in range(k)]
+        Sg, wg = eng.fuse_ci_msckf(P, H, [other] * k, Hs, 0.1)
+        So, wo = oracle_c.fuse_ci_msckf(P, H, [other] * k, Hs, 0.1)
+        assert wg == wo and rel(Sg, So) <= 1e-12
+        S = So + 1e-4 * np.eye(m)
+        r = 1e-2 * rng.standard_normal(m)
+        Pj = P.copy()
+        Pj[15:18, 15:18] *= wo
+        Pg, cg = eng.apply_ci(Pj, H, r, S)
+        Po, co = oracle_c.apply_ci(Pj, H, r, S)
+        assert rel(Pg, Po) <= 1e-9 and rel(cg, co) <= 1e-8
+    Ha, Hb = rng.standard_normal((3, n)), rng.standard_normal((3, other.shape[0]))
+    Sg, wg = eng.fuse_ci_slam(P, Ha, other, Hb, 0.25)
+    So, wo = oracle_c.fuse_ci_slam(P, Ha, other, Hb, 0.25)
+    assert wg == wo and rel(Sg, So) <= 1e-12
+    for bad in (0.0, 1.5, -2.0, -0.5):   # throws in the reference (ci.cpp:59-62,98-101) / NLopt branch unsupported
+        with pytest.raises(xk.XkError) as e:
+            eng.fuse_ci_slam(P, Ha, other, Hb, bad)
+        assert e.value.status == 1
+    eng.close()
+
+
+def test_multi_slam_match_golden(xk):
+    z = np.load(os.path.join(GOLDEN_DIR, "ci_two_agents.npz"))
+    a = {k[2:]: z[k] for k in z.files if k.startswith("a_")}
+    b = {k[2:]: z[k] for k in z.files if k.startswith("b_")}
+    N = int(z["n_poses_max"])
+    eng = xk.Engine(N, 4, 12)
+    for j in range(4):
+        m = eng.multi_slam_match(a["C_q_G"], a["G_p_C"], a["slam_feat"], int(a["slam_anchor_idxs"][j]), j, a["P"], N,
+                                 b["C_q_G"], b["G_p_C"], b["slam_feat"], int(b["slam_anchor_idxs"][j]), j, b["P"], N,
+                                 float(z["sigma_landmark"]), float(z["ci_slam_w"]))
+        assert m["inlier"] == bool(z[f"ms{j}_inlier"])
+        assert abs(m["gamma"] - float(z[f"ms{j}_gamma"])) <= 1e-9 * abs(float(z[f"ms{j}_gamma"]))
+        assert rel(m["H"], z[f"ms{j}_H"]) <= 1e-12 and rel(m["res"], z[f"ms{j}_res"]) <= 1e-10
+        if m["inlier"]:
+            assert rel(m["S"], z[f"ms{j}_S"]) <= 1e-10 and rel(m["P_j"], z[f"ms{j}_Pj"]) <= 1e-14
+            Pn, corr = eng.apply_ci(m["P_j"], m["H"], m["res"], m["S"])
+            assert rel(Pn, z[f"ms{j}_Ppost"]) <= 1e-9 and rel(corr, z[f"ms{j}_corr"]) <= 1e-8
+    with pytest.raises(xk.XkError):   # anchor_idx < 0 throws in the reference (multi_slam_update.cpp:83-85)
+        eng.multi_slam_match(a["C_q_G"], a["G_p_C"], a["slam_feat"], -1, 0, a["P"], N, b["C_q_G"], b["G_p_C"],
+                             b["slam_feat"], 0, 0, b["P"], N, 0.1, 0.4)
+    eng.close()
+
+
+def test_collaborative_update_sequential_overwrite(xk, oracle_c):
+    """Updater::collaborativeUpdate applies applyCI per match, every P_j built from the SAME prior;
+    the covariance after the loop reflects only the last match."""
+    z = np.load(os.path.join(GOLDEN_DIR, "ci_two_agents.npz"))
+    a = {k[2:]: z[k] for k in z.files if k.startswith("a_")}
+    N = int(z["n_poses_max"])
+    eng = xk.Engine(N, 4, 12)
+    last = None
+    for j in range(4):
+        if not bool(z[f"ms{j}_inlier"]):
+            continue
+        last, _ = eng.apply_ci(z[f"ms{j}_Pj"], z[f"ms{j}_H"], z[f"ms{j}_res"], z[f"ms{j}_S"])
+    assert last is not None and rel(last, z["ms3_Ppost"]) <= 1e-9
+    eng.close()

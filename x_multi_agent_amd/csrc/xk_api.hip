@@ -879,8 +879,9 @@ __global__ void xk_pack_small(const double *hdr_dyn /*24*/, const double *p, con
 }
 
 extern "C" int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, const double *dyn16,
-                               double **d_payload) {
-  if (!h || !dyn16 || !d_payload) return XK_EINVAL;
+                               double *d_dst, double **d_payload) {
+  if (!h || !dyn16) return XK_EINVAL;
+  double *dst = d_dst ? d_dst : h->d_payload;
   HIPCHK(h, hipSetDevice(h->device));
   double *hd = h->h_pin;
   hd[0] = agent_id; hd[1] = timestamp; hd[2] = h->N; hd[3] = h->Mmax; hd[4] = h->n; hd[5] = h->n_poses;
@@ -889,10 +890,25 @@ extern "C" int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, 
   HIPCHK(h, hipMemcpyAsync(h->d_ci, hd, sizeof(double) * 24, hipMemcpyHostToDevice, h->stream));
   const int small = 24 + 7 * h->N + 4 * h->Mmax;
   hipLaunchKernelGGL(xk_pack_small, dim3((small + 255) / 256), dim3(256), 0, h->stream, h->d_ci, h->d_p, h->d_q,
-                     h->n_poses, h->d_feat, h->d_anchor, h->M, h->N, h->Mmax, h->d_payload);
-  HIPCHK(h, hipMemcpyAsync(h->d_payload + small, h->d_P, sizeof(double) * (size_t)h->n * h->n,
+                     h->n_poses, h->d_feat, h->d_anchor, h->M, h->N, h->Mmax, dst);
+  HIPCHK(h, hipMemcpyAsync(dst + small, h->d_P, sizeof(double) * (size_t)h->n * h->n,
                            hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  *d_payload = h->d_payload;
+  if (d_payload) *d_payload = dst;
   return XK_OK;
+}
+
+extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
+  if (!h || steps < 0 || !(sigma_img > 0.0)) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int it = 0; it < steps; ++it) {
+    int rc = launch_build(h, sigma_img);
+    if (rc != XK_OK) return rc;
+    rc = launch_tsqr(h);
+    if (rc != XK_OK) return rc;
+    UpdateSpec u = compressed_spec(h, nullptr, 1);
+    rc = launch_update(h, u);
+    if (rc != XK_OK) return rc;
+  }
+  return read_status(h);
 }

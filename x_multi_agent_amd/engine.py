@@ -26,7 +26,7 @@ SYMBOLS = [
     "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match",
-    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged",
+    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps",
 ]
 
 
@@ -301,9 +301,14 @@ class Engine:
     def payload_doubles(self):
         return int(self.L.xk_payload_doubles(C.c_int(self.N), C.c_int(self.M)))
 
-    def pack_payload(self, agent_id, timestamp, dyn16):
+    def pack_payload_into(self, agent_id, timestamp, dyn16, device_ptr=None):
+        """Pack the SimpleState payload into a caller-owned DEVICE buffer (e.g. a torch tensor's data_ptr)."""
         d, dp = _d(dyn16)
         ptr = c_dp()
-        self._chk(self.L.xk_pack_payload(self.h, C.c_double(agent_id), C.c_double(timestamp), dp, C.byref(ptr)),
-                  "xk_pack_payload")
+        dst = C.cast(C.c_void_p(device_ptr), c_dp) if device_ptr else None
+        self._chk(self.L.xk_pack_payload(self.h, C.c_double(agent_id), C.c_double(timestamp), dp, dst,
+                                         C.byref(ptr)), "xk_pack_payload")
         return C.cast(ptr, C.c_void_p).value
+
+    def run_steps(self, sigma_img, steps):
+        self._chk(self.L.xk_run_steps(self.h, C.c_double(sigma_img), C.c_int(steps)), "xk_run_steps")
