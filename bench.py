@@ -102,7 +102,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
-    from x_multi_agent_amd import engine, synth
+    from x_multi_agent_amd import engine, fleet, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); no CPU fallback exists")
@@ -119,18 +119,17 @@ def main():
     eng.stage(sc)
     sigma = sc["sigma_img"]
 
-    # CI payload exchange buffers (torch owns them so RCCL can use them directly)
+    # CI payload exchange (torch owns the buffers so RCCL sends/receives them in place)
     pay_n = eng.payload_doubles()
-    send = torch.empty(pay_n, dtype=torch.float64, device=f"cuda:{local_rank}")
-    recv = torch.empty(pay_n * world, dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+    ex = fleet.Exchange(dist, world, rank, pay_n, f"cuda:{local_rank}")
     dyn16 = np.zeros(16)
     dyn16[9] = 1.0
 
     def exchange(step):
         if world == 1:
             return
-        eng.pack_payload_into(rank, float(step), dyn16, send.data_ptr())
-        dist.all_gather_into_tensor(recv, send)
+        eng.pack_payload_into(rank, float(step), dyn16, ex.send.data_ptr())
+        ex.all_gather()
 
     def sync():
         torch.cuda.synchronize()

@@ -199,6 +199,11 @@ int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_ti
  * them; nothing crosses PCIe.  This is the timed region of bench.py. */
 int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 
+/* Micro-benchmark of the fp64 ceiling this path is priced against: a grid of
+ * waves issuing independent v_mfma_f64_16x16x4_f64 (use_mfma=1) or v_fma_f64
+ * (use_mfma=0) chains.  Reports sustained TFLOP/s. */
+int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the agent sharding + CI payload exchange
+(the same fleet.Exchange code bench.py drives over RCCL)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from oracle import c_oracle
+    from x_multi_agent_amd import fleet, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, K, M = 6, 12, 4
+        base = synth.make_scenario(N, K, M, seed=synth.seed_for(4, 0) + 7)
+        mine = base if rank == 0 else synth.make_scenario(N, K, M, seed=synth.seed_for(4, rank) + 7,
+                                                          agent_offset=0.05 * rank,
+                                                          landmarks=base["landmarks_true"])
+        lay = fleet.payload_layout(N, M)
+        ex = fleet.Exchange(dist, world, rank, lay["total"], "cpu")
+        dyn = np.arange(16, dtype=float) + 100 * rank
+        ex.send.copy_(torch.from_numpy(fleet.pack_payload_host(rank, 0.1 * rank, dyn, mine["C_q_G"], mine["G_p_C"],
+                                                               mine["slam_feat"], mine["slam_anchor_idxs"],
+                                                               mine["P"], N, M)))
+        allp = ex.all_gather().numpy()
+        other = 1 - rank
+        o = fleet.unpack_payload(allp[other], N, M)
+        me = fleet.unpack_payload(allp[rank], N, M)
+        assert o["agent_id"] == other and me["agent_id"] == rank
+        assert np.array_equal(me["P"], mine["P"]) and np.array_equal(me["C_q_G"], mine["C_q_G"])
+        # request/response delivers the same bytes point to point
+        got = ex.request_response(fleet.ring_requests(world, tick=0))
+        assert list(got) == [other] and np.array_equal(got[other].numpy(), allp[other])
+        # the received snapshot is sufficient for the CI step (a16): run the SLAM-SLAM match locally
+        m = c_oracle.multi_slam_match(mine["C_q_G"], mine["G_p_C"], mine["slam_feat"], int(mine["slam_anchor_idxs"][0]),
+                                      0, mine["P"], N, o["C_q_G"], o["G_p_C"], o["feat"], int(o["anchors"][0]), 0,
+                                      o["P"], N, 0.1, 0.4)
+        q.put((rank, "ok", float(m["gamma"]), float(np.abs(o["P"]).sum())))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "fail: " + repr(e), 0.0, 0.0))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_agents_exchange_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    # gamma of the match is symmetric in the two agents' data up to the sign of the residual
+    assert res[0][2] > 0 and res[1][2] > 0
+
+
+def test_payload_roundtrip_and_layout():
+    sys.path.insert(0, ROOT)
+    from x_multi_agent_amd import engine, fleet, synth
+    sc = synth.make_scenario(5, 4, 3, seed=5, n_poses=4)
+    lay = fleet.payload_layout(5, 3)
+    assert lay["total"] == engine.lib().xk_payload_doubles(5, 3)
+    buf = fleet.pack_payload_host(7, 1.5, np.arange(16.0), sc["C_q_G"], sc["G_p_C"], sc["slam_feat"],
+                                  sc["slam_anchor_idxs"], sc["P"], 5, 3)
+    u = fleet.unpack_payload(buf, 5, 3)
+    assert u["agent_id"] == 7 and u["n_poses"] == 4 and np.array_equal(u["P"], sc["P"])
+    assert np.array_equal(u["anchors"], sc["slam_anchor_idxs"]) and np.array_equal(u["feat"], sc["slam_feat"])
+    assert fleet.ring_requests(4, 0) == [(0, 1), (1, 2), (2, 3), (3, 0)]
+    assert fleet.ring_requests(1, 0) == []

@@ -119,3 +119,23 @@ def test_collaborative_update_sequential_overwrite(xk, oracle_c):
         last, _ = eng.apply_ci(z[f"ms{j}_Pj"], z[f"ms{j}_H"], z[f"ms{j}_res"], z[f"ms{j}_S"])
     assert last is not None and rel(last, z["ms3_Ppost"]) <= 1e-9
     eng.close()
+
+
+def test_device_payload_matches_host_layout(xk):
+    """xk_pack_payload writes the SimpleState payload straight into a caller-owned device buffer
+    (the RCCL send buffer); the bytes must equal the host packer's (fleet.pack_payload_host)."""
+    import torch
+    from x_multi_agent_amd import fleet
+    sc = synth.make_scenario(6, 10, 3, seed=55, n_poses=5)
+    eng = xk.Engine(6, 3, 10)
+    eng.stage(sc)
+    send = torch.zeros(eng.payload_doubles(), dtype=torch.float64, device="cuda:0")
+    dyn = np.arange(16.0)
+    eng.pack_payload_into(2, 0.25, dyn, send.data_ptr())
+    torch.cuda.synchronize()
+    host = fleet.pack_payload_host(2, 0.25, dyn, sc["C_q_G"], sc["G_p_C"], sc["slam_feat"], sc["slam_anchor_idxs"],
+                                   sc["P"], 6, 3)
+    assert np.array_equal(send.cpu().numpy(), host)
+    u = fleet.unpack_payload(send.cpu().numpy(), 6, 3)
+    assert u["n_poses"] == 5 and np.array_equal(u["P"], sc["P"])
+    eng.close()

@@ -107,7 +107,8 @@ def test_no_measurements_and_all_outliers(xk):
     empty = dict(sc, trk_off=np.zeros(1, dtype=np.int32), obs_xy=np.zeros((0, 2)))
     got = eng.visual_update(empty)     # h.size() == 0 -> no update (updater.cpp:106)
     assert np.array_equal(got["P"], sc["P"]) and not got["correction"].any()
-    bad = dict(sc, obs_xy=sc["obs_xy"] + 0.5)   # every track fails the gate -> zero rows (Q1)
+    noise = 0.05 * np.random.default_rng(1).standard_normal(sc["obs_xy"].shape)
+    bad = dict(sc, obs_xy=sc["obs_xy"] + noise)   # every track fails the gate -> zero rows (Q1)
     got = eng.visual_update(bad)
     assert got["inlier"].sum() == 0
     assert rel(got["P"], 0.5 * (sc["P"] + sc["P"].T)) <= 1e-14 and np.abs(got["correction"]).max() <= 1e-14

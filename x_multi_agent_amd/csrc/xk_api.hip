@@ -912,3 +912,54 @@ extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
   }
   return read_status(h);
 }
+
+// ---------------------------------------------------------------------------
+// fp64 ceiling probe
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xk_probe_mfma(double *out, int iters) {
+  xk_d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3];
+}
+__global__ __launch_bounds__(256) void xk_probe_fma(double *out, int iters) {
+  double a[8];
+  const double x = 1.0 + threadIdx.x * 1e-9, y = 1e-9 * threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = k;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = fma(a[k], x, y);
+  }
+  double s = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += a[k];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
+  if (!h || !tflops) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int blocks = 256 * 8, iters = 20000;
+  double *buf = nullptr;
+  HIPCHK(h, hipMalloc((void **)&buf, sizeof(double) * blocks * 256));
+  for (int rep = 0; rep < 2; ++rep) {
+    HIPCHK(h, hipEventRecord(h->ev[8], h->stream));
+    if (use_mfma) hipLaunchKernelGGL(xk_probe_mfma, dim3(blocks), dim3(256), 0, h->stream, buf, iters);
+    else hipLaunchKernelGGL(xk_probe_fma, dim3(blocks), dim3(256), 0, h->stream, buf, iters);
+    HIPCHK(h, hipEventRecord(h->ev[9], h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  float ms = 0;
+  hipEventElapsedTime(&ms, h->ev[8], h->ev[9]);
+  hipFree(buf);
+  const double waves = (double)blocks * 4;
+  const double flops = use_mfma ? waves * iters * 4.0 * (2.0 * 16 * 16 * 4) : waves * 64.0 * iters * 8.0 * 2.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  return XK_OK;
+}

@@ -26,7 +26,7 @@ SYMBOLS = [
     "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match",
-    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps",
+    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
 ]
 
 
@@ -297,6 +297,11 @@ class Engine:
                             for s in range(XK_NSTAGE)},
                     n=t.n, c1=t.c1, k_tracks=t.k_tracks, rows_stacked=t.rows_stacked, n_leaf=t.n_leaf,
                     n_levels=t.n_levels)
+
+    def probe_fp64_peak(self, use_mfma=True):
+        t = C.c_double()
+        self._chk(self.L.xk_probe_fp64_peak(self.h, C.c_int(int(use_mfma)), C.byref(t)), "xk_probe_fp64_peak")
+        return t.value
 
     def payload_doubles(self):
         return int(self.L.xk_payload_doubles(C.c_int(self.N), C.c_int(self.M)))

@@ -1,0 +1,116 @@
+"""One-agent-per-GPU fleet plumbing: payload layout and the CI exchange step.
+
+Each agent is a complete filter (reference: `VIO` owns its `Ekf`, state and P;
+include/x/vio/vio.h:225-247); the only coupling is the CI message, a
+`SimpleState` snapshot (include/x/ekf/simple_state.h:33-35, assembled at
+src/x/vio/vio.cpp:447-450).  Agents therefore shard one per rank with NO
+data-path collective inside an update; every `ci_every` updates the payloads
+are exchanged:
+  broadcast mode   (VIO::getDataToSend, vio.cpp:440-451)     -> one all-gather
+  request/response (VIO::processOtherRequests, vio.cpp:462-496) -> send/recv pairs
+The same functions run over RCCL (backend "nccl", GPU tensors) in bench.py and
+over gloo (CPU tensors) in tests/test_fleet_gloo.py.
+
+Payload (all doubles, matches xk_payload_doubles / xk_pack_payload in xk.h):
+  hdr[8]  {agent_id, timestamp, N, M, n, n_poses_valid, 0, 0}
+  dyn[16] p,v,q(xyzw),b_w,b_a        (State::getDynamicStates, state.cpp:87-99)
+  pos[3N] att[4N xyzw] feat[3M] anchors[M]  cov[n*n] column-major
+"""
+import numpy as np
+
+K_CORE = 15
+
+
+def payload_layout(N, M):
+    n = K_CORE + 6 * N + 3 * M
+    o = {}
+    o["hdr"] = (0, 8)
+    o["dyn"] = (8, 24)
+    o["pos"] = (24, 24 + 3 * N)
+    o["att"] = (o["pos"][1], o["pos"][1] + 4 * N)
+    o["feat"] = (o["att"][1], o["att"][1] + 3 * M)
+    o["anchors"] = (o["feat"][1], o["feat"][1] + M)
+    o["cov"] = (o["anchors"][1], o["anchors"][1] + n * n)
+    o["total"] = o["cov"][1]
+    o["n"] = n
+    return o
+
+
+def pack_payload_host(agent_id, timestamp, dyn16, C_q_G, G_p_C, feat, anchors, P, N, M):
+    """Host-side packer with the layout of the device packer (xk_pack_payload)."""
+    lay = payload_layout(N, M)
+    buf = np.zeros(lay["total"])
+    npz = len(G_p_C)
+    buf[0:8] = [agent_id, timestamp, N, M, lay["n"], npz, 0, 0]
+    buf[8:24] = dyn16
+    buf[lay["pos"][0]:lay["pos"][0] + 3 * npz] = np.asarray(G_p_C, float).ravel()
+    buf[lay["att"][0]:lay["att"][0] + 4 * npz] = np.asarray(C_q_G, float).ravel()
+    mcur = 0 if feat is None else len(feat) // 3
+    if mcur:
+        buf[lay["feat"][0]:lay["feat"][0] + 3 * mcur] = feat
+    buf[lay["anchors"][0]:lay["anchors"][1]] = -1.0
+    if mcur:
+        buf[lay["anchors"][0]:lay["anchors"][0] + mcur] = anchors
+    buf[lay["cov"][0]:lay["cov"][1]] = np.asarray(P, float).ravel(order="F")
+    return buf
+
+
+def unpack_payload(buf, N, M):
+    """Inverse of the packers -> dict(agent_id, timestamp, n_poses, dyn, C_q_G, G_p_C, feat, anchors, P)."""
+    buf = np.asarray(buf, dtype=np.float64)
+    lay = payload_layout(N, M)
+    assert buf.size == lay["total"] and int(buf[2]) == N and int(buf[3]) == M and int(buf[4]) == lay["n"]
+    npz = int(buf[5])
+    n = lay["n"]
+    anchors = buf[lay["anchors"][0]:lay["anchors"][1]].astype(np.int32)
+    return dict(agent_id=int(buf[0]), timestamp=float(buf[1]), n_poses=npz, dyn=buf[8:24].copy(),
+                G_p_C=buf[lay["pos"][0]:lay["pos"][0] + 3 * npz].reshape(npz, 3).copy(),
+                C_q_G=buf[lay["att"][0]:lay["att"][0] + 4 * npz].reshape(npz, 4).copy(),
+                feat=buf[lay["feat"][0]:lay["feat"][1]].copy(), anchors=anchors,
+                P=buf[lay["cov"][0]:lay["cov"][1]].reshape(n, n, order="F").copy())
+
+
+class Exchange:
+    """CI message exchange over torch.distributed (RCCL on GPUs, gloo on CPU)."""
+
+    def __init__(self, dist, world, rank, payload_doubles, device):
+        import torch
+        self.dist, self.world, self.rank, self.n = dist, world, rank, payload_doubles
+        self.torch = torch
+        self.send = torch.zeros(payload_doubles, dtype=torch.float64, device=device)
+        self.recv = torch.zeros(payload_doubles * max(world, 1), dtype=torch.float64, device=device)
+
+    def all_gather(self):
+        """Broadcast mode: every agent receives every agent's payload (config 4)."""
+        if self.world == 1:
+            self.recv.copy_(self.send)
+        else:
+            self.dist.all_gather_into_tensor(self.recv, self.send)
+        return self.recv.view(max(self.world, 1), self.n)
+
+    def request_response(self, requests):
+        """Request/response mode (config 5): `requests` = list of (requester, responder) pairs for
+        this tick; the responder's payload goes point-to-point to the requester.  Returns
+        {responder: tensor} for the pairs in which this rank is the requester."""
+        got = {}
+        ops = []
+        for req, rsp in requests:
+            if req == rsp:
+                continue
+            if self.rank == rsp:
+                ops.append(self.dist.P2POp(self.dist.isend, self.send, req))
+            if self.rank == req:
+                buf = self.torch.empty_like(self.send)
+                got[rsp] = buf
+                ops.append(self.dist.P2POp(self.dist.irecv, buf, rsp))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        return got
+
+
+def ring_requests(world, tick):
+    """Deterministic 5 Hz request pattern: at tick t agent a asks agent (a + 1 + t mod (world-1)) mod world."""
+    if world < 2:
+        return []
+    return [(a, (a + 1 + tick % (world - 1)) % world) for a in range(world)]
