@@ -130,6 +130,7 @@ def test_device_payload_matches_host_layout(xk):
     eng = xk.Engine(6, 3, 10)
     eng.stage(sc)
     send = torch.zeros(eng.payload_doubles(), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()   # the engine packs on its own stream
     dyn = np.arange(16.0)
     eng.pack_payload_into(2, 0.25, dyn, send.data_ptr())
     torch.cuda.synchronize()

@@ -16,9 +16,9 @@ import json
 print(json.dumps({'fp64_mfma_tflops': e.probe_fp64_peak(True), 'fp64_fma_tflops': e.probe_fp64_peak(False)}))
 " > $OUT/fp64_peak.json 2>$OUT/fp64_peak.err
 cat $OUT/fp64_peak.json
-rocprofv3 --kernel-trace --stats -d $OUT/prof_r01_trace -o r01 -- python bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_r01_trace -o r01 -- python bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_prof.log 2>&1
 tail -2 $OUT/bench_prof.log | cut -c1-300
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_r01_fetch -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_r01_write -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/prof_r01_sq -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_r01_fetch -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_r01_write -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/prof_r01_sq -o r01 -- python bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench_sq.log 2>&1
 find $OUT -name "*.csv" | head -30

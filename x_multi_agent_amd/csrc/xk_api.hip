@@ -300,18 +300,36 @@ static int launch_build(xk_handle *h, double sigma_img) {
   return XK_OK;
 }
 
-template <int NB, int MAXT>
+template <int NB, int SPLIT, int MAXT, bool RLDS>
 static void launch_tsqr_t(xk_handle *h, XkQrArgs &a, int *levels, hipEvent_t mid) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_leaf<NB, MAXT>), dim3(a.nleaf), dim3(h->qr_threads), 0, h->stream, a);
+  // packed destination triangle in LDS (RLDS): C1*(C1+1)/2 doubles
+  const size_t lds = RLDS ? sizeof(double) * ((size_t)a.C1 * (a.C1 + 1) / 2 + 2) : 0;
+  const int threads = round_up(SPLIT * a.C1, 64);
+  static bool attr_done = false;
+  if (RLDS && !attr_done) {
+    hipFuncSetAttribute((const void *)xk_tsqr_leaf<NB, SPLIT, MAXT, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    hipFuncSetAttribute((const void *)xk_tsqr_merge<NB, SPLIT, MAXT, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_leaf<NB, SPLIT, MAXT, RLDS>), dim3(a.nleaf), dim3(threads), lds, h->stream, a);
   if (mid) hipEventRecord(mid, h->stream);
   int lv = 0;
   for (int s = 1; s < a.nleaf; s *= 2) {
     a.stride = s;
     const int grid = (a.nleaf + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_merge<NB, MAXT>), dim3(grid), dim3(h->qr_threads), 0, h->stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_merge<NB, SPLIT, MAXT, RLDS>), dim3(grid), dim3(threads), lds, h->stream, a);
     ++lv;
   }
   *levels = lv;
+}
+
+template <int SPLIT, int MAXT, bool RLDS>
+static void launch_tsqr_nb(xk_handle *h, XkQrArgs &a, int *levels, hipEvent_t mid, int nb) {
+  switch (nb) {
+    case 16: launch_tsqr_t<16, SPLIT, MAXT, RLDS>(h, a, levels, mid); break;
+    case 32: launch_tsqr_t<32, SPLIT, MAXT, RLDS>(h, a, levels, mid); break;
+    default: launch_tsqr_t<64, SPLIT, MAXT, RLDS>(h, a, levels, mid); break;
+  }
 }
 
 static int pick_nleaf(xk_handle *h, int ntiles) {
@@ -335,19 +353,20 @@ static int launch_tsqr(xk_handle *h, hipEvent_t mid = nullptr) {
   a.DB = h->DB; a.C1P = h->C1P; a.C1 = h->C1; a.R = h->d_R; a.stride = 1;
   a.nleaf = pick_nleaf(h, a.ntiles);
   int lv = 0;
-  if (h->qr_threads <= 256) {  // one wave per SIMD: up to 512 VGPRs for the register-resident row block
-    switch (h->NBT) {
-      case 20: launch_tsqr_t<20, 256>(h, a, &lv, mid); break;
-      case 40: launch_tsqr_t<40, 256>(h, a, &lv, mid); break;
-      case 100: launch_tsqr_t<100, 256>(h, a, &lv, mid); break;
-      default: launch_tsqr_t<60, 256>(h, a, &lv, mid); break;
-    }
-  } else {  // two waves per SIMD: 256 VGPRs, row blocks of at most 60 (taller tiles take two passes)
-    switch (h->NBT) {
-      case 20: launch_tsqr_t<20, 512>(h, a, &lv, mid); break;
-      case 40: launch_tsqr_t<40, 512>(h, a, &lv, mid); break;
-      default: launch_tsqr_t<60, 512>(h, a, &lv, mid); break;
-    }
+  // Row block per pass: the smallest of {16, 32, 64} covering the tallest tile; taller tiles
+  // (window > 33 poses) take several passes.  Lanes per column: 4 while 4*C1 threads fit a
+  // workgroup of 768 (C1 <= 192), else 2 (C1 <= 352 at 704 threads, C1 <= 512 at 1024).
+  const int dmax = 2 * h->N - 3;
+  const int nb = dmax <= 16 ? 16 : dmax <= 32 ? 32 : 64;
+  // the packed triangle plus the broadcast buffers must fit the 160 KB LDS of a CU
+  const bool rlds = sizeof(double) * ((size_t)a.C1 * (a.C1 + 1) / 2 + 512) <= 156 * 1024 && !getenv("XK_NO_RLDS");
+  if (a.C1 <= 192) {
+    if (rlds) launch_tsqr_nb<4, 768, true>(h, a, &lv, mid, nb);
+    else launch_tsqr_nb<4, 768, false>(h, a, &lv, mid, nb);
+  } else if (a.C1 <= 352) {
+    launch_tsqr_nb<2, 704, false>(h, a, &lv, mid, nb);
+  } else {
+    launch_tsqr_nb<2, 1024, false>(h, a, &lv, mid, nb > 32 ? 32 : nb);
   }
   h->nleaf = a.nleaf;
   h->nlevels = lv;

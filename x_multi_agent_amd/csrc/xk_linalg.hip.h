@@ -19,56 +19,144 @@
 // column.  The reflector of step k only involves R[k][k] and B[:,k]
 // (rows of R below k are zero), i.e. v = [1; scale * B[:,k]].
 // ----------------------------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ void xk_qr_pass(double (&b)[NB], double *__restrict__ Rg, int ldr, int C1,
-                                           int kstart, bool first, double *vbuf /*[2][NB]*/,
-                                           double *sc /*[2][2]*/) {
-  const int j = threadIdx.x;
+// Access to the destination triangle R during a pass.
+//   XkRLds : R packed (row k holds columns k..C1-1) in LDS -- 132 KB at C1 = 181;
+//            loaded/stored to global once per kernel, every step's row access is an
+//            LDS access.
+//   XkRGlb : R in global memory (row-major, ld = C1P) with a 3-step register
+//            prefetch ring, for systems whose triangle does not fit the 160 KB LDS.
+struct XkRLds {
+  double *base;
+  int C1;
+  __device__ __forceinline__ int off(int k) const { return k * C1 - (k * (k - 1)) / 2 - k; }  // + j
+  __device__ __forceinline__ double ld(int k, int j) const { return base[off(k) + j]; }
+  __device__ __forceinline__ void st(int k, int j, double v) const { base[off(k) + j] = v; }
+};
+struct XkRGlb {
+  double *base;
+  int ldr;
+  __device__ __forceinline__ double ld(int k, int j) const { return base[(size_t)k * ldr + j]; }
+  __device__ __forceinline__ void st(int k, int j, double v) const { base[(size_t)k * ldr + j] = v; }
+};
+
+typedef double xk_d2 __attribute__((ext_vector_type(2)));
+
+// 1/x and sqrt(x) from the hardware seeds plus Newton steps (~1 ulp).  The IEEE-exact
+// division/sqrt sequences are long dependent chains and sit on the critical path of every
+// Householder step; the reflector only needs tau and v consistent to rounding.
+__device__ __forceinline__ double xk_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(y, fma(-x, y, 1.0), y);
+  y = fma(y, fma(-x, y, 1.0), y);
+  return y;
+}
+__device__ __forceinline__ double xk_sqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);          // ~1/sqrt(a)
+  double h = 0.5 * y;
+  double g = a * y;                            // ~sqrt(a)
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  return fma(fma(-g, g, a), h, g);             // final residual correction
+}
+
+// Sum over the SPLIT (2 or 4) adjacent lanes that share a column, with quad-permute DPP moves
+// (no LDS round trip, unlike ds_bpermute-based shuffles).
+template <int CTRL>
+__device__ __forceinline__ double xk_dpp_quad(double x) {
+  const long long q = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(q & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(q >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int SPLIT>
+__device__ __forceinline__ double xk_group_sum(double x) {
+  x += xk_dpp_quad<0xB1>(x);                 // quad_perm [1,0,3,2]: lane ^ 1
+  if (SPLIT == 4) x += xk_dpp_quad<0x4E>(x); // quad_perm [2,3,0,1]: lane ^ 2
+  return x;
+}
+
+// One pass of the structured Householder update R <- qr([R; B]).
+//   SPLIT lanes share a column: lane (col, part) holds rows [part*RPL, (part+1)*RPL) of that
+//   column in registers (RPL = NB / SPLIT); partial dot products are combined with an xor
+//   butterfly inside the lane group.  With SPLIT = 4 a 181-column system runs 12 waves per CU
+//   (3 per SIMD), so the dependent fp64 latencies of one wave hide behind the others.
+template <int NB, int SPLIT, typename RA>
+__device__ __forceinline__ void xk_qr_pass(double (&b)[NB / SPLIT], const RA &R, int C1, int kstart, bool first,
+                                           double *vbuf, double *sc /*[2][2]*/) {
+  constexpr int RPL = NB / SPLIT;      // rows per lane
+  constexpr int RPLP = RPL + 2;        // LDS stride of one part (bank spread)
+  static_assert(RPL % 2 == 0, "rows per lane must be even (16-byte LDS accesses)");
+  const int col = threadIdx.x / SPLIT, part = threadIdx.x % SPLIT;
+  const bool mine = col < C1;
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0;  // prefetch ring: rows kstart..kstart+2
+  if (!first && mine) {
+    if (col >= kstart && kstart < C1) r0 = R.ld(kstart, col);
+    if (col >= kstart + 1 && kstart + 1 < C1) r1 = R.ld(kstart + 1, col);
+    if (col >= kstart + 2 && kstart + 2 < C1) r2 = R.ld(kstart + 2, col);
+  }
   for (int k = kstart; k < C1; ++k) {
     const int pb = k & 1;
-    double rkj = 0.0;
-    if (!first && j >= k && j < C1) rkj = Rg[(size_t)k * ldr + j];
-    if (j == k) {
-      double s = 0.0;
+    const double rkj = r0;
+    r0 = r1;
+    r1 = r2;
+    r2 = (!first && mine && k + 3 < C1 && col >= k + 3) ? R.ld(k + 3, col) : 0.0;
+    xk_d2 *vseg = reinterpret_cast<xk_d2 *>(vbuf + (pb * SPLIT + part) * RPLP);
+    if (col == k) {
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        s += b[r] * b[r];
-        vbuf[pb * NB + r] = b[r];
+      for (int r = 0; r < RPL; r += 2) {
+        if (r & 2) { s2 = fma(b[r], b[r], s2); s3 = fma(b[r + 1], b[r + 1], s3); }
+        else { s0 = fma(b[r], b[r], s0); s1 = fma(b[r + 1], b[r + 1], s1); }
+        xk_d2 t = {b[r], b[r + 1]};
+        vseg[r >> 1] = t;
       }
-      double tau, scale, beta;
-      if (s <= 2.2250738585072014e-308) {
-        tau = 0.0; scale = 0.0; beta = rkj;
-      } else {
-        beta = sqrt(rkj * rkj + s);
-        if (rkj >= 0) beta = -beta;
-        tau = (beta - rkj) / beta;
-        scale = 1.0 / (rkj - beta);
+      const double s = xk_group_sum<SPLIT>((s0 + s1) + (s2 + s3));
+      if (part == 0) {
+        double tau, scale, beta;
+        if (s <= 2.2250738585072014e-308) {
+          tau = 0.0; scale = 0.0; beta = rkj;
+        } else {
+          beta = xk_sqrt(fma(rkj, rkj, s));
+          if (rkj >= 0) beta = -beta;
+          tau = (beta - rkj) * xk_rcp(beta);
+          scale = xk_rcp(rkj - beta);
+        }
+        sc[pb * 2] = tau;
+        sc[pb * 2 + 1] = scale;
+        if (first || tau != 0.0) R.st(k, k, beta);
       }
-      sc[pb * 2] = tau;
-      sc[pb * 2 + 1] = scale;
-      if (first || tau != 0.0) Rg[(size_t)k * ldr + k] = beta;
 #pragma unroll
-      for (int r = 0; r < NB; ++r) b[r] = 0.0;
+      for (int r = 0; r < RPL; ++r) b[r] = 0.0;
     }
     __syncthreads();
     const double tau = sc[pb * 2];
-    if (j > k && j < C1) {
+    const double scale = sc[pb * 2 + 1];
+    xk_d2 v[RPL / 2];  // read unconditionally: overlaps the LDS latency with the scalars' read
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) v[r] = vseg[r];
+    if (col > k && mine) {
       if (tau != 0.0) {
-        const double scale = sc[pb * 2 + 1];
-        double d0 = 0.0, d1 = 0.0;
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-        for (int r = 0; r + 1 < NB; r += 2) {
-          d0 += vbuf[pb * NB + r] * b[r];
-          d1 += vbuf[pb * NB + r + 1] * b[r + 1];
+        for (int r = 0; r < RPL / 2; ++r) {
+          if (r & 1) { d2 = fma(v[r][0], b[2 * r], d2); d3 = fma(v[r][1], b[2 * r + 1], d3); }
+          else { d0 = fma(v[r][0], b[2 * r], d0); d1 = fma(v[r][1], b[2 * r + 1], d1); }
         }
-        if (NB & 1) d0 += vbuf[pb * NB + NB - 1] * b[NB - 1];
-        const double w = tau * (rkj + scale * (d0 + d1));
-        Rg[(size_t)k * ldr + j] = rkj - w;
-        const double ws = w * scale;
+        const double d = xk_group_sum<SPLIT>((d0 + d1) + (d2 + d3));
+        const double w = tau * fma(scale, d, rkj);
+        if (part == 0) R.st(k, col, rkj - w);
+        const double ws = -w * scale;
 #pragma unroll
-        for (int r = 0; r < NB; ++r) b[r] -= ws * vbuf[pb * NB + r];
-      } else if (first) {
-        Rg[(size_t)k * ldr + j] = 0.0;
+        for (int r = 0; r < RPL / 2; ++r) {
+          b[2 * r] = fma(ws, v[r][0], b[2 * r]);
+          b[2 * r + 1] = fma(ws, v[r][1], b[2 * r + 1]);
+        }
+      } else if (first && part == 0) {
+        R.st(k, col, 0.0);
       }
     }
   }
@@ -84,50 +172,76 @@ struct XkQrArgs {
   int stride;  // merge: R[g*2*stride] <- qr([R[g*2*stride]; R[g*2*stride+stride]])
 };
 
+extern __shared__ __attribute__((aligned(16))) double xk_dyn_lds[];
+
+#define XK_QR_VBUF(NB, SPLIT) (2 * (SPLIT) * ((NB) / (SPLIT) + 2))
+
 // Leaf: workgroup g folds tiles g, g+nleaf, g+2*nleaf, ... into R[g].
-template <int NB, int MAXT>
+template <int NB, int SPLIT, int MAXT, bool RLDS>
 __global__ __launch_bounds__(MAXT) void xk_tsqr_leaf(XkQrArgs a) {
-  __shared__ double vbuf[2 * NB];
+  constexpr int RPL = NB / SPLIT;
+  __shared__ __attribute__((aligned(16))) double vbuf[XK_QR_VBUF(NB, SPLIT)];
   __shared__ double sc[4];
-  const int g = blockIdx.x, j = threadIdx.x;
+  const int g = blockIdx.x, col = threadIdx.x / SPLIT, part = threadIdx.x % SPLIT;
   double *Rg = a.R + (size_t)g * a.C1P * a.C1P;
   bool first = true;
-  double b[NB];
+  double b[RPL];
+  XkRLds rl{xk_dyn_lds, a.C1};
+  XkRGlb rg{Rg, a.C1P};
   for (int t = g; t < a.ntiles; t += a.nleaf) {
     const int rows = a.tile_rows[t];
     if (rows == 0) continue;
     const double *tile = a.A + (size_t)t * a.DB * a.C1P;
     for (int r0 = 0; r0 < rows; r0 += NB) {
 #pragma unroll
-      for (int r = 0; r < NB; ++r)
-        b[r] = (r0 + r < rows && j < a.C1) ? tile[(size_t)(r0 + r) * a.C1P + j] : 0.0;
-      xk_qr_pass<NB>(b, Rg, a.C1P, a.C1, 0, first, vbuf, sc);
+      for (int r = 0; r < RPL; ++r) {
+        const int row = r0 + part * RPL + r;
+        b[r] = (row < rows && col < a.C1) ? tile[(size_t)row * a.C1P + col] : 0.0;
+      }
+      if (RLDS) xk_qr_pass<NB, SPLIT>(b, rl, a.C1, 0, first, vbuf, sc);
+      else xk_qr_pass<NB, SPLIT>(b, rg, a.C1, 0, first, vbuf, sc);
       first = false;
     }
   }
-  if (first)  // no data at all: define R = 0 so the merges stay well formed
-    for (int k = 0; k < a.C1; ++k)
-      if (j >= k && j < a.C1) Rg[(size_t)k * a.C1P + j] = 0.0;
+  if (part != 0 || col >= a.C1) return;
+  if (first) {  // no data at all: define R = 0 so the merges stay well formed
+    for (int k = 0; k <= col; ++k) Rg[(size_t)k * a.C1P + col] = 0.0;
+  } else if (RLDS) {
+    for (int k = 0; k <= col; ++k) Rg[(size_t)k * a.C1P + col] = rl.ld(k, col);
+  }
 }
 
 // Merge: the source triangle is fed as row blocks; rows [r0, r0+NB) have
 // leading zeros up to column r0, so the pass starts at step r0.
-template <int NB, int MAXT>
+template <int NB, int SPLIT, int MAXT, bool RLDS>
 __global__ __launch_bounds__(MAXT) void xk_tsqr_merge(XkQrArgs a) {
-  __shared__ double vbuf[2 * NB];
+  constexpr int RPL = NB / SPLIT;
+  __shared__ __attribute__((aligned(16))) double vbuf[XK_QR_VBUF(NB, SPLIT)];
   __shared__ double sc[4];
-  const int g = blockIdx.x, j = threadIdx.x;
+  const int g = blockIdx.x, col = threadIdx.x / SPLIT, part = threadIdx.x % SPLIT;
   const int dst = g * 2 * a.stride, src = dst + a.stride;
   if (src >= a.nleaf) return;
   double *Rd = a.R + (size_t)dst * a.C1P * a.C1P;
   const double *Rs = a.R + (size_t)src * a.C1P * a.C1P;
-  double b[NB];
+  double b[RPL];
+  XkRLds rl{xk_dyn_lds, a.C1};
+  XkRGlb rg{Rd, a.C1P};
+  if (RLDS) {
+    if (part == 0 && col < a.C1)
+      for (int k = 0; k <= col; ++k) rl.st(k, col, Rd[(size_t)k * a.C1P + col]);
+    __syncthreads();
+  }
   for (int r0 = 0; r0 < a.C1; r0 += NB) {
 #pragma unroll
-    for (int r = 0; r < NB; ++r)
-      b[r] = (r0 + r < a.C1 && j >= r0 + r && j < a.C1) ? Rs[(size_t)(r0 + r) * a.C1P + j] : 0.0;
-    xk_qr_pass<NB>(b, Rd, a.C1P, a.C1, r0, false, vbuf, sc);
+    for (int r = 0; r < RPL; ++r) {
+      const int row = r0 + part * RPL + r;
+      b[r] = (row < a.C1 && col >= row && col < a.C1) ? Rs[(size_t)row * a.C1P + col] : 0.0;
+    }
+    if (RLDS) xk_qr_pass<NB, SPLIT>(b, rl, a.C1, r0, false, vbuf, sc);
+    else xk_qr_pass<NB, SPLIT>(b, rg, a.C1, r0, false, vbuf, sc);
   }
+  if (RLDS && part == 0 && col < a.C1)
+    for (int k = 0; k <= col; ++k) Rd[(size_t)k * a.C1P + col] = rl.ld(k, col);
 }
 
 // ----------------------------------------------------------------------------

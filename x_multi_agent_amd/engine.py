@@ -50,6 +50,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build it with `python -m x_multi_agent_amd.build` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        try:
+            # PyTorch bundles its own HIP runtime; whichever libamdhip64 is loaded first serves the
+            # whole process, so when torch is installed (it is the device-memory / RCCL plumbing of
+            # bench.py and the tests) load it first -- the other order leaves torch without a GPU.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.xk_strerror.restype = C.c_char_p
         L.xk_last_error.restype = C.c_char_p
