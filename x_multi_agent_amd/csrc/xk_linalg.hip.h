@@ -120,10 +120,14 @@ __device__ __forceinline__ void xk_qr_pass(double (&b)[NB / SPLIT], const RA &R,
         if (s <= 2.2250738585072014e-308) {
           tau = 0.0; scale = 0.0; beta = rkj;
         } else {
+#ifdef XK_EXP_NO_SQRT
+          beta = -(fabs(rkj) + s); tau = 1.5; scale = 0.25;
+#else
           beta = xk_sqrt(fma(rkj, rkj, s));
           if (rkj >= 0) beta = -beta;
           tau = (beta - rkj) * xk_rcp(beta);
           scale = xk_rcp(rkj - beta);
+#endif
         }
         sc[pb * 2] = tau;
         sc[pb * 2 + 1] = scale;
@@ -132,7 +136,9 @@ __device__ __forceinline__ void xk_qr_pass(double (&b)[NB / SPLIT], const RA &R,
 #pragma unroll
       for (int r = 0; r < RPL; ++r) b[r] = 0.0;
     }
+#ifndef XK_EXP_NO_BARRIER
     __syncthreads();
+#endif
     const double tau = sc[pb * 2];
     const double scale = sc[pb * 2 + 1];
     xk_d2 v[RPL / 2];  // read unconditionally: overlaps the LDS latency with the scalars' read
@@ -335,53 +341,53 @@ struct XkCholDiagArgs {
   int *status;   // set to 2 (XK_ESINGULAR) if a pivot is not positive
 };
 
+// One wave.  Lane t keeps row t of the block in registers (static indexing, fully unrolled);
+// column k of L is published through LDS and read back as wave-wide broadcasts, so there is no
+// workgroup barrier and no per-element index arithmetic.  L^-1 is built the same way: lane t
+// carries column t of the inverse in registers through a forward substitution.
 __global__ __launch_bounds__(64) void xk_chol_diag(XkCholDiagArgs a) {
-  __shared__ double L[XK_CHOL_NB][XK_CHOL_NB + 1];
-  __shared__ double Li[XK_CHOL_NB][XK_CHOL_NB + 1];
+  constexpr int B = XK_CHOL_NB;
+  __shared__ double Lc[B][B + 1];  // Lc[k][i] = L(i,k)  (column k contiguous)
+  __shared__ double dinv[B];
   const int t = threadIdx.x, nb = a.nb;
-  for (int idx = t; idx < nb * nb; idx += 64) {
-    const int i = idx / nb, j = idx - i * nb;
-    // read the upper triangle (row-oriented updates keep it current), mirror
-    const int r = i < j ? i : j, c = i < j ? j : i;
-    L[i][j] = a.Maug[(size_t)(a.kb + r) * a.ld + a.kb + c];
-    Li[i][j] = (i == j) ? 1.0 : 0.0;
+  double row[B];
+  // read the upper triangle (row-oriented updates keep it current): A(t,j) = M(min,max)
+#pragma unroll
+  for (int j = 0; j < B; ++j) {
+    const int r = t < j ? t : j, c = t < j ? j : t;
+    row[j] = (t < nb && j < nb) ? a.Maug[(size_t)(a.kb + r) * a.ld + a.kb + c] : ((t == j) ? 1.0 : 0.0);
   }
-  __syncthreads();
   bool bad = false;
-  for (int k = 0; k < nb; ++k) {
-    const double piv = L[k][k];
-    if (!(piv > 0.0)) { bad = true; break; }
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    const double piv = __shfl(row[k], k, 64);
+    if (!(piv > 0.0)) bad = true;
     const double inv = 1.0 / sqrt(piv);
-    __syncthreads();
-    if (t >= k && t < nb) L[t][k] *= inv;  // includes the diagonal: L[k][k] = sqrt(piv)
-    __syncthreads();
-    // trailing update of the lower triangle
-    const int cnt = nb - k - 1;
-    for (int idx = t; idx < cnt * cnt; idx += 64) {
-      const int ii = idx / cnt, jj = idx - ii * cnt;
-      if (jj > ii) continue;
-      L[k + 1 + ii][k + 1 + jj] -= L[k + 1 + ii][k] * L[k + 1 + jj][k];
-    }
-    __syncthreads();
+    const double lik = row[k] * inv;  // L(t,k) for t >= k (garbage above the diagonal, never used)
+    if (t < B) Lc[k][t] = lik;
+    if (t == k) dinv[k] = inv;        // 1 / L(k,k)
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = k + 1; j < B; ++j) row[j] = fma(-lik, Lc[k][j], row[j]);  // A(t,j) -= L(t,k) L(j,k)
   }
   if (bad) {
     if (t == 0) *a.status = 2;
-    // still emit a finite Linv so downstream kernels do not fault
-    for (int idx = t; idx < XK_CHOL_NB * XK_CHOL_NB; idx += 64) a.Linv[idx] = 0.0;
+    for (int idx = t; idx < B * B; idx += 64) a.Linv[idx] = 0.0;
     return;
   }
-  // Linv = L^-1 by forward substitution, one column per thread
-  if (t < nb) {
-    for (int i = t; i < nb; ++i) {
-      double s = (i == t) ? 1.0 : 0.0;
-      for (int m = t; m < i; ++m) s -= L[i][m] * Li[m][t];
-      Li[i][t] = s / L[i][i];
-    }
+  // forward substitution for column t of L^-1:  x_i = (delta_it - sum_{m<i} L(i,m) x_m) / L(i,i)
+  double x[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    double sum = (i == t) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < i; ++m) sum = fma(-Lc[m][i], x[m], sum);
+    x[i] = sum * dinv[i];
   }
-  __syncthreads();
-  for (int idx = t; idx < XK_CHOL_NB * XK_CHOL_NB; idx += 64) {
-    const int i = idx / XK_CHOL_NB, j = idx - i * XK_CHOL_NB;
-    a.Linv[idx] = (i < nb && j < nb && j <= i) ? Li[i][j] : 0.0;
+  if (t < B) {
+#pragma unroll
+    for (int i = 0; i < B; ++i) a.Linv[i * B + t] = (i < nb && t < nb && t <= i) ? x[i] : 0.0;
   }
 }
 
@@ -395,9 +401,16 @@ struct XkCorrArgs {
 __global__ void xk_corr(XkCorrArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  double s = 0.0;
-  for (int k = 0; k < a.c; ++k) s += a.X[(size_t)k * a.ld + a.xoff + i] * a.X[(size_t)k * a.ld + a.yoff];
-  a.corr[i] = s - (a.ct ? a.ct[i] : 0.0);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int k = 0;
+  for (; k + 4 <= a.c; k += 4) {
+    s0 = fma(a.X[(size_t)k * a.ld + a.xoff + i], a.X[(size_t)k * a.ld + a.yoff], s0);
+    s1 = fma(a.X[(size_t)(k + 1) * a.ld + a.xoff + i], a.X[(size_t)(k + 1) * a.ld + a.yoff], s1);
+    s2 = fma(a.X[(size_t)(k + 2) * a.ld + a.xoff + i], a.X[(size_t)(k + 2) * a.ld + a.yoff], s2);
+    s3 = fma(a.X[(size_t)(k + 3) * a.ld + a.xoff + i], a.X[(size_t)(k + 3) * a.ld + a.yoff], s3);
+  }
+  for (; k < a.c; ++k) s0 = fma(a.X[(size_t)k * a.ld + a.xoff + i], a.X[(size_t)k * a.ld + a.yoff], s0);
+  a.corr[i] = ((s0 + s1) + (s2 + s3)) - (a.ct ? a.ct[i] : 0.0);
 }
 
 // z'[k] = z[k] + sum_j T[k][j] * ct[col0 + j]     (res + H corr_tot, updater.cpp:126)
