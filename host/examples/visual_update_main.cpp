@@ -1,0 +1,81 @@
+// Drives ONE visual update through the mirrored reference API:
+//   Ekf::processUpdateMeasurement -> Updater::update -> VioUpdater::constructUpdate -> applyUpdate
+// Input/outputs are flat little-endian double files written/read by tests/test_gpu_host_cpp.py.
+//   in : N M K n_poses sigma_img | q[4N] p[3N] | L_k[K] | obs[2*sum L] | feat[3M] anchors[M] zlast[2M] tsz[M] | P[n*n]
+//   out: P_post[n*n] | p_array[3N] q_array[4N] f_array[3M] | inlier_msckf[K]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "x/ekf/ekf.h"
+#include "x/vio/vio_updater.h"
+
+using namespace x;
+
+static std::vector<double> slurp(const char *path) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { perror(path); exit(2); }
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<double> v(sz / sizeof(double));
+  if (fread(v.data(), sizeof(double), v.size(), f) != v.size()) exit(2);
+  fclose(f);
+  return v;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 2; }
+  const std::vector<double> in = slurp(argv[1]);
+  size_t at = 0;
+  const int N = (int)in[at++], M = (int)in[at++], K = (int)in[at++], n_poses = (int)in[at++];
+  const double sigma_img = in[at++];
+  const int n = kSizeCoreErr + 6 * N + 3 * M;
+  State s(N, M);
+  s.setTime(1.0);
+  for (int i = 0; i < 4 * N; ++i) s.q_array_(i) = in[at + i];
+  at += 4 * N;
+  for (int i = 0; i < 3 * N; ++i) s.p_array_(i) = in[at + i];
+  at += 3 * N;
+  VioMeasurement meas;
+  meas.timestamp = 1.0;
+  std::vector<int> L(K);
+  for (int k = 0; k < K; ++k) L[k] = (int)in[at++];
+  for (int k = 0; k < K; ++k) {
+    Track t;
+    for (int i = 0; i < L[k]; ++i) { t.emplace_back(in[at], in[at + 1]); at += 2; }
+    meas.msckf_tracks.push_back(t);
+  }
+  for (int i = 0; i < 3 * M; ++i) s.f_array_(i) = in[at + i];
+  at += 3 * M;
+  std::vector<int> anchors(M);
+  for (int j = 0; j < M; ++j) anchors[j] = (int)in[at++];
+  std::vector<double> zl(in.begin() + at, in.begin() + at + 2 * M);
+  at += 2 * M;
+  for (int j = 0; j < M; ++j) {
+    Track t((size_t)in[at + j] - 1, Feature(0, 0));
+    t.emplace_back(zl[2 * j], zl[2 * j + 1]);
+    meas.slam_tracks.push_back(t);
+  }
+  at += M;
+  for (size_t i = 0; i < (size_t)n * n; ++i) s.cov_.data()[i] = in[at + i];
+
+  VioUpdater updater(0, N, M, K > 0 ? K : 1, sigma_img);
+  updater.setWindow(n_poses, anchors);
+  updater.setMeasurement(meas);
+  Ekf ekf(updater);
+  ekf.set(4, State(N, M), nullptr, 0.02);
+  ekf.initializeFromState(s);
+  std::optional<State> post = ekf.processUpdateMeasurement();
+  if (!post) { fprintf(stderr, "no update applied\n"); return 3; }
+
+  FILE *f = fopen(argv[2], "wb");
+  fwrite(post->cov_.data(), sizeof(double), (size_t)n * n, f);
+  fwrite(post->p_array_.data(), sizeof(double), 3 * N, f);
+  fwrite(post->q_array_.data(), sizeof(double), 4 * N, f);
+  fwrite(post->f_array_.data(), sizeof(double), 3 * M, f);
+  for (int k = 0; k < K; ++k) { double v = updater.getMsckfInlierFlags()[k]; fwrite(&v, sizeof(double), 1, f); }
+  fclose(f);
+  printf("ok n=%d K=%d M=%d\n", n, K, M);
+  return 0;
+}

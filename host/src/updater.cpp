@@ -1,0 +1,71 @@
+// Mirror of src/x/ekf/updater.cpp.  Orchestration is the reference's; the Kalman algebra goes
+// through the C ABI (include/xk.h) into the HIP kernels.
+#include "x/ekf/updater.h"
+
+#include <stdexcept>
+#include <string>
+
+#include "xk.h"
+
+using namespace x;
+
+static void check(xk_handle *h, int rc, const char *what) {
+  if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + xk_last_error(h) + ")");
+}
+
+void Updater::collaborativeUpdate(State &state) {      // updater.cpp:22-36
+  if (preUpdateCI()) {
+    std::vector<std::shared_ptr<Matrix>> S_list, P_list, H_list, res_list;
+    constructSlamCIUpdate(state, S_list, P_list, H_list, res_list);
+    for (size_t i = 0; i < P_list.size(); i++) applyCI(state, *P_list[i], *H_list[i], *res_list[i], *S_list[i]);
+  }
+}
+
+void Updater::update(State &state) {                   // updater.cpp:39-115
+  Matrix h, res, r;
+  Matrix correction = Matrix::Zero(state.nErrorStates(), 1);
+  preProcess(state);
+  if (preUpdateShortMsckf()) {
+    constructShortMsckfUpdate(state, h, res, r);
+    if (h.size() > 0) applyUpdate(state, h, res, r, correction, true);
+  }
+  if (preUpdate(state)) {
+    correction = Matrix::Zero(state.nErrorStates(), 1);
+    for (int i = 0; i < iekf_iter_; i++) {
+      const bool is_last_iter = i == iekf_iter_ - 1;
+      constructUpdate(state, h, res, r);
+      if (h.size() > 0) applyUpdate(state, h, res, r, correction, is_last_iter);
+    }
+    postUpdate(state, correction);
+  }
+}
+
+void Updater::applyUpdate(State &state, const Matrix &H, const Matrix &res, const Matrix &R, Matrix &correction_total,
+                          const bool cov_update) {     // updater.cpp:117-141
+  Matrix &P = state.getCovarianceRef();
+  const int n = P.rows();
+  Matrix correction(n, 1);
+  if (compressed_on_device_) {
+    // constructUpdate left the compressed [T_H | z] and the prior covariance resident in HBM
+    check(xk_, xk_apply_update(xk_, correction_total.data(), cov_update ? 1 : 0, correction.data()), "xk_apply_update");
+    if (cov_update) check(xk_, xk_download_P(xk_, P.data(), n, n), "xk_download_P");
+    compressed_on_device_ = false;
+    for (int i = 0; i < n; ++i) correction_total(i) += correction(i);                     // :140
+  } else {
+    std::vector<double> rdiag(H.rows());
+    for (int i = 0; i < H.rows(); ++i) rdiag[i] = R(i, i);
+    check(xk_, xk_apply_update_dense(xk_, P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), rdiag.data(),
+                                     correction_total.data(), cov_update ? 1 : 0, correction.data()),
+          "xk_apply_update_dense");  // adds correction to correction_total (:140)
+  }
+  state.correct(correction);                                                                // :137
+}
+
+void Updater::applyCI(State &state, Matrix &ci_P, const Matrix &H, const Matrix &res, Matrix &S) {  // updater.cpp:144-161
+  Matrix &P = state.getCovarianceRef();
+  const int n = P.rows();
+  Matrix correction(n, 1);
+  check(xk_, xk_apply_ci(xk_, P.data(), n, ci_P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), S.data(),
+                         S.rows(), correction.data()), "xk_apply_ci");
+  state.correct(correction);
+}

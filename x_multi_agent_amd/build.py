@@ -25,5 +25,24 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_host(force=False, verbose=True):
+    """Host-side C++ mirror of the reference API (host/) and its example driver."""
+    root = os.path.join(HERE, "..")
+    lib = os.path.join(HERE, "libx_host.so")
+    exe = os.path.join(HERE, "xk_host_example")
+    srcs = [os.path.join(root, "host", "src", f) for f in ("state.cpp", "updater.cpp", "vio_updater.cpp", "ekf.cpp")]
+    inc = ["-I" + os.path.join(root, "host", "include"), "-I" + os.path.join(root, "include")]
+    link = ["-L" + HERE, "-lxk", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    cmds = [["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + inc + srcs + ["-o", lib] + link,
+            ["g++", "-std=c++17", "-O2", "-Wall"] + inc + [os.path.join(root, "host", "examples", "visual_update_main.cpp"),
+                                                           "-o", exe, "-L" + HERE, "-lx_host"] + link[1:]]
+    for c in cmds:
+        if verbose:
+            print(" ".join(c), flush=True)
+        subprocess.check_call(c)
+    return lib, exe
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_host()
