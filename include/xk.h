@@ -161,6 +161,28 @@ int xk_multi_slam_match(xk_handle *h, const double *C_q_G, const double *G_p_C, 
                         double ci_slam_w, int *inlier, double *gamma, double *H, int ldh, double *res,
                         double *S, double *P_j, int ldpj);
 
+/* MSCKF-MSCKF CI block of MsckfUpdate::preProcessOneTrack (src/x/vio/msckf_update.cpp:96-279)
+ * for ONE of this agent's tracks that k other agents also observed (k <= 7):
+ * joint triangulation over all agents' observations (matched agents first, self last,
+ * :113-165), own single-agent gate (:172, :457-463), column-space rows of every agent
+ * (:201-203, :439-443), null-space projection of the landmark (:207, :494-501),
+ * S_j over all agents (:217-237), chi2(2*sum(L) - 3, 0.95) gate (:243-250), fixed-weight
+ * fuseCI (:252-255) and the block scaling of P_j (:256-267).
+ *   obs [L x 2], own window lists / P as in xk_stage_*;
+ *   per matched agent i: m_obs[i] [m_L[i] x 2], m_q[i] [m_nposes[i] x 4], m_p[i]
+ *   [m_nposes[i] x 3] (its full window lists; its track sees the LAST m_L[i] poses),
+ *   m_P[i] [m_n[i] x m_n[i]] dense column-major, m_n[i] = 15 + 6*m_nposes[i] + 3*M_i.
+ * Outputs: *self_inlier, *self_gamma; *has_ci; if *has_ci: H (3k x n, ldh), res (3k),
+ * S (3k x 3k, lds), P_j (n x n, ldpj), feed them to xk_apply_ci.  H/res/S are defined up to
+ * a common orthogonal factor (basis of the null space), H^T S^-1 H and H^T S^-1 res are not. */
+int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const double *C_q_G, const double *G_p_C,
+                      int n_poses, const double *P, int ldp, int n, int n_poses_max, double sigma_img, int k,
+                      const double *const *m_obs, const int *m_L, const double *const *m_q,
+                      const double *const *m_p, const int *m_nposes, const double *const *m_P,
+                      const int *m_n, double ci_msckf_w, int *self_inlier, double *self_gamma, int *has_ci,
+                      double *ci_gamma, double *H, int ldh, double *res, double *S, int lds, double *P_j,
+                      int ldpj);
+
 /* ---- inter-agent payload (SimpleState, include/x/ekf/simple_state.h:33-35,
  * assembled at src/x/vio/vio.cpp:447-450) ------------------------------ */
 

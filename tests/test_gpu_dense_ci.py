@@ -140,3 +140,40 @@ def test_device_payload_matches_host_layout(xk):
     u = fleet.unpack_payload(send.cpu().numpy(), 6, 3)
     assert u["n_poses"] == 5 and np.array_equal(u["P"], sc["P"])
     eng.close()
+
+
+def test_msckf_ci_track_golden_and_oracle(xk, oracle_c):
+    """MSCKF-MSCKF CI block (msckf_update.cpp:96-279) on the device vs golden vectors and the C oracle;
+    H/res/S are compared through the basis-independent products."""
+    z = np.load(os.path.join(GOLDEN_DIR, "ci_two_agents.npz"))
+    a = {k[2:]: z[k] for k in z.files if k.startswith("a_")}
+    b = {k[2:]: z[k] for k in z.files if k.startswith("b_")}
+    N = int(z["n_poses_max"])
+    ta, tb = synth.tracks_as_list(a), synth.tracks_as_list(b)
+    eng = xk.Engine(N, 4, 12)
+    n_ci = 0
+    for j in range(len(ta)):
+        match = [dict(obs=tb[j], q_list=b["C_q_G"], p_list=b["G_p_C"], P=b["P"], n_poses_max=N)]
+        for w, matches in ((float(z["ci_msckf_w"]), match), (0.15, match + match)):
+            g = eng.msckf_ci_track(ta[j], a["C_q_G"], a["G_p_C"], a["P"], N, float(z["sigma_img"]), matches, w)
+            o = oracle_c.msckf_ci_track(ta[j], a["C_q_G"], a["G_p_C"], a["P"], N, float(z["sigma_img"]), matches, w)
+            assert g["self_inlier"] == o["self_inlier"]
+            assert abs(g["self_gamma"] - o["self_gamma"]) <= 1e-8 * abs(o["self_gamma"])
+            assert (g["ci"] is not None) == (o["ci"] is not None)
+            if o["self_inlier"]:
+                assert abs(g["ci_gamma"] - o["ci_gamma"]) <= 1e-7 * abs(o["ci_gamma"])
+            if g["ci"] is None:
+                continue
+            n_ci += 1
+            gc, oc = g["ci"], o["ci"]
+            Sg, So = np.linalg.inv(gc["S"]), np.linalg.inv(oc["S"])
+            assert rel(gc["H"].T @ Sg @ gc["H"], oc["H"].T @ So @ oc["H"]) <= 1e-7
+            assert rel(gc["H"].T @ Sg @ gc["res"], oc["H"].T @ So @ oc["res"]) <= 1e-7
+            assert rel(gc["P_j"], oc["P_j"]) <= 1e-14
+            Pg, cg = eng.apply_ci(gc["P_j"], gc["H"], gc["res"], gc["S"])
+            Po, co = oracle_c.apply_ci(oc["P_j"], oc["H"], oc["res"], oc["S"])
+            assert rel(Pg, Po) <= 1e-8 and rel(cg, co) <= 1e-7
+            if j < 4 and len(matches) == 1 and bool(z[f"mc{j}_has_ci"]):
+                assert rel(Pg, z[f"mc{j}_Ppost"]) <= 1e-8 and rel(cg, z[f"mc{j}_corr"]) <= 1e-7
+    assert n_ci >= 2
+    eng.close()

@@ -273,6 +273,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
+    a.gpf_in = nullptr; a.up_out = nullptr;
     const size_t lds = xk_feature_lds_bytes(h->n_poses);
     hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
   }
@@ -872,6 +873,160 @@ extern "C" int xk_multi_slam_match(xk_handle *h, const double *C_q_G, const doub
                                hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// MSCKF-MSCKF CI block (msckf_update.cpp:96-279) for one track
+// ---------------------------------------------------------------------------
+extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const double *C_q_G, const double *G_p_C,
+                                 int n_poses, const double *P, int ldp, int n, int n_poses_max, double sigma_img,
+                                 int k, const double *const *m_obs, const int *m_L, const double *const *m_q,
+                                 const double *const *m_p, const int *m_nposes, const double *const *m_P,
+                                 const int *m_n, double ci_msckf_w, int *self_inlier, double *self_gamma,
+                                 int *has_ci, double *ci_gamma, double *H, int ldh, double *res, double *S, int lds,
+                                 double *P_j, int ldpj) {
+  if (!h || !obs || !C_q_G || !G_p_C || !P || !self_inlier || !self_gamma || !has_ci || k < 0) return XK_EINVAL;
+  if (k > XK_CI_MAXK) return fail(h, XK_ECAPACITY, "more than 7 matched agents");
+  if (n != h->n || ldp < n || L < 2 || L > n_poses || n_poses > h->N || n_poses_max != h->N) return XK_EINVAL;
+  if (k > 0 && (!m_obs || !m_L || !m_q || !m_p || !m_nposes || !m_P || !m_n || !H || !res || !S || !P_j || !ci_gamma ||
+                ldh < 3 * k || lds < 3 * k || ldpj < n))
+    return XK_EINVAL;
+  if (k > 0 && check_w(ci_msckf_w) != XK_OK)
+    return fail(h, XK_EINVAL, "The CI weights must be lower than 1.0 and larger 0.0");
+  int Ltot = L, nmax = n;
+  for (int i = 0; i < k; ++i) {
+    if (m_L[i] < 2 || m_L[i] > m_nposes[i] || m_nposes[i] > 64 || m_n[i] < XK_CORE + 6 * m_nposes[i]) return XK_EINVAL;
+    Ltot += m_L[i];
+    nmax = std::max(nmax, m_n[i]);
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  *has_ci = 0;
+  const int m = 3 * k, k1 = k + 1;
+  // workspace (lazily sized): concatenated lists, per-agent window/obs/P, up rows, H blocks, S buffers
+  const size_t upsz = 3 * (size_t)nmax + 16;
+  const size_t need = 9 * (size_t)Ltot + 7 * 64 + 2 * 64 + (size_t)nmax * nmax + k1 * upsz + (size_t)std::max(m, 1) * k1 * nmax +
+                      4 * 24 * 24 + 1024;
+  double *ws = nullptr;
+  HIPCHK(h, hipMalloc((void **)&ws, sizeof(double) * need));
+  struct Guard { double *p; ~Guard() { if (p) hipFree(p); } } guard{ws};
+  double *dq = ws, *dp = dq + 4 * (size_t)Ltot, *dobs = dp + 3 * (size_t)Ltot;
+  double *aq = dobs + 2 * (size_t)Ltot, *ap = aq + 4 * 64, *aobs = ap + 3 * 64;   // one agent's window + track
+  double *aP = aobs + 2 * 64, *up = aP + (size_t)nmax * nmax, *Hs = up + k1 * upsz;
+  double *S1 = Hs + (size_t)std::max(m, 1) * k1 * nmax, *S2 = S1 + 24 * 24, *dres = S2 + 24 * 24, *dgpf = dres + 24;
+  double *dscal = dgpf + 8;  // [0] ci gamma, [1] w_result
+  int *dint = (int *)(dscal + 8);  // [0] gn iters, [1] inlier, [2] tile rows, [3..] block columns
+  // concatenated lists: matched agents first, self last (:113-149)
+  size_t at = 0;
+  for (int i = 0; i < k; ++i) {
+    HIPCHK(h, hipMemcpyAsync(dq + 4 * at, m_q[i] + 4 * (size_t)(m_nposes[i] - m_L[i]), sizeof(double) * 4 * m_L[i], hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dp + 3 * at, m_p[i] + 3 * (size_t)(m_nposes[i] - m_L[i]), sizeof(double) * 3 * m_L[i], hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dobs + 2 * at, m_obs[i], sizeof(double) * 2 * m_L[i], hipMemcpyHostToDevice, h->stream));
+    at += m_L[i];
+  }
+  HIPCHK(h, hipMemcpyAsync(dq + 4 * at, C_q_G + 4 * (size_t)(n_poses - L), sizeof(double) * 4 * L, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dp + 3 * at, G_p_C + 3 * (size_t)(n_poses - L), sizeof(double) * 3 * L, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dobs + 2 * at, obs, sizeof(double) * 2 * L, hipMemcpyHostToDevice, h->stream));
+  XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint};
+  hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, h->stream, ta);
+  // per-agent column-space rows (self first = row block 0, then the matched agents, :168-204)
+  const int offs[2] = {0, 0};
+  (void)offs;
+  for (int i = 0; i < k1; ++i) {
+    const bool self = (i == 0);
+    const double *hq = self ? C_q_G : m_q[i - 1], *hp = self ? G_p_C : m_p[i - 1], *hobs = self ? obs : m_obs[i - 1];
+    const double *hP = self ? P : m_P[i - 1];
+    const int np_i = self ? n_poses : m_nposes[i - 1], L_i = self ? L : m_L[i - 1], n_i = self ? n : m_n[i - 1];
+    const int ld_i = self ? ldp : n_i, npm_i = self ? n_poses_max : m_nposes[i - 1];
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // scratch reuse across agents
+    HIPCHK(h, hipMemcpyAsync(aq, hq, sizeof(double) * 4 * np_i, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(ap, hp, sizeof(double) * 3 * np_i, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(aobs, hobs, sizeof(double) * 2 * L_i, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(aP, sizeof(double) * n_i, hP, sizeof(double) * ld_i, sizeof(double) * n_i, n_i, hipMemcpyHostToDevice, h->stream));
+    const int toff[2] = {0, L_i};
+    HIPCHK(h, hipMemcpyAsync(dint + 8, toff, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
+    XkFeatArgs a;
+    a.q = aq; a.p = ap; a.n_poses = np_i; a.n_poses_max = npm_i; a.trk_off = dint + 8; a.obs = aobs; a.K = 1;
+    a.P = aP; a.n = n_i; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
+    a.A = nullptr; a.DB = 0; a.C1P = 0; a.na = n_i - XK_CORE;
+    a.tile_rows = dint + 2; a.inlier = dint + 1; a.gamma = dscal + 2; a.gpf = dgpf + 4; a.gn_iters = dint + 3;
+    a.gpf_in = dgpf; a.up_out = up + i * upsz;
+    hipLaunchKernelGGL(xk_msckf_feature, dim3(1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(np_i), h->stream, a);
+    if (self) {
+      int inl = 0;
+      double g = 0;
+      HIPCHK(h, hipMemcpyAsync(&inl, dint + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipMemcpyAsync(&g, dscal + 2, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      *self_inlier = inl;
+      *self_gamma = g;
+      if (!inl || k == 0) return XK_OK;  // proceed_with_multi_ false (:180)
+    }
+  }
+  // null-space projection of the landmark and split into per-agent Jacobians (:207-223)
+  XkCiProjArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.k1 = k1;
+  pa.res = dres;
+  for (int i = 0; i < k1; ++i) {
+    pa.up[i] = up + i * upsz;
+    pa.n[i] = (i == 0) ? n : m_n[i - 1];
+    pa.H[i] = Hs + (size_t)m * nmax * i;
+  }
+  hipLaunchKernelGGL(xk_ci_project, dim3(1), dim3(256), 0, h->stream, pa);
+  // S_gate = sum H_i P_i H_i^T + sigma^2 I (:217-237) and the CI-weighted S (ci.cpp:78-85 + :255)
+  const double w0 = 1.0 - (double)k * ci_msckf_w, var_img = sigma_img * sigma_img;
+  for (int i = 0; i < k1; ++i) {
+    const double *hP = (i == 0) ? P : m_P[i - 1];
+    const int n_i = (i == 0) ? n : m_n[i - 1], ld_i = (i == 0) ? ldp : n_i;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy2DAsync(aP, sizeof(double) * n_i, hP, sizeof(double) * ld_i, sizeof(double) * n_i, n_i, hipMemcpyHostToDevice, h->stream));
+    XkGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = pa.H[i]; g.sar = 1; g.sac = m; g.B = aP; g.sbr = 1; g.sbc = n_i;
+    g.C = h->d_Maug; g.scr = n_i; g.scc = 1; g.D = g.C; g.sdr = n_i; g.sdc = 1;
+    g.M = m; g.N = n_i; g.K = n_i; g.alpha = 1.0; g.beta = 0.0;
+    gemm(h, g);  // W = H_i P_i
+    for (int pass = 0; pass < 2; ++pass) {
+      memset(&g, 0, sizeof(g));
+      g.A = h->d_Maug; g.sar = n_i; g.sac = 1; g.B = pa.H[i]; g.sbr = m; g.sbc = 1;
+      g.C = pass ? S2 : S1; g.scr = 1; g.scc = m; g.D = g.C; g.sdr = 1; g.sdc = m;
+      g.M = m; g.N = m; g.K = n_i;
+      g.alpha = pass ? (i == 0 ? 1.0 / w0 : 1.0 / ci_msckf_w) : 1.0;
+      g.beta = (i == 0) ? 0.0 : 1.0;
+      g.mode = (i == k) ? 1 : 0;            // noise once, on the last term
+      g.diag = nullptr; g.diag_scalar = var_img;
+      gemm(h, g);
+    }
+  }
+  hipLaunchKernelGGL(xk_small_gamma, dim3(1), dim3(1), 0, h->stream, S1, dres, m, dscal);
+  double g_ci = 0;
+  HIPCHK(h, hipMemcpyAsync(&g_ci, dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *ci_gamma = g_ci;
+  const int dof = 2 * Ltot - 3;
+  if (dof >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
+  if (!(g_ci < XK_CHI2_095[dof])) return XK_OK;   // :243-250
+  // P_j: diagonal 3x3 blocks of the L observed poses scaled by w_result = 1/w0 (:256-267)
+  std::vector<int> cols(2 * L);
+  for (int i = 0; i < L; ++i) {
+    const int pos = n_poses - L + i;
+    cols[2 * i] = XK_CORE + 3 * pos;
+    cols[2 * i + 1] = XK_CORE + 3 * pos + 3 * n_poses_max;
+  }
+  const double wres = 1.0 / w0;
+  int *dcols = dint + 16;
+  HIPCHK(h, hipMemcpyAsync(dcols, cols.data(), sizeof(int) * 2 * L, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dscal + 1, &wres, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, P, sizeof(double) * ldp, sizeof(double) * n, n, hipMemcpyHostToDevice, h->stream));
+  XkScaleArgs sc{h->d_tmpP, h->d_Pout, n, 2 * L, dcols, dscal + 1};
+  hipLaunchKernelGGL(xk_scale_blocks, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, sc);
+  HIPCHK(h, hipMemcpy2DAsync(H, sizeof(double) * ldh, pa.H[0], sizeof(double) * m, sizeof(double) * m, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(res, dres, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(S, sizeof(double) * lds, S2, sizeof(double) * m, sizeof(double) * m, m, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(P_j, sizeof(double) * ldpj, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *has_ci = 1;
   return XK_OK;
 }
 

@@ -128,3 +128,175 @@ __global__ void xk_scale_blocks(XkScaleArgs a) {
   }
   a.Pj[idx] = v;
 }
+
+// ----------------------------------------------------------------------------
+// MSCKF-MSCKF CI block (msckf_update.cpp:96-279).
+// ----------------------------------------------------------------------------
+// Triangulation of ONE landmark from the concatenated observations of several agents
+// (matched agents first, self last, msckf_update.cpp:113-149,160-165).  One wave.
+struct XkTriMultiArgs {
+  const double *q, *p, *obs;  // [Ltot][4], [Ltot][3], [Ltot][2]
+  int Ltot;
+  double *gpf;                // [3]
+  int *iters;
+};
+
+__global__ __launch_bounds__(64) void xk_triangulate_multi(XkTriMultiArgs a) {
+  const int lane = threadIdx.x, L = a.Ltot;
+  double Ra[9], R1[9];
+  xk_quat_to_rot(a.q + 4 * (size_t)(L - 1), Ra);
+  xk_quat_to_rot(a.q, R1);
+  const double *pa = a.p + 3 * (size_t)(L - 1), *p1 = a.p;
+  double alpha, beta, rho;
+  {
+    double A4[4][4], X[4], P1[3][4], P2[3][4];
+    for (int r = 0; r < 3; ++r) {
+      double t1 = 0, t2 = 0;
+      for (int c = 0; c < 3; ++c) {
+        P1[r][c] = R1[3 * c + r];
+        P2[r][c] = Ra[3 * c + r];
+        t1 -= R1[3 * c + r] * p1[c];
+        t2 -= Ra[3 * c + r] * pa[c];
+      }
+      P1[r][3] = t1;
+      P2[r][3] = t2;
+    }
+    const double o1x = a.obs[0], o1y = a.obs[1], o2x = a.obs[2 * (size_t)(L - 1)], o2y = a.obs[2 * (size_t)(L - 1) + 1];
+    for (int c = 0; c < 4; ++c) {
+      A4[0][c] = o1x * P1[2][c] - P1[0][c];
+      A4[1][c] = o1y * P1[2][c] - P1[1][c];
+      A4[2][c] = o2x * P2[2][c] - P2[0][c];
+      A4[3][c] = o2y * P2[2][c] - P2[1][c];
+    }
+    xk_null4(A4, X);
+    const double wx = X[0] / X[3], wy = X[1] / X[3], wz = X[2] / X[3];
+    double pc[3];
+    for (int r = 0; r < 3; ++r) pc[r] = P2[r][0] * wx + P2[r][1] * wy + P2[r][2] * wz + P2[r][3];
+    alpha = pc[0] / pc[2];
+    beta = pc[1] / pc[2];
+    rho = 1.0 / pc[2];
+  }
+  double r_norm_last = 1000.0, r_norm = 100.0;
+  int iter = 0;
+  bool ok = true;
+  while (r_norm_last - r_norm > 1e-5) {
+    iter++;
+    if (iter > 10) break;
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = lane; i < L; i += 64) {
+      double Ri[9], drot[3][3], dpos[3];
+      xk_quat_to_rot(a.q + 4 * (size_t)i, Ri);
+      const double *pi = a.p + 3 * (size_t)i;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) drot[r][c] = Ri[r] * Ra[c] + Ri[3 + r] * Ra[3 + c] + Ri[6 + r] * Ra[6 + c];
+        dpos[r] = (Ri[r] * pa[0] + Ri[3 + r] * pa[1] + Ri[6 + r] * pa[2]) - (Ri[r] * pi[0] + Ri[3 + r] * pi[1] + Ri[6 + r] * pi[2]);
+      }
+      xk_gn_accum(drot, dpos, a.obs[2 * (size_t)i], a.obs[2 * (size_t)i + 1], alpha, beta, rho, acc);
+    }
+    for (int c = 0; c < 10; ++c) acc[c] = xk_wave_sum(acc[c]);
+    double dl[3];
+    if (!xk_solve3(acc, acc + 6, dl)) { ok = false; break; }
+    alpha -= dl[0];
+    beta -= dl[1];
+    rho -= dl[2];
+    r_norm_last = r_norm;
+    r_norm = sqrt(acc[9]);
+  }
+  if (lane == 0) {
+    for (int r = 0; r < 3; ++r)
+      a.gpf[r] = ok ? (1.0 / rho) * (Ra[3 * r] * alpha + Ra[3 * r + 1] * beta + Ra[3 * r + 2]) + pa[r] : nan("");
+    *a.iters = iter;
+  }
+}
+
+// Null-space projection of the stacked column-space rows (nullSpaceProjection, msckf_update.cpp:494-501)
+// and the split into per-agent Jacobians (:211-223).  up[i] = [3*n_i | 9 | 3] from xk_msckf_feature.
+#define XK_CI_MAXK 7
+struct XkCiProjArgs {
+  int k1;                               // agents incl. self (k + 1)
+  const double *up[XK_CI_MAXK + 1];
+  int n[XK_CI_MAXK + 1];
+  double *H[XK_CI_MAXK + 1];            // out: (3k) x n_i column-major, ld = 3k
+  double *res;                          // out: 3k
+};
+
+__global__ __launch_bounds__(256) void xk_ci_project(XkCiProjArgs a) {
+  __shared__ double Q[24][24];   // full Q of the 3(k+1) x 3 stack
+  __shared__ double rp[24];
+  const int mr = 3 * a.k1, m = mr - 3, tid = threadIdx.x;
+  if (tid == 0) {
+    double jf[24][3], tau[3];
+    for (int i = 0; i < a.k1; ++i) {
+      const double *uh = a.up[i] + 3 * (size_t)a.n[i];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) jf[3 * i + r][c] = uh[r + 3 * c];
+        rp[3 * i + r] = uh[9 + r];
+      }
+    }
+    for (int kk = 0; kk < 3; ++kk) {   // Householder QR (Eigen convention)
+      double tail = 0;
+      for (int r = kk + 1; r < mr; ++r) tail += jf[r][kk] * jf[r][kk];
+      const double c0 = jf[kk][kk];
+      double bet, sc;
+      if (tail <= 2.2250738585072014e-308) { tau[kk] = 0; bet = c0; sc = 0; }
+      else { bet = sqrt(c0 * c0 + tail); if (c0 >= 0) bet = -bet; tau[kk] = (bet - c0) / bet; sc = 1.0 / (c0 - bet); }
+      for (int r = kk + 1; r < mr; ++r) jf[r][kk] *= sc;
+      jf[kk][kk] = bet;
+      for (int c2 = kk + 1; c2 < 3; ++c2) {
+        double w = jf[kk][c2];
+        for (int r = kk + 1; r < mr; ++r) w += jf[r][kk] * jf[r][c2];
+        w *= tau[kk];
+        jf[kk][c2] -= w;
+        for (int r = kk + 1; r < mr; ++r) jf[r][c2] -= w * jf[r][kk];
+      }
+    }
+    for (int i = 0; i < mr; ++i)
+      for (int j = 0; j < mr; ++j) Q[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int kk = 2; kk >= 0; --kk) {  // Q = H0 H1 H2 applied to I
+      if (tau[kk] == 0.0) continue;
+      for (int j = kk; j < mr; ++j) {
+        double w = Q[kk][j];
+        for (int r = kk + 1; r < mr; ++r) w += jf[r][kk] * Q[r][j];
+        w *= tau[kk];
+        Q[kk][j] -= w;
+        for (int r = kk + 1; r < mr; ++r) Q[r][j] -= w * jf[r][kk];
+      }
+    }
+    for (int c = 0; c < m; ++c) {      // res = A^T res_pf, A = Q[:, 3:]
+      double s = 0;
+      for (int r = 0; r < mr; ++r) s += Q[r][3 + c] * rp[r];
+      a.res[c] = s;
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < a.k1; ++i) {     // H_i = A[3i:3i+3, :]^T * up_jac_i
+    const double *uj = a.up[i];
+    for (int col = tid; col < a.n[i]; col += 256) {
+      const double u0 = uj[3 * (size_t)col], u1 = uj[3 * (size_t)col + 1], u2 = uj[3 * (size_t)col + 2];
+      for (int c = 0; c < m; ++c)
+        a.H[i][c + (size_t)m * col] = Q[3 * i][3 + c] * u0 + Q[3 * i + 1][3 + c] * u1 + Q[3 * i + 2][3 + c] * u2;
+    }
+  }
+}
+
+// gamma = res^T S^-1 res for a small SPD S (m <= 24), by Cholesky in one thread (msckf_update.cpp:243-244).
+__global__ void xk_small_gamma(const double *S /*m x m col-major*/, const double *res, int m, double *gamma) {
+  if (threadIdx.x || blockIdx.x) return;
+  double L[24][24], y[24];
+  bool bad = false;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = S[i + (size_t)m * j];
+      for (int t = 0; t < j; ++t) s -= L[i][t] * L[j][t];
+      if (i == j) { if (!(s > 0)) bad = true; L[i][i] = sqrt(s); }
+      else L[i][j] = s / L[j][j];
+    }
+  double g = 0;
+  for (int i = 0; i < m; ++i) {
+    double s = res[i];
+    for (int t = 0; t < i; ++t) s -= L[i][t] * y[t];
+    y[i] = s / L[i][i];
+    g += y[i] * y[i];
+  }
+  *gamma = bad ? INFINITY : g;
+}

@@ -40,6 +40,10 @@ struct XkFeatArgs {
   double *gamma;
   double *gpf;       // [K][3] triangulated landmark, world frame
   int *gn_iters;     // [K]
+  // multi-agent MSCKF (msckf_update.cpp:201-203,439-443): use a landmark triangulated elsewhere and
+  // also emit the 3 column-space rows  A_up^T [jac | Hf | res]  (up_out: [3*n | 9 | 3] doubles, col-major)
+  const double *gpf_in;
+  double *up_out;
 };
 
 __device__ __forceinline__ void xk_quat_to_rot(const double *q, double *r /*row-major 3x3*/) {
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   double *res = Ja + 6 * Lmax;   // [2L]
   double *V = res + 2 * Lmax;    // [3][2L] Hf, then the three reflectors
   double *Mm = V + 6 * Lmax;     // [(2L+1)][ldm] gate matrix (+ appended residual row)
-  double *scal = Mm + (size_t)(2 * Lmax + 1) * ldm;  // 32 scalars
+  double *scal = Mm + (size_t)(2 * Lmax + 1) * ldm;  // 32 scalars (16..24: R factor of Hf)
   // scal: 0..2 tau, 3 g01, 4 g02, 5 g12, 6..8 gpf, 9 valid, 10 bad, 11 inlier, 12 gamma
 
   const int off = a.trk_off[k], L = a.trk_off[k + 1] - off, m2 = 2 * L, d = m2 - 3, p0 = np - L;
@@ -204,7 +208,10 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   __syncthreads();
 
   // ---- triangulation: DLT + Gauss-Newton, wave 0 (triangulation.cpp:102-206)
-  if (tid < 64) {
+  if (a.gpf_in) {
+    if (tid < 3) scal[6 + tid] = a.gpf_in[tid];
+    if (tid == 0) a.gn_iters[k] = 0;
+  } else if (tid < 64) {
     const int lane = tid;
     const double *Ra = rot + 9 * (p0 + L - 1), *pa = pos + 3 * (p0 + L - 1);
     const double *R1 = rot + 9 * p0, *p1 = pos + 3 * p0;
@@ -384,6 +391,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
       }
       for (int r = lane; r < m2; r += 64)
         if (r > kk) col[r] *= sc;
+      if (lane == 0) scal[16 + 4 * kk] = bet;  // R(kk,kk) of Hf = (A_up^T Hf)(kk,kk)
       for (int c2 = kk + 1; c2 < 3; ++c2) {
         double *cc = V + c2 * m2;
         double w = 0.0;
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
         w = tau * (xk_wave_sum(w) + cc[kk]);
         for (int r = lane; r < m2; r += 64)
           if (r > kk) cc[r] -= w * col[r];
-        if (lane == 0) cc[kk] -= w;
+        if (lane == 0) { cc[kk] -= w; scal[16 + kk + 3 * c2] = cc[kk]; }  // R(kk,c2), column-major 3x3 at scal[16..24]
       }
       if (lane == 0) scal[kk] = tau;
     }
@@ -545,7 +553,42 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   }
 #undef XK_S
   __syncthreads();
-  if (scal[11] == 0.0) return;
+  if (a.up_out) {
+    // rows 0..2 of Q^T [J | Hf | res]   (msckf_update.cpp:439-443)
+    double *uj = a.up_out, *uh = a.up_out + 3 * (size_t)a.n, *ur = uh + 9;
+    const int N3u = 3 * a.n_poses_max;
+    for (int sc_ = tid; sc_ < a.n; sc_ += XK_FEAT_THREADS) {
+      double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+      const int c = sc_ - XK_CORE;
+      int i = -1, comp = 0;
+      const double *blk = nullptr;
+      if (c >= 0 && c < N3u) { i = c / 3 - p0; comp = c % 3; blk = Jp; }
+      else if (c >= N3u && c < 2 * N3u) { i = (c - N3u) / 3 - p0; comp = (c - N3u) % 3; blk = Ja; }
+      if (blk && i >= 0 && i < L) {
+        const double x0 = blk[6 * i + comp], x1 = blk[6 * i + 3 + comp];
+        const int r0 = 2 * i;
+        const double a0 = V[r0] * x0 + V[r0 + 1] * x1;
+        const double a1 = V[m2 + r0] * x0 + V[m2 + r0 + 1] * x1;
+        const double a2 = V[2 * m2 + r0] * x0 + V[2 * m2 + r0 + 1] * x1;
+        const double w0 = tau0 * a0, w1 = tau1 * (a1 - w0 * g01), w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
+        double o[3];
+        for (int r = 0; r < 3; ++r) {
+          double v = -w0 * V[r] - w1 * V[m2 + r] - w2 * V[2 * m2 + r];
+          if (r == r0) v += x0;
+          if (r == r0 + 1) v += x1;
+          o[r] = v;
+        }
+        o0 = o[0]; o1 = o[1]; o2 = o[2];
+      }
+      uj[3 * (size_t)sc_] = o0; uj[3 * (size_t)sc_ + 1] = o1; uj[3 * (size_t)sc_ + 2] = o2;
+    }
+    if (tid < 9) {
+      const int r = tid % 3, c = tid / 3;
+      uh[tid] = (r <= c) ? scal[16 + r + 3 * c] : 0.0;
+    }
+    if (tid < 3) ur[tid] = res[tid];
+  }
+  if (scal[11] == 0.0 || !a.A) return;
 
   // ---- tile write: rows 3.. of Q^T [J | res] over the active columns (:431-432,468-479)
   double *tile = a.A + (size_t)k * a.DB * a.C1P;

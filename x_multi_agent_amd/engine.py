@@ -25,7 +25,7 @@ SYMBOLS = [
     "xk_create", "xk_destroy", "xk_strerror", "xk_last_error", "xk_version", "xk_stream",
     "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
-    "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match",
+    "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
 ]
 
@@ -292,6 +292,35 @@ class Engine:
         out = dict(inlier=bool(inl.value), gamma=gam.value, H=np.ascontiguousarray(H), res=res)
         if out["inlier"]:
             out.update(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj))
+        return out
+
+    def msckf_ci_track(self, trk, C_q_G, G_p_C, P, n_poses_max, sigma_img, matches, ci_msckf_w):
+        k = len(matches)
+        n = P.shape[0]
+        base = [_d(trk), _d(C_q_G), _d(G_p_C), _f(P)]
+        mo = [_d(m["obs"]) for m in matches]
+        mq = [_d(m["q_list"]) for m in matches]
+        mp = [_d(m["p_list"]) for m in matches]
+        mP = [_f(m["P"]) for m in matches]
+        arr = lambda xs: (c_dp * max(k, 1))(*[x[1] for x in xs])
+        mL, mLp = _i([len(m["obs"]) for m in matches] or [0])
+        mnp, mnpp = _i([len(m["p_list"]) for m in matches] or [0])
+        mn, mnp_ = _i([m["P"].shape[0] for m in matches] or [0])
+        si, sg, hc, cg = C.c_int(), C.c_double(), C.c_int(), C.c_double()
+        m3 = max(3 * k, 1)
+        H = np.zeros((m3, n), order="F")
+        res = np.zeros(m3)
+        S = np.zeros((m3, m3), order="F")
+        Pj = np.zeros((n, n), order="F")
+        self._chk(self.L.xk_msckf_ci_track(
+            self.h, base[0][1], C.c_int(len(trk)), base[1][1], base[2][1], C.c_int(len(G_p_C)), base[3][1],
+            C.c_int(n), C.c_int(n), C.c_int(n_poses_max), C.c_double(sigma_img), C.c_int(k), arr(mo), mLp, arr(mq),
+            arr(mp), mnpp, arr(mP), mnp_, C.c_double(ci_msckf_w), C.byref(si), C.byref(sg), C.byref(hc), C.byref(cg),
+            H.ctypes.data_as(c_dp), C.c_int(m3), res.ctypes.data_as(c_dp), S.ctypes.data_as(c_dp), C.c_int(m3),
+            Pj.ctypes.data_as(c_dp), C.c_int(n)), "xk_msckf_ci_track")
+        out = dict(self_inlier=bool(si.value), self_gamma=sg.value, ci=None, ci_gamma=cg.value)
+        if hc.value:
+            out["ci"] = dict(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj), H=np.ascontiguousarray(H), res=res)
         return out
 
     # ---- measurement -------------------------------------------------
