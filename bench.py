@@ -31,6 +31,8 @@ sys.path.insert(0, HERE)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
 CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
+CI_TRACKS = 2             # shared MSCKF tracks fused per CI round
+CI_MSCKF_W = 0.05         # fixed CI weight per other agent (w0 = 1 - k*w > 0 for k <= 7)
 
 
 def alg_flops(N, K, M, rows=None):
@@ -106,30 +108,57 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); no CPU fallback exists")
-    torch.cuda.set_device(local_rank)
+    # XK_BENCH_BACKEND=gloo XK_BENCH_DEVICE=0 lets several ranks share one GPU with CPU exchange buffers
+    # (functional check of the N>1 path on a single-GPU box); the default is one GPU per rank over RCCL.
+    backend = os.environ.get("XK_BENCH_BACKEND", "nccl")
+    dev = int(os.environ.get("XK_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
+    xdev = f"cuda:{dev}" if backend == "nccl" else "cpu"
 
     N, K, M = synth.CONFIGS[args.config]
-    sc = synth.make_config(args.config, agent_id=rank)
-    eng = engine.Engine(N, M, K, device=local_rank)
+    sc = fleet.shared_scenario(synth, args.config, rank)
+    eng = engine.Engine(N, M, K, device=dev)
     eng.stage(sc)
     sigma = sc["sigma_img"]
 
     # CI payload exchange (torch owns the buffers so RCCL sends/receives them in place)
     pay_n = eng.payload_doubles()
-    ex = fleet.Exchange(dist, world, rank, pay_n, f"cuda:{local_rank}")
+    ex = fleet.Exchange(dist, world, rank, pay_n, xdev)
+    pay_dev = torch.zeros(pay_n, dtype=torch.float64, device=f"cuda:{dev}")
     dyn16 = np.zeros(16)
     dyn16[9] = 1.0
 
+    # observations of the shared tracks travel next to the SimpleState payload
+    tex = fleet.Exchange(dist, world, rank, CI_TRACKS * (1 + 2 * N), xdev)
+    tex.send.copy_(torch.from_numpy(fleet.pack_tracks(sc, CI_TRACKS, N).ravel()))
+    ci_stats = {"rounds": 0, "fused": 0}
+
     def exchange(step):
+        """CI round: all-gather the snapshots over RCCL, then fuse the shared tracks against them."""
         if world == 1:
             return
-        eng.pack_payload_into(rank, float(step), dyn16, ex.send.data_ptr())
-        ex.all_gather()
+        eng.pack_payload_into(rank, float(step), dyn16, pay_dev.data_ptr())   # packed on the device ...
+        ex.send.copy_(pay_dev)                                                # ... into the RCCL send buffer
+        allp = ex.all_gather().cpu().numpy()
+        allt = tex.all_gather().cpu().numpy()
+        others = []
+        for r in range(world):
+            if r == rank:
+                continue
+            u = fleet.unpack_payload(allp[r], N, M)
+            u["tracks"] = fleet.unpack_tracks(allt[r], N)
+            others.append(u)
+        fused, _ = fleet.ci_round(eng, sc, others, CI_TRACKS, CI_MSCKF_W)
+        ci_stats["rounds"] += 1
+        ci_stats["fused"] += fused
 
     def sync():
         torch.cuda.synchronize()
@@ -152,7 +181,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -197,7 +226,8 @@ def main():
                                       f"K={K} MSCKF tracks (L=N), M={M} SLAM features, n={15 + 6 * N + 3 * M}; "
                                       f"CI payload all-gather every {CI_EVERY} updates",
                           "n_poses_max": N, "k_msckf": K, "m_slam": M, "agents": world,
-                          "ci_every": CI_EVERY, "payload_bytes": 8 * pay_n},
+                          "ci_every": CI_EVERY, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
+                          "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"]},
                "roofline": roof, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
         print(json.dumps(out), flush=True)

@@ -177,3 +177,44 @@ def test_msckf_ci_track_golden_and_oracle(xk, oracle_c):
                 assert rel(Pg, z[f"mc{j}_Ppost"]) <= 1e-8 and rel(cg, z[f"mc{j}_corr"]) <= 1e-7
     assert n_ci >= 2
     eng.close()
+
+
+def test_fleet_ci_round_two_agents_one_gpu(xk, oracle_c):
+    """The CI round bench.py runs after the RCCL all-gather, with both agents on one GPU:
+    device payload -> host unpack -> xk_msckf_ci_track + xk_apply_ci, checked against the oracle."""
+    import torch
+    from x_multi_agent_amd import fleet
+    N, K, M = 10, 16, 0
+    scs = []
+    for rank in range(2):
+        if rank == 0:
+            scs.append(synth.make_scenario(N, K, M, seed=4242))
+        else:
+            scs.append(synth.make_scenario(N, K, M, seed=4243, agent_offset=0.03, landmarks=scs[0]["landmarks_true"]))
+    engs = [xk.Engine(N, M, K) for _ in range(2)]
+    pays, trks = [], []
+    for rank in range(2):
+        engs[rank].stage(scs[rank])
+        send = torch.zeros(engs[rank].payload_doubles(), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        engs[rank].pack_payload_into(rank, 0.0, np.zeros(16), send.data_ptr())
+        pays.append(send.cpu().numpy())
+        trks.append(fleet.pack_tracks(scs[rank], 6, N))
+    other = fleet.unpack_payload(pays[1], N, M)
+    other["tracks"] = fleet.unpack_tracks(trks[1], N)
+    fused, last = fleet.ci_round(engs[0], scs[0], [other], 6, 0.2)
+    # oracle: same loop
+    ofused, olast = 0, None
+    tr0, tr1 = synth.tracks_as_list(scs[0]), synth.tracks_as_list(scs[1])
+    for j in range(6):
+        o = oracle_c.msckf_ci_track(tr0[j], scs[0]["C_q_G"], scs[0]["G_p_C"], scs[0]["P"], N, scs[0]["sigma_img"],
+                                    [dict(obs=tr1[j], q_list=scs[1]["C_q_G"], p_list=scs[1]["G_p_C"], P=scs[1]["P"],
+                                          n_poses_max=N)], 0.2)
+        if o["ci"] is not None:
+            c = o["ci"]
+            olast, _ = oracle_c.apply_ci(c["P_j"], c["H"], c["res"], c["S"])
+            ofused += 1
+    assert fused == ofused and fused >= 1
+    assert rel(last, olast) <= 1e-8
+    for e in engs:
+        e.close()

@@ -114,3 +114,51 @@ def ring_requests(world, tick):
     if world < 2:
         return []
     return [(a, (a + 1 + tick % (world - 1)) % world) for a in range(world)]
+
+
+def shared_scenario(synth, config, rank, **kw):
+    """Agent `rank`'s synthetic problem for the multi-agent configs: every agent observes agent 0's
+    landmark set (ground-truth association, mirroring the reference's GT_DEBUG build) from its own
+    arc of the circle, with its own noise, window error and prior."""
+    N, K, M = synth.CONFIGS[config]
+    if rank == 0:
+        return synth.make_config(config, agent_id=0, **kw)
+    lm = synth.make_config(config, agent_id=0, **kw)["landmarks_true"]
+    return synth.make_scenario(N, K, M, seed=synth.seed_for(config, rank), agent_offset=0.02 * rank, landmarks=lm, **kw)
+
+
+def pack_tracks(sc, n_tracks, N):
+    """Observations of the first n_tracks tracks, padded to N poses each: [n_tracks, 1 + 2N] (length first)."""
+    out = np.zeros((n_tracks, 1 + 2 * N))
+    off = sc["trk_off"]
+    for j in range(n_tracks):
+        o = sc["obs_xy"][off[j]:off[j + 1]]
+        out[j, 0] = len(o)
+        out[j, 1:1 + 2 * len(o)] = o.ravel()
+    return out
+
+
+def unpack_tracks(buf, N):
+    buf = np.asarray(buf).reshape(-1, 1 + 2 * N)
+    return [row[1:1 + 2 * int(row[0])].reshape(int(row[0]), 2).copy() for row in buf]
+
+
+def ci_round(eng, sc, others, n_tracks, ci_msckf_w):
+    """One MSCKF-MSCKF CI round of an agent against the snapshots it received
+    (MsckfUpdate::preProcessOneTrack CI block + Updater::applyCI per list entry,
+    msckf_update.cpp:96-279, updater.cpp:90-93).  `others`: list of
+    dict(C_q_G, G_p_C, P, tracks=[obs per shared track]).  Returns (n_fused, last posterior or None):
+    every P_j is built from the same prior and applyCI overwrites P each time."""
+    N = sc["n_poses_max"]
+    off = sc["trk_off"]
+    fused, last = 0, None
+    for j in range(n_tracks):
+        trk = sc["obs_xy"][off[j]:off[j + 1]]
+        matches = [dict(obs=o["tracks"][j], q_list=o["C_q_G"], p_list=o["G_p_C"], P=o["P"], n_poses_max=N)
+                   for o in others]
+        r = eng.msckf_ci_track(trk, sc["C_q_G"], sc["G_p_C"], sc["P"], N, sc["sigma_img"], matches, ci_msckf_w)
+        if r["ci"] is not None:
+            c = r["ci"]
+            last, _corr = eng.apply_ci(c["P_j"], c["H"], c["res"], c["S"])
+            fused += 1
+    return fused, last
