@@ -191,7 +191,8 @@ def main():
         f_feat, f_qr, f_upd = alg_flops(N, K, M)
         f_alg = f_feat + f_qr + f_upd
         st = tm["stages"]
-        qr_ms = st["xk_tsqr_leaf"]["ms"] + st["xk_tsqr_merge"]["ms"]
+        qr_keys = [k for k in st if k.startswith("xk_tsqr") or k.startswith("xk_caqr")]
+        qr_ms = sum(st[k]["ms"] for k in qr_keys)
         dom = max(st.items(), key=lambda kv: kv[1]["ms"])
         traffic = None
         pmc = os.path.join(HERE, "profiles", "r01_pmc_traffic.json")
@@ -203,9 +204,9 @@ def main():
         ach = f_qr / (qr_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
-                "kernel": "xk_tsqr_leaf+xk_tsqr_merge (Householder TSQR of the stacked [H|res])",
+                "kernel": "+".join(qr_keys) + " (Householder QR compression of the stacked [H|res])",
                 "alg_flops_per_update": f_qr, "stage_ms": qr_ms,
-                "launches_per_update": st["xk_tsqr_leaf"]["launches"] + st["xk_tsqr_merge"]["launches"],
+                "launches_per_update": sum(st[k]["launches"] for k in qr_keys),
                 "dominant_kernel_by_time": dom[0], "dominant_kernel_ms": dom[1]["ms"],
                 "dominant_kernel_launches": dom[1]["launches"],
                 "whole_update": {"alg_flops": f_alg, "ms": tm["total_ms"],

@@ -32,7 +32,8 @@ struct xk_handle {
   double *d_P, *d_Pout;
   double *d_chi95, *d_chi90;
   double *d_A;
-  int *d_tile_rows;
+  int *d_tile_rows, *d_tile_list, *d_ntl;
+  bool caqr;            // compression path: CAQR (C1 <= 192, tiles <= 64 rows) or the binary TSQR tree
   int *d_inl, *d_inl_s, *d_gn;
   double *d_gam, *d_gam_s, *d_gpf;
   double *d_R;
@@ -109,6 +110,8 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   const int dmax = 2 * n_poses_max - 3;
   h->NBT = dmax <= 20 ? 20 : dmax <= 40 ? 40 : dmax <= 60 ? 60 : dmax <= 100 ? 100 : 60;
   h->DB = round_up(dmax, 4);
+  h->caqr = (dmax <= 64 && h->C1 <= 192 && !getenv("XK_FORCE_TSQR"));
+  if (h->caqr) h->DB = 64;   // CAQR works on 64-row tiles in place
   const int slam_tiles = (2 * n_feat_max + h->DB - 1) / h->DB;
   h->ntiles_max = k_max + slam_tiles;
   h->nleaf_max = 256;
@@ -135,6 +138,8 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
   HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
+  HIPCHK(h, dalloc(&h->d_tile_list, (size_t)h->ntiles_max + 8));
+  HIPCHK(h, dalloc(&h->d_ntl, (size_t)4));
   HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_inl_s, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_gn, (size_t)k_max));
@@ -170,7 +175,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->d_q, h->d_p, h->d_obs, h->d_trk_off, h->d_feat, h->d_zlast, h->d_anchor, h->d_tsz,
-                  h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_inl, h->d_inl_s,
+                  h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_tile_list, h->d_ntl, h->d_inl, h->d_inl_s,
                   h->d_gn, h->d_gam, h->d_gam_s, h->d_gpf, h->d_R, h->d_Maug, h->d_X, h->d_Linv, h->d_corr,
                   h->d_ct, h->d_tmpH, h->d_tmpS, h->d_tmpP, h->d_rdiag, h->d_tmpz, h->d_status, h->d_payload,
                   h->d_ci};
@@ -346,8 +351,44 @@ static int pick_nleaf(xk_handle *h, int ntiles) {
   return nl;
 }
 
+// CAQR: panels of 16 columns; per panel one in-place tile factorisation on every tile, then 8-way
+// strip merges (<= 3 levels for <= 512 tiles); the root strip of each panel is 16 rows of R.
+static int launch_caqr(xk_handle *h, hipEvent_t mid) {
+  const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
+  const int ntiles = h->K + slam_tiles;
+  if (ntiles > 1024) return fail(h, XK_ECAPACITY, "CAQR path supports at most 1024 tiles");
+  hipMemsetAsync(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P, h->stream);
+  hipLaunchKernelGGL(xk_compact_tiles, dim3(1), dim3(1024), 0, h->stream, h->d_tile_rows, ntiles, h->d_tile_list, h->d_ntl);
+  XkCaqrArgs a;
+  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.tile_list = h->d_tile_list; a.ntl = h->d_ntl;
+  a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R;
+  int launches = 0;
+  for (int c0 = 0; c0 < h->C1; c0 += 16) {
+    a.c0 = c0; a.stride = 1; a.final_level = 0;
+    const int threads = round_up(4 * (h->C1 - c0), 64);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<16, false>), dim3(ntiles), dim3(threads), 0, h->stream, a);
+    if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
+    int stride = 1;
+    do {
+      a.stride = stride;
+      a.final_level = (8 * stride >= ntiles) ? 1 : 0;
+      const int grid = (ntiles + 8 * stride - 1) / (8 * stride);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<32, true>), dim3(grid), dim3(threads), 0, h->stream, a);
+      ++launches;
+      stride *= 8;
+    } while (stride < ntiles);
+  }
+  h->nleaf = ntiles;
+  h->nlevels = launches;
+  h->have_R = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
+  return XK_OK;
+}
+
 static int launch_tsqr(xk_handle *h, hipEvent_t mid = nullptr) {
   if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
+  if (h->caqr) return launch_caqr(h, mid);
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   XkQrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = h->K + slam_tiles;
@@ -683,7 +724,8 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
   if (!h || !out || steps <= 0 || warmup < 0) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   memset(out, 0, sizeof(*out));
-  const char *names[XK_NSTAGE] = {"xk_msckf_feature", "xk_slam_rows", "xk_tsqr_leaf", "xk_tsqr_merge",
+  const char *names[XK_NSTAGE] = {"xk_msckf_feature", "xk_slam_rows", h->caqr ? "xk_caqr_panel0" : "xk_tsqr_leaf",
+                                  h->caqr ? "xk_caqr_rest" : "xk_tsqr_merge",
                                   "xk_kalman_update", "(unused)"};
   for (int s = 0; s < XK_NSTAGE; ++s) snprintf(out->stage_name[s], sizeof(out->stage_name[s]), "%s", names[s]);
   double acc[XK_NSTAGE] = {0, 0, 0, 0, 0, 0}, tot = 0;

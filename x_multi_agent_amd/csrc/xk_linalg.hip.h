@@ -446,3 +446,170 @@ __global__ void xk_copy2d(XkCopyArgs a) {
   const int r = (int)(idx % a.rows), c = (int)(idx / a.rows);
   a.dst[(long)r * a.dsr + (long)c * a.dsc] = a.src[(long)r * a.ssr + (long)c * a.ssc];
 }
+
+// ----------------------------------------------------------------------------
+// Communication-avoiding QR (CAQR) of the tile stack: the compression path for systems with
+// C1 <= 192 columns and tiles of at most 64 rows.
+//
+// The binary TSQR tree above serialises 7 merges of ~350 Householder steps each on ONE
+// workgroup.  CAQR walks the columns in panels of 16 instead; per panel
+//   (1) every tile factors its own 64 x 16 panel IN PLACE (pivot rows = its rows 0..15) and
+//       applies the 16 reflectors to its trailing columns           -- grid = #tiles
+//   (2) the 16-row strips [R_loc | C_loc] (rows 0..15 of each tile) are merged 8 at a time by
+//       the same in-place QR on the stacked 128 x 16 triangles      -- 3 levels for <= 512 tiles
+//   (3) the root strip is the next 16 rows of the global R; it is moved out and zeroed.
+// The dependent chain is 12 panels x 4 launches of 16 steps, and step (1) runs on every CU.
+//
+// Lane layout as in xk_qr_pass: 4 lanes per column, lane `part` holds RPL consecutive rows of the
+// block in registers (RPL = 16: one tile; RPL = 32: eight strips).  The pivot row of step kk is
+// register kk of the part-0 lane; the 16 steps are fully unrolled so that index is static.  The
+// broadcast vector u has u[<kk] = 0, u[kk] = 1, so the update code is identical for every lane.
+// ----------------------------------------------------------------------------
+struct XkCaqrArgs {
+  double *A;              // tiles [ntiles][64][C1P] row-major (in place)
+  const int *tile_rows;   // valid rows per tile before panel 0
+  const int *tile_list;   // compacted list of tiles that hold data
+  const int *ntl;         // device: number of entries in tile_list
+  int C1P, C1, c0;        // panel = columns [c0, min(c0+16, C1))
+  int stride;             // strip mode: group g merges list positions g*8*stride + u*stride
+  int final_level;        // strip mode: root strip -> Rout, then zeroed
+  double *Rout;           // [C1P][C1P] row-major
+};
+
+template <int KK, int RPL>
+__device__ __forceinline__ double xk_caqr_pivot(const double (&b)[RPL]) { return b[KK]; }
+
+template <int RPL, bool STRIP>
+__global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
+  constexpr int RPLP = RPL + 2;
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * 4 * RPLP];
+  __shared__ double sc[4];
+  const int col = a.c0 + (int)threadIdx.x / 4, part = threadIdx.x & 3;
+  const int ntl = *a.ntl;
+  const bool mine = col < a.C1;
+  // ---- which rows does this lane hold?
+  double *rowp[RPL / 16];   // base pointer of each 16-row group (nullptr = absent -> zeros)
+  int nvalid[RPL / 16];     // valid rows within the group
+  if (!STRIP) {
+    if ((int)blockIdx.x >= ntl) return;
+    const int t = a.tile_list[blockIdx.x];
+    const int rows = (a.c0 == 0) ? a.tile_rows[t] : 64;
+    rowp[0] = a.A + ((size_t)t * 64 + part * 16) * a.C1P;
+    nvalid[0] = rows - part * 16;
+  } else {
+    const int base = blockIdx.x * 8 * a.stride;
+    if (base >= ntl) return;
+#pragma unroll
+    for (int g = 0; g < RPL / 16; ++g) {
+      const int pos = base + (part * (RPL / 16) + g) * a.stride;
+      rowp[g] = (pos < ntl) ? a.A + (size_t)a.tile_list[pos] * 64 * a.C1P : nullptr;
+      nvalid[g] = 16;
+    }
+  }
+  double b[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int g = r / 16, rr = r % 16;
+    b[r] = (mine && rowp[g] && rr < nvalid[g]) ? rowp[g][(size_t)rr * a.C1P + col] : 0.0;
+  }
+  const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    if (kk < nsteps) {   // uniform
+      const int pb = kk & 1;
+      xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
+      if (col == a.c0 + kk) {
+        // tail^2 over the rows below the pivot row kk (part 0: registers kk+1..; other parts: all)
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const bool below = (part != 0) || (r > kk);
+          const double x = below ? b[r] : 0.0;
+          if (r & 1) s1 = fma(x, x, s1); else s0 = fma(x, x, s0);
+        }
+        const double tail = xk_group_sum<4>(s0 + s1);
+        const double c0v = xk_dpp_quad<0x00>(b[kk]);   // quad_perm [0,0,0,0]: pivot from the part-0 lane
+        double tau, scale, beta;
+        if (tail <= 2.2250738585072014e-308) { tau = 0.0; scale = 0.0; beta = c0v; }
+        else {
+          beta = xk_sqrt(fma(c0v, c0v, tail));
+          if (c0v >= 0) beta = -beta;
+          tau = (beta - c0v) * xk_rcp(beta);
+          scale = xk_rcp(c0v - beta);
+        }
+        // u = [0.. (rows < kk), 1 (row kk), scale * x (rows below)]; own column <- [.., beta, 0..]
+#pragma unroll
+        for (int r = 0; r < RPL; r += 2) {
+          double u0, u1;
+          if (part == 0) {
+            u0 = (r < kk) ? 0.0 : (r == kk ? 1.0 : b[r] * scale);
+            u1 = (r + 1 < kk) ? 0.0 : (r + 1 == kk ? 1.0 : b[r + 1] * scale);
+          } else { u0 = b[r] * scale; u1 = b[r + 1] * scale; }
+          xk_d2 t = {u0, u1};
+          useg[r >> 1] = t;
+        }
+        if (part == 0) { sc[pb * 2] = tau; }
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const bool below = (part != 0) || (r > kk);
+          if (below) b[r] = 0.0;
+        }
+        if (part == 0) b[kk] = beta;
+      }
+      __syncthreads();
+      const double tau = sc[pb * 2];
+      xk_d2 u[RPL / 2];
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+      if (col > a.c0 + kk && mine && tau != 0.0) {
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL / 2; ++r) {
+          if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+          else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+        }
+        const double w = -tau * xk_group_sum<4>((d0 + d1) + (d2 + d3));
+#pragma unroll
+        for (int r = 0; r < RPL / 2; ++r) {
+          b[2 * r] = fma(w, u[r][0], b[2 * r]);
+          b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+        }
+      }
+    }
+  }
+  // ---- write back in place; the root strip of the last level becomes rows c0.. of R
+  if (!mine) return;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int g = r / 16, rr = r % 16;
+    if (!rowp[g]) continue;
+    double v = b[r];
+    if (STRIP && a.final_level && part == 0 && g == 0) {
+      if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + col] = v;
+      v = 0.0;
+    }
+    rowp[g][(size_t)rr * a.C1P + col] = v;
+  }
+}
+
+// Deterministic compaction of the tiles that hold data (inlier tracks / SLAM tiles).
+__global__ __launch_bounds__(1024) void xk_compact_tiles(const int *tile_rows, int ntiles, int *tile_list, int *ntl) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x;
+  // each thread scans a contiguous chunk so the order is the tile order
+  const int per = (ntiles + 1023) / 1024, lo = t * per, hi = min(ntiles, lo + per);
+  int c = 0;
+  for (int i = lo; i < hi; ++i) c += tile_rows[i] > 0;
+  cnt[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? cnt[t - o] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  int at = cnt[t] - c;
+  for (int i = lo; i < hi; ++i)
+    if (tile_rows[i] > 0) tile_list[at++] = i;
+  if (t == 1023) *ntl = cnt[1023];
+}
