@@ -361,7 +361,7 @@ static int launch_caqr(xk_handle *h, hipEvent_t mid) {
   hipLaunchKernelGGL(xk_compact_tiles, dim3(1), dim3(1024), 0, h->stream, h->d_tile_rows, ntiles, h->d_tile_list, h->d_ntl);
   XkCaqrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.tile_list = h->d_tile_list; a.ntl = h->d_ntl;
-  a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R;
+  a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
   int launches = 0;
   for (int c0 = 0; c0 < h->C1; c0 += 16) {
     a.c0 = c0; a.stride = 1; a.final_level = 0;

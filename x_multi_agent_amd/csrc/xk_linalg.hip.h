@@ -474,6 +474,7 @@ struct XkCaqrArgs {
   int stride;             // strip mode: group g merges list positions g*8*stride + u*stride
   int final_level;        // strip mode: root strip -> Rout, then zeroed
   double *Rout;           // [C1P][C1P] row-major
+  long long *dbg;         // optional: s_memtime stamps of workgroup 0 (probe builds only)
 };
 
 template <int KK, int RPL>
@@ -507,11 +508,19 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
     }
   }
   double b[RPL];
+#ifdef XK_CAQR_PROBE
+  long long t0 = clock64();
+#endif
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
     const int g = r / 16, rr = r % 16;
     b[r] = (mine && rowp[g] && rr < nvalid[g]) ? rowp[g][(size_t)rr * a.C1P + col] : 0.0;
   }
+#ifdef XK_CAQR_PROBE
+  double sink = 0; for (int r = 0; r < RPL; ++r) sink += b[r];
+  asm volatile("" :: "v"(sink));
+  long long t1 = clock64();
+#endif
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
@@ -577,6 +586,10 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
       }
     }
   }
+#ifdef XK_CAQR_PROBE
+  long long t2 = clock64();
+  if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[3] = nsteps; }
+#endif
   // ---- write back in place; the root strip of the last level becomes rows c0.. of R
   if (!mine) return;
 #pragma unroll

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxk.so")
+LIB_PATH = os.environ.get("XK_LIB_PATH", os.path.join(_HERE, "libxk.so"))  # override: experiments only
 _LIB = None
 
 c_dp = C.POINTER(C.c_double)
