@@ -267,6 +267,8 @@ extern "C" int xk_download_P(xk_handle *h, double *P, int ldp, int n) {
 // ---------------------------------------------------------------------------
 // launch helpers (all asynchronous on h->stream)
 // ---------------------------------------------------------------------------
+static long long *g_feat_dbg = nullptr;  // probe builds only
+
 static int launch_build(xk_handle *h, double sigma_img) {
   if (h->n_poses < 2) return fail(h, XK_EINVAL, "window not staged");
   if (h->K > 0 && h->h_pin_i[0] > h->n_poses) return fail(h, XK_EINVAL, "track longer than the staged window");
@@ -278,7 +280,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
-    a.gpf_in = nullptr; a.up_out = nullptr;
+    a.gpf_in = nullptr; a.up_out = nullptr; a.dbg = g_feat_dbg;
     const size_t lds = xk_feature_lds_bytes(h->n_poses);
     hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
   }
@@ -992,7 +994,7 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
     a.P = aP; a.n = n_i; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = nullptr; a.DB = 0; a.C1P = 0; a.na = n_i - XK_CORE;
     a.tile_rows = dint + 2; a.inlier = dint + 1; a.gamma = dscal + 2; a.gpf = dgpf + 4; a.gn_iters = dint + 3;
-    a.gpf_in = dgpf; a.up_out = up + i * upsz;
+    a.gpf_in = dgpf; a.up_out = up + i * upsz; a.dbg = nullptr;
     hipLaunchKernelGGL(xk_msckf_feature, dim3(1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(np_i), h->stream, a);
     if (self) {
       int inl = 0;
@@ -1179,3 +1181,16 @@ extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
   *tflops = flops / (ms * 1e-3) / 1e12;
   return XK_OK;
 }
+
+#ifdef XK_FEAT_PROBE
+extern "C" int xk_debug_feature_phases(xk_handle *h, double sigma_img, long long *out8) {
+  hipMalloc((void **)&g_feat_dbg, 64);
+  hipMemset(g_feat_dbg, 0, 64);
+  int rc = launch_build(h, sigma_img);
+  hipStreamSynchronize(h->stream);
+  hipMemcpy(out8, g_feat_dbg, 64, hipMemcpyDeviceToHost);
+  hipFree(g_feat_dbg);
+  g_feat_dbg = nullptr;
+  return rc;
+}
+#endif

@@ -20,7 +20,13 @@
 #include <hip/hip_runtime.h>
 
 #define XK_CORE 15
+typedef double xk_f2 __attribute__((ext_vector_type(2)));
 #define XK_FEAT_THREADS 256
+#ifdef XK_FEAT_PROBE
+#define XK_STAMP(i) do { __syncthreads(); if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
+#else
+#define XK_STAMP(i)
+#endif
 
 struct XkFeatArgs {
   const double *q;   // [n_poses][4] xyzw
@@ -44,6 +50,7 @@ struct XkFeatArgs {
   // also emit the 3 column-space rows  A_up^T [jac | Hf | res]  (up_out: [3*n | 9 | 3] doubles, col-major)
   const double *gpf_in;
   double *up_out;
+  long long *dbg;   // probe builds only: phase stamps of block 0
 };
 
 __device__ __forceinline__ void xk_quat_to_rot(const double *q, double *r /*row-major 3x3*/) {
@@ -59,9 +66,22 @@ __device__ __forceinline__ void xk_quat_to_rot(const double *q, double *r /*row-
   r[6] = txz - twy;       r[7] = tyz + twx;       r[8] = 1 - (txx + tyy);
 }
 
+template <int CTRL>
+__device__ __forceinline__ double xk_dpp_f64(double x) {
+  const long long q = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(q & 0xffffffffLL), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(q >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// All-lanes sum over the wave: four DPP stages inside each 16-lane row (quad xor 1, quad xor 2,
+// half-row mirror, row mirror), then two cross-row shuffles.  Every lane gets the same value.
 __device__ __forceinline__ double xk_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += xk_dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += xk_dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += xk_dpp_f64<0x141>(v);   // row_half_mirror
+  v += xk_dpp_f64<0x140>(v);   // row_mirror
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -175,10 +195,42 @@ __device__ __forceinline__ void xk_gn_accum(const double (&dr)[3][3], const doub
   acc[9] += rx * rx + ry * ry;
 }
 
+// Cholesky-based gate on S = M[3:,3:] (d x d, lower triangle) with the residual stored as row d:
+// right-looking and un-normalised, S(i,j) -= S(i,k) S(j,k) / S(k,k) for i >= j > k, which touches
+// only columns > k -- column k and the pivot stay valid through the step, so ONE barrier per step
+// suffices; gamma = sum_k S(d,k)^2 / S(k,k).  Threads form a fixed 16 x 16 grid; each owns an
+// the elements (i,j) = (ti, tj) mod 16 (no index divisions in the loop).
+template <int NT>
+__device__ __forceinline__ void xk_chol_gate(double *Mm, int ldm, int d, int tid, double *scal) {
+#define XK_S(i, j) Mm[(size_t)(3 + (i)) * ldm + 3 + (j)]
+  const int ti = tid >> 4, tj = tid & 15;
+  double g = 0.0;
+  bool bad = false;
+  for (int kk = 0; kk < d; ++kk) {
+    const double piv = XK_S(kk, kk);
+    if (!(piv > 0.0)) { bad = true; break; }   // uniform: every thread reads the same pivot
+    double rp = __builtin_amdgcn_rcp(piv);
+    rp = fma(rp, fma(-piv, rp, 1.0), rp);
+    rp = fma(rp, fma(-piv, rp, 1.0), rp);
+    if (tid == 0) { const double y = XK_S(d, kk); g = fma(y * y, rp, g); }
+    for (int i = kk + 1 + ((ti - (kk + 1)) & 15); i <= d; i += 16) {
+      const double sik = XK_S(i, kk) * rp;
+      for (int j = kk + 1 + ((tj - (kk + 1)) & 15); j <= i && j < d; j += 16)
+        XK_S(i, j) = fma(-sik, XK_S(j, kk), XK_S(i, j));
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (bad) scal[10] = 1.0;
+    scal[12] = g;
+  }
+#undef XK_S
+}
+
 // LDS size in bytes for n_poses window poses.
 static inline size_t xk_feature_lds_bytes(int n_poses) {
   const int L = n_poses, m2 = 2 * L, ldm = m2 + 1;
-  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32);
+  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64);
 }
 
 __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a) {
@@ -207,6 +259,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   if (tid == 0) { scal[9] = 1.0; scal[10] = 0.0; }
   __syncthreads();
 
+  XK_STAMP(0);
   // ---- triangulation: DLT + Gauss-Newton, wave 0 (triangulation.cpp:102-206)
   if (a.gpf_in) {
     if (tid < 3) scal[6 + tid] = a.gpf_in[tid];
@@ -313,6 +366,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   const double gx = scal[6], gy = scal[7], gz = scal[8];
   if (tid < 3) a.gpf[3 * (size_t)k + tid] = scal[6 + tid];
 
+  XK_STAMP(1);
   // ---- per-observation Jacobians (msckf_update.cpp:328-417)
   for (int i = tid; i < L; i += XK_FEAT_THREADS) {
     const double *R = rot + 9 * (p0 + i), *pp = pos + 3 * (p0 + i);
@@ -371,6 +425,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   }
   __syncthreads();
 
+  XK_STAMP(2);
   // ---- Householder QR of Hf (2L x 3) -> three reflectors (:423)
   if (tid < 64) {
     const int lane = tid;
@@ -431,6 +486,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   const double tau0 = scal[0], tau1 = scal[1], tau2 = scal[2];
   const double g01 = scal[3], g02 = scal[4], g12 = scal[5];
 
+  XK_STAMP(3);
   // ---- gate matrix M = J P J^T + sigma^2 I from 6x6 blocks of P (:452-457)
   {
     const int n = a.n;
@@ -487,71 +543,112 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   }
   __syncthreads();
 
-  // ---- M <- Q^T M Q, three reflectors from the left, then from the right
-  for (int kk = 0; kk < 3; ++kk) {
-    const double tk = scal[kk];
-    const double *v = V + kk * m2;
-    if (tid < m2) {
-      double w = 0.0;
-      for (int i = kk; i < m2; ++i) w += v[i] * Mm[(size_t)i * ldm + tid];
-      w *= tk;
-      for (int i = kk; i < m2; ++i) Mm[(size_t)i * ldm + tid] -= w * v[i];
+  XK_STAMP(4);
+  // ---- M <- Q^T M Q with Q = H0 H1 H2 = I - V T V^T (compact WY):
+  //        Q^T M Q = M - V Z^T - Z V^T,   Z = Y T - V B / 2,  Y = M V,  B = T^T (V^T Y) T
+  // one matvec sweep + one rank-6 sweep over the lower triangle instead of six reflector sweeps.
+  // Y and Z (3 x 2L each) and the Cholesky broadcast column live behind the scalar block.
+  double *Yv = scal + 32;          // [3][m2]
+  double *Zv = Yv + 3 * 2 * Lmax;  // [3][m2]
+  {
+    // Y = M V : 4 lanes per row, each sweeps a quarter of the columns
+    const int row = tid >> 2, qd = tid & 3;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    if (row < m2) {
+      const double *mr = Mm + (size_t)row * ldm;
+      for (int j = qd; j < m2; j += 4) {
+        const double mv = mr[j];
+        y0 = fma(mv, V[j], y0);
+        y1 = fma(mv, V[m2 + j], y1);
+        y2 = fma(mv, V[2 * m2 + j], y2);
+      }
     }
-    __syncthreads();
-  }
-  for (int kk = 0; kk < 3; ++kk) {
-    const double tk = scal[kk];
-    const double *v = V + kk * m2;
-    if (tid < m2) {
-      double *row = Mm + (size_t)tid * ldm;
-      double w = 0.0;
-      for (int j = kk; j < m2; ++j) w += row[j] * v[j];
-      w *= tk;
-      for (int j = kk; j < m2; ++j) row[j] -= w * v[j];
+    y0 += __shfl_xor(y0, 1, 64); y0 += __shfl_xor(y0, 2, 64);
+    y1 += __shfl_xor(y1, 1, 64); y1 += __shfl_xor(y1, 2, 64);
+    y2 += __shfl_xor(y2, 1, 64); y2 += __shfl_xor(y2, 2, 64);
+    if (row < m2 && qd == 0) { Yv[row] = y0; Yv[m2 + row] = y1; Yv[2 * m2 + row] = y2; }
+    // rows 64.. (tracks longer than 32): second sweep
+    for (int row2 = row + 64; row2 < m2; row2 += 64) {
+      const double *mr = Mm + (size_t)row2 * ldm;
+      double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+      for (int j = qd; j < m2; j += 4) {
+        const double mv = mr[j];
+        z0 = fma(mv, V[j], z0);
+        z1 = fma(mv, V[m2 + j], z1);
+        z2 = fma(mv, V[2 * m2 + j], z2);
+      }
+      z0 += __shfl_xor(z0, 1, 64); z0 += __shfl_xor(z0, 2, 64);
+      z1 += __shfl_xor(z1, 1, 64); z1 += __shfl_xor(z1, 2, 64);
+      z2 += __shfl_xor(z2, 1, 64); z2 += __shfl_xor(z2, 2, 64);
+      if (qd == 0) { Yv[row2] = z0; Yv[m2 + row2] = z1; Yv[2 * m2 + row2] = z2; }
     }
-    __syncthreads();
-  }
-  // appended row: y = L^-1 r0 falls out of the factorisation
-  for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)m2 * ldm + 3 + j] = res[3 + j];
-  __syncthreads();
-
-  // ---- Cholesky of S = M[3:,3:] (d x d) with the residual as row d (:457-458)
-#define XK_S(i, j) Mm[(size_t)(3 + (i)) * ldm + 3 + (j)]
-  for (int kk = 0; kk < d; ++kk) {
-    const double piv = XK_S(kk, kk);
-    if (!(piv > 0.0)) {
-      if (tid == 0) scal[10] = 1.0;
-      break;  // uniform: every thread reads the same pivot
-    }
-    const double inv = 1.0 / sqrt(piv);
-    __syncthreads();
-    for (int i = kk + 1 + tid; i <= d; i += XK_FEAT_THREADS) XK_S(i, kk) *= inv;
-    __syncthreads();
-    const int cnt = d - kk;  // rows kk+1..d
-    for (int idx = tid; idx < cnt * cnt; idx += XK_FEAT_THREADS) {
-      const int ii = idx / cnt, jj = idx - ii * cnt;
-      if (jj > ii || jj >= cnt - 1) continue;
-      XK_S(kk + 1 + ii, kk + 1 + jj) -= XK_S(kk + 1 + ii, kk) * XK_S(kk + 1 + jj, kk);
-    }
-    __syncthreads();
   }
   __syncthreads();
   if (tid < 64) {
-    double g = 0.0;
-    for (int j = tid; j < d; j += 64) g += XK_S(d, j) * XK_S(d, j);
-    g = xk_wave_sum(g);
-    if (tid == 0) {
-      const bool valid = scal[9] != 0.0 && gx == gx;
-      const bool bad = scal[10] != 0.0;
-      const double gam = (valid && !bad) ? g : (valid ? INFINITY : nan(""));
-      const bool inl = valid && !bad && (g < a.chi95[d]);  // :459-463
-      scal[11] = inl ? 1.0 : 0.0;
-      a.gamma[k] = gam;
-      a.inlier[k] = inl ? 1 : 0;
-      a.tile_rows[k] = inl ? d : 0;
+    // W = V^T Y (3x3), T, B = T^T W T, then Z = Y T - V B / 2
+    double wacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = tid; r < m2; r += 64)
+#pragma unroll
+      for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) wacc[3 * x + y] = fma(V[x * m2 + r], Yv[y * m2 + r], wacc[3 * x + y]);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) wacc[c] = xk_wave_sum(wacc[c]);
+    const double T00 = tau0, T11 = tau1, T22 = tau2;
+    const double T01 = -tau1 * T00 * g01;
+    const double T02 = -tau2 * (T00 * g02 + T01 * g12);
+    const double T12 = -tau2 * (T11 * g12);
+    const double Tm[3][3] = {{T00, T01, T02}, {0.0, T11, T12}, {0.0, 0.0, T22}};
+    double WT[3][3], Bm[3][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int y = 0; y < 3; ++y) WT[x][y] = wacc[3 * x] * Tm[0][y] + wacc[3 * x + 1] * Tm[1][y] + wacc[3 * x + 2] * Tm[2][y];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+      for (int y = 0; y < 3; ++y) Bm[x][y] = Tm[0][x] * WT[0][y] + Tm[1][x] * WT[1][y] + Tm[2][x] * WT[2][y];
+    for (int r = tid; r < m2; r += 64) {
+      const double yv0 = Yv[r], yv1 = Yv[m2 + r], yv2 = Yv[2 * m2 + r];
+      const double v0 = V[r], v1 = V[m2 + r], v2 = V[2 * m2 + r];
+#pragma unroll
+      for (int y = 0; y < 3; ++y)
+        Zv[y * m2 + r] = (yv0 * Tm[0][y] + yv1 * Tm[1][y] + yv2 * Tm[2][y]) - 0.5 * (v0 * Bm[0][y] + v1 * Bm[1][y] + v2 * Bm[2][y]);
     }
   }
-#undef XK_S
+  __syncthreads();
+  // rank-6 update of the lower triangle (rows >= 3 are all the Cholesky reads)
+  for (int idx = tid; idx < m2 * m2; idx += XK_FEAT_THREADS) {
+    const int i = idx / m2, j = idx - i * m2;
+    if (j > i || i < 3) continue;
+    Mm[(size_t)i * ldm + j] -= V[i] * Zv[j] + Zv[i] * V[j] + V[m2 + i] * Zv[m2 + j] + Zv[m2 + i] * V[m2 + j] +
+                               V[2 * m2 + i] * Zv[2 * m2 + j] + Zv[2 * m2 + i] * V[2 * m2 + j];
+  }
+  __syncthreads();
+  XK_STAMP(5);
+  // ---- Cholesky of S = M[3:,3:] (d x d) with the residual as an extra row d (:457-458):
+  //      y = L^-1 r0 falls out of the factorisation, gamma = |y|^2
+  // Right-looking, un-normalised: S(i,j) -= S(i,k) S(j,k) / S(k,k) for i >= j > k touches only
+  // columns > k, so column k and the pivot stay valid through the step and ONE barrier per step
+  // suffices; gamma accumulates S(d,k)^2 / S(k,k).  Threads form a fixed 16 x 16 grid over the
+  // matrix (no index arithmetic in the loop).
+  for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)m2 * ldm + 3 + j] = res[3 + j];
+  __syncthreads();
+  if (d < 64) xk_chol_gate<4>(Mm, ldm, d, tid, scal);
+  else xk_chol_gate<8>(Mm, ldm, d, tid, scal);
+  __syncthreads();
+  if (tid == 0) {
+    const double g = scal[12];
+    const bool valid = scal[9] != 0.0 && gx == gx;
+    const bool bad = scal[10] != 0.0;
+    const double gam = (valid && !bad) ? g : (valid ? INFINITY : nan(""));
+    const bool inl = valid && !bad && (g < a.chi95[d]);  // :459-463
+    scal[11] = inl ? 1.0 : 0.0;
+    a.gamma[k] = gam;
+    a.inlier[k] = inl ? 1 : 0;
+    a.tile_rows[k] = inl ? d : 0;
+  }
+  XK_STAMP(6);
   __syncthreads();
   if (a.up_out) {
     // rows 0..2 of Q^T [J | Hf | res]   (msckf_update.cpp:439-443)
@@ -621,6 +718,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
       tile[(size_t)(r - 3) * a.C1P + c] = v;
     }
   }
+  XK_STAMP(7);
 }
 
 // ----------------------------------------------------------------------------
