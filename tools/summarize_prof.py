@@ -53,7 +53,7 @@ if pmc:
     res = {"note": "FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts 64 B per 128-B "
                    "request for wide coalesced reads (MI355X_MICROARCH.md HBM section) -> fetch_bytes_corrected = 2x.",
            "updates_in_run": updates, "kernels": pmc}
-    tsqr = [k for k in pmc if "tsqr" in k]
+    tsqr = [k for k in pmc if "tsqr" in k or "caqr" in k]
     f = sum(pmc[k].get("FETCH_SIZE", {}).get("sum", 0.0) for k in tsqr) * 1024.0
     w = sum(pmc[k].get("WRITE_SIZE", {}).get("sum", 0.0) for k in tsqr) * 1024.0
     res["tsqr_fetch_bytes_per_update_raw"] = f / updates
