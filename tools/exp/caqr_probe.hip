@@ -17,7 +17,7 @@ int main() {
   for (int c0 : {0, 96}) {
     hipMemcpy(A, hA.data(), sizeof(double) * hA.size(), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(xk_compact_tiles, dim3(1), dim3(1024), 0, 0, rows, nt, list, ntl);
-    XkCaqrArgs a{A, rows, list, ntl, C1P, C1, c0, 1, 0, R, dbg};
+    XkCaqrArgs a{A, rows, list, ntl, C1P, C1, c0, 1, 0, R, 1, C1 - c0 - 16, dbg};
     const int threads = (4 * (C1 - c0) + 63) / 64 * 64;
     for (int mode = 0; mode < 4; ++mode) {
       long long d[4];
@@ -35,6 +35,28 @@ int main() {
       hipMemcpy(d, dbg, 32, hipMemcpyDeviceToHost);
       printf("c0=%3d mode=%d grid=%3d threads=%d: %.1f us | WG0: load %lld ticks, %lld steps %lld ticks (%.0f/step)\n", c0, mode, grid,
              threads, 1e3 * ms, d[0], d[3], d[1], (double)d[1] / d[3]);
+    }
+  }
+  // MFMA kernels
+  hipFree(dbg); hipMalloc(&dbg, 128);
+  for (int c0 : {0, 96}) {
+    hipMemcpy(A, hA.data(), sizeof(double) * hA.size(), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(xk_compact_tiles, dim3(1), dim3(1024), 0, 0, rows, nt, list, ntl);
+    XkCaqrArgs a{A, rows, list, ntl, C1P, C1, c0, 1, 0, R, 1, C1 - c0 - 16, dbg};
+    const int threads = 64 * (1 + (C1 - c0 - 16 + 15) / 16);
+    for (int mode = 0; mode < 2; ++mode) {
+      long long d[16]; float ms;
+      int grid = mode == 0 ? nt : 41;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        if (mode == 0) hipLaunchKernelGGL((xk_caqr_mfma<4, false>), dim3(grid), dim3(threads), 0, 0, a);
+        else hipLaunchKernelGGL((xk_caqr_mfma<8, true>), dim3(grid), dim3(threads), 0, 0, a);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+      }
+      hipMemcpy(d, dbg, 128, hipMemcpyDeviceToHost);
+      printf("MFMA c0=%3d mode=%d threads=%d: %.1f us | w0: load %lld, +steps %lld, +T %lld | w1: at-barrier %lld, released %lld, mfma-done %lld\n",
+             c0, mode, threads, 1e3 * ms, d[4], d[5], d[6], d[7], d[8], d[9]);
     }
   }
   printf("%s\n", hipGetErrorString(hipGetLastError()));

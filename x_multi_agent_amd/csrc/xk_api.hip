@@ -367,15 +367,31 @@ static int launch_caqr(xk_handle *h, hipEvent_t mid) {
   int launches = 0;
   for (int c0 = 0; c0 < h->C1; c0 += 16) {
     a.c0 = c0; a.stride = 1; a.final_level = 0;
-    const int threads = round_up(4 * (h->C1 - c0), 64);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<16, false>), dim3(ntiles), dim3(threads), 0, h->stream, a);
+    // default: broadcast-per-step kernels.  XK_CAQR_MFMA=1 selects the matrix-core variant (panel on one
+    // wave + compact-WY trailing update as fp64 MFMAs): parity-identical, but measured 2x SLOWER because the
+    // single-wave panel chain (1.25 k cycles/step) and the T recurrence dominate.
+    static const bool valu = getenv("XK_CAQR_MFMA") == nullptr;
+    // MFMA kernels: wave 0 = panel, one wave per trailing 16-column block
+    // column split of the strip merges: while more than 96 trailing columns are live, two workgroups
+    // share them (the per-tile kernel already runs on every CU and stays unsplit)
+    const int trail = std::max(0, h->C1 - c0 - 16);
+    const int csplit = (valu && trail > 96 && !getenv("XK_CAQR_NOSPLIT")) ? 2 : 1;
+    const int threads_mfma = 64 * (1 + (h->C1 - c0 - 16 + 15) / 16);
+    a.csplit = 1;
+    a.chalf = trail;
+    if (valu) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<16, false>), dim3(ntiles, 1), dim3(round_up(4 * (16 + trail), 64)), 0, h->stream, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_mfma<4, false>), dim3(ntiles), dim3(threads_mfma), 0, h->stream, a);
+    a.csplit = csplit;
+    a.chalf = (csplit == 1) ? trail : round_up((trail + 1) / 2, 16);
+    const int threads = valu ? round_up(4 * (16 + a.chalf), 64) : threads_mfma;
     if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
     int stride = 1;
     do {
       a.stride = stride;
       a.final_level = (8 * stride >= ntiles) ? 1 : 0;
       const int grid = (ntiles + 8 * stride - 1) / (8 * stride);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<32, true>), dim3(grid), dim3(threads), 0, h->stream, a);
+      if (valu) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<32, true>), dim3(grid, csplit), dim3(threads), 0, h->stream, a);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_mfma<8, true>), dim3(grid), dim3(threads), 0, h->stream, a);
       ++launches;
       stride *= 8;
     } while (stride < ntiles);

@@ -474,6 +474,7 @@ struct XkCaqrArgs {
   int stride;             // strip mode: group g merges list positions g*8*stride + u*stride
   int final_level;        // strip mode: root strip -> Rout, then zeroed
   double *Rout;           // [C1P][C1P] row-major
+  int csplit, chalf;      // trailing columns split over gridDim.y workgroups of `chalf` columns each
   long long *dbg;         // optional: s_memtime stamps of workgroup 0 (probe builds only)
 };
 
@@ -484,10 +485,18 @@ template <int RPL, bool STRIP>
 __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
   constexpr int RPLP = RPL + 2;
   __shared__ __attribute__((aligned(16))) double ubuf[2 * 4 * RPLP];
-  __shared__ double sc[4];
-  const int col = a.c0 + (int)threadIdx.x / 4, part = threadIdx.x & 3;
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  // Column map: the 16 panel columns first (every column-split workgroup factors the panel
+  // redundantly -- the step chain is sequential anyway), then this workgroup's share of the
+  // trailing columns.  Splitting halves the LDS broadcast traffic per CU, which is what bounds
+  // a step while more than ~100 columns are live.
+  // (Only the strip merges are split; the per-tile kernel keeps the plain map -- two extra live
+  // values there cost the 80-VGPR step that lets two of its workgroups share a CU.)
+  const int cidx = (int)threadIdx.x / 4, part = threadIdx.x & 3;
+  const int col = (!STRIP || cidx < 16) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
   const int ntl = *a.ntl;
-  const bool mine = col < a.C1;
+  const bool mine = col < a.C1 && (!STRIP || cidx < 16 || cidx - 16 < a.chalf);
+  const bool wr = mine && (!STRIP || cidx >= 16 || blockIdx.y == 0);   // the panel is written by split 0 only
   // ---- which rows does this lane hold?
   double *rowp[RPL / 16];   // base pointer of each 16-row group (nullptr = absent -> zeros)
   int nvalid[RPL / 16];     // valid rows within the group
@@ -522,62 +531,77 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
   long long t1 = clock64();
 #endif
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
+  // Un-normalised reflectors  H = I - tt v v^T,  v = [c0 - beta; x_below],  tt = 1/(|beta|(|beta|+|c0|))
+  //   = y^2 / (1 + |c0| y) with y = 1/|beta| from ONE rsq + Newton.  The owner publishes its raw column
+  // BEFORE the scalar chain (the LDS write latency hides behind rsq/Newton) and only three scalars
+  // after it; the division by t = 1 + |c0| y is done by every consumer, overlapped with its LDS reads.
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) {
     if (kk < nsteps) {   // uniform
       const int pb = kk & 1;
       xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
+      double *scp = sc + pb * 4;
       if (col == a.c0 + kk) {
-        // tail^2 over the rows below the pivot row kk (part 0: registers kk+1..; other parts: all)
+#pragma unroll
+        for (int r = 0; r < RPL; r += 2) {
+          xk_d2 tt = {b[r], b[r + 1]};
+          useg[r >> 1] = tt;
+        }
         double s0 = 0.0, s1 = 0.0;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-          const bool below = (part != 0) || (r > kk);
-          const double x = below ? b[r] : 0.0;
+          const double x = ((part != 0) || (r > kk)) ? b[r] : 0.0;
           if (r & 1) s1 = fma(x, x, s1); else s0 = fma(x, x, s0);
         }
         const double tail = xk_group_sum<4>(s0 + s1);
         const double c0v = xk_dpp_quad<0x00>(b[kk]);   // quad_perm [0,0,0,0]: pivot from the part-0 lane
-        double tau, scale, beta;
-        if (tail <= 2.2250738585072014e-308) { tau = 0.0; scale = 0.0; beta = c0v; }
-        else {
-          beta = xk_sqrt(fma(c0v, c0v, tail));
-          if (c0v >= 0) beta = -beta;
-          tau = (beta - c0v) * xk_rcp(beta);
-          scale = xk_rcp(c0v - beta);
+        double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+        if (tail > 2.2250738585072014e-308) {
+          const double n2 = fma(c0v, c0v, tail);
+          double y = __builtin_amdgcn_rsq(n2);             // ~ 1/|beta|
+          y = y * fma(-0.5 * n2 * y, y, 1.5);
+          y = y * fma(-0.5 * n2 * y, y, 1.5);
+          const double ab = n2 * y;                        // |beta|
+          const double ac = fabs(c0v);
+          beta = (c0v >= 0) ? -ab : ab;
+          vp = c0v - beta;
+          y2 = y * y;
+          tden = fma(ac, y, 1.0);
         }
-        // u = [0.. (rows < kk), 1 (row kk), scale * x (rows below)]; own column <- [.., beta, 0..]
+        if (part == 0) {
+          xk_d2 s01 = {y2, tden};
+          *reinterpret_cast<xk_d2 *>(scp) = s01;
+          scp[2] = vp;
+        }
 #pragma unroll
-        for (int r = 0; r < RPL; r += 2) {
-          double u0, u1;
-          if (part == 0) {
-            u0 = (r < kk) ? 0.0 : (r == kk ? 1.0 : b[r] * scale);
-            u1 = (r + 1 < kk) ? 0.0 : (r + 1 == kk ? 1.0 : b[r + 1] * scale);
-          } else { u0 = b[r] * scale; u1 = b[r + 1] * scale; }
-          xk_d2 t = {u0, u1};
-          useg[r >> 1] = t;
-        }
-        if (part == 0) { sc[pb * 2] = tau; }
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          const bool below = (part != 0) || (r > kk);
-          if (below) b[r] = 0.0;
-        }
+        for (int r = 0; r < RPL; ++r)
+          if ((part != 0) || (r > kk)) b[r] = 0.0;
         if (part == 0) b[kk] = beta;
       }
       __syncthreads();
-      const double tau = sc[pb * 2];
+      const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
+      const double vp = scp[2];
       xk_d2 u[RPL / 2];
 #pragma unroll
       for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-      if (col > a.c0 + kk && mine && tau != 0.0) {
+      if (col > a.c0 + kk && mine && s01[0] != 0.0) {
+        double rt = __builtin_amdgcn_rcp(s01[1]);
+        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+        if (part == 0) {   // rows above the pivot are not part of the reflector; the pivot entry is vp
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            if (r < kk) u[r >> 1][r & 1] = 0.0;
+            else if (r == kk) u[r >> 1][r & 1] = vp;
+          }
+        }
         double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
         for (int r = 0; r < RPL / 2; ++r) {
           if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
           else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
         }
-        const double w = -tau * xk_group_sum<4>((d0 + d1) + (d2 + d3));
+        const double w = -(s01[0] * rt) * xk_group_sum<4>((d0 + d1) + (d2 + d3));
 #pragma unroll
         for (int r = 0; r < RPL / 2; ++r) {
           b[2 * r] = fma(w, u[r][0], b[2 * r]);
@@ -591,7 +615,7 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
   if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[3] = nsteps; }
 #endif
   // ---- write back in place; the root strip of the last level becomes rows c0.. of R
-  if (!mine) return;
+  if (!wr) return;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
     const int g = r / 16, rr = r % 16;
@@ -602,6 +626,240 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
       v = 0.0;
     }
     rowp[g][(size_t)rr * a.C1P + col] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// CAQR panel step on the matrix cores.
+//
+// Same in-place block QR as xk_caqr_panel (block = one 64-row tile, NT = 4, or eight 16-row strips,
+// NT = 8), but only the 16 panel columns go through the step-by-step reflector broadcast: wave 0
+// factors the (16*NT) x 16 panel on its own (wave-local LDS exchange, no workgroup barrier), forms
+// the compact-WY factor T (T^-1 = striu(V^T V) + diag(1/tau), V^T V by MFMA) and publishes V, T.
+// Every other wave owns ONE 16-column block of the trailing matrix, resident in the fp64 MFMA C/D
+// layout (lane l, register r <-> row 16m + (l>>4) + 4r, column l&15), and applies
+//      W = V^T A        (4*NT MFMAs)     A fragment (m, r) IS the B operand of K-slice (m, r)
+//      Y = T^T W        (4 MFMAs)        W registers are the B operands of the next product
+//      A -= V Y         (4*NT MFMAs)     Y registers likewise
+// so no fragment ever moves between lanes.
+// ----------------------------------------------------------------------------
+template <int NT, bool STRIP>
+__global__ __launch_bounds__(768) void xk_caqr_mfma(XkCaqrArgs a) {
+  constexpr int ROWS = 16 * NT, RPL = 4 * NT, RPLP = RPL + 2, LDV = 17;
+  __shared__ __attribute__((aligned(16))) double Vs[ROWS * LDV];   // explicit V (unit diagonal, zeros above)
+  __shared__ __attribute__((aligned(16))) double Ts[16 * LDV];     // T (upper triangular)
+  __shared__ __attribute__((aligned(16))) double Gs[16 * LDV];     // V^T V
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * 4 * RPLP];
+  __shared__ double taus[16];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ntl = *a.ntl;
+  // ---- row sources: 16-row groups of the block
+  double *grp[NT];
+  int gvalid[NT];
+  if (!STRIP) {
+    if ((int)blockIdx.x >= ntl) return;
+    const int t = a.tile_list[blockIdx.x];
+    const int rows = (a.c0 == 0) ? a.tile_rows[t] : 64;
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      grp[m] = a.A + ((size_t)t * 64 + 16 * m) * a.C1P;
+      gvalid[m] = rows - 16 * m;
+    }
+  } else {
+    const int base = blockIdx.x * 8 * a.stride;
+    if (base >= ntl) return;
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+      const int pos = base + m * a.stride;
+      grp[m] = (pos < ntl) ? a.A + (size_t)a.tile_list[pos] * 64 * a.C1P : nullptr;
+      gvalid[m] = 16;
+    }
+  }
+  const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
+  const bool root_out = STRIP && a.final_level;
+
+#ifdef XK_CAQR_PROBE
+  long long q0 = clock64();
+#define XK_QSTAMP(i) do { if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[i] = clock64() - q0; } while (0)
+#else
+#define XK_QSTAMP(i)
+#endif
+  if (wave == 0) {
+    // ================= panel factorisation: 4 lanes per column, RPL rows per lane =================
+    const int pj = lane >> 2, part = lane & 3, col = a.c0 + pj;
+    const bool mine = pj < nsteps;
+    double b[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const int row = part * RPL + r, m = row >> 4, rr = row & 15;
+      b[r] = (mine && grp[m] && rr < gvalid[m]) ? grp[m][(size_t)rr * a.C1P + col] : 0.0;
+    }
+    XK_QSTAMP(4);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int pb = kk & 1;
+      xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
+      double tau = 0.0;
+      if (kk < nsteps) {
+        if (pj == kk) {
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) {
+            const double x = ((part != 0) || (r > kk)) ? b[r] : 0.0;
+            if (r & 1) s1 = fma(x, x, s1); else s0 = fma(x, x, s0);
+          }
+          const double tail = xk_group_sum<4>(s0 + s1);
+          const double c0v = xk_dpp_quad<0x00>(b[kk]);
+          double scale, beta;
+          if (tail <= 2.2250738585072014e-308) { tau = 0.0; scale = 0.0; beta = c0v; }
+          else {
+            beta = xk_sqrt(fma(c0v, c0v, tail));
+            if (c0v >= 0) beta = -beta;
+            tau = (beta - c0v) * xk_rcp(beta);
+            scale = xk_rcp(c0v - beta);
+          }
+#pragma unroll
+          for (int r = 0; r < RPL; r += 2) {
+            double u0 = b[r] * scale, u1 = b[r + 1] * scale;
+            if (part == 0) {
+              u0 = (r < kk) ? 0.0 : (r == kk ? 1.0 : u0);
+              u1 = (r + 1 < kk) ? 0.0 : (r + 1 == kk ? 1.0 : u1);
+            }
+            xk_d2 tt = {u0, u1};
+            useg[r >> 1] = tt;
+            Vs[(part * RPL + r) * LDV + kk] = u0;      // explicit V for the MFMA phase
+            Vs[(part * RPL + r + 1) * LDV + kk] = u1;
+          }
+          if (part == 0) taus[kk] = tau;
+#pragma unroll
+          for (int r = 0; r < RPL; ++r)
+            if ((part != 0) || (r > kk)) b[r] = 0.0;
+          if (part == 0) b[kk] = beta;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // wave-local exchange: no workgroup barrier needed
+        __builtin_amdgcn_wave_barrier();
+        const double tk = taus[kk];
+        xk_d2 u[RPL / 2];
+#pragma unroll
+        for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+        if (pj > kk && mine && tk != 0.0) {
+          double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+          for (int r = 0; r < RPL / 2; ++r) {
+            if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+            else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+          }
+          const double w = -tk * xk_group_sum<4>((d0 + d1) + (d2 + d3));
+#pragma unroll
+          for (int r = 0; r < RPL / 2; ++r) {
+            b[2 * r] = fma(w, u[r][0], b[2 * r]);
+            b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        // panel narrower than 16 (last panel): H_kk = I
+        if (pj == kk) {
+#pragma unroll
+          for (int r = 0; r < RPL; ++r) Vs[(part * RPL + r) * LDV + kk] = 0.0;
+          if (part == 0) taus[kk] = 0.0;
+        }
+      }
+    }
+    XK_QSTAMP(5);
+    // panel columns back in place (R in the pivot rows, zeros below); root strip -> R
+    if (mine) {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
+        const int row = part * RPL + r, m = row >> 4, rr = row & 15;
+        if (!grp[m]) continue;
+        double v = b[r];
+        if (root_out && m == 0) {
+          if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + col] = v;
+          v = 0.0;
+        }
+        grp[m][(size_t)rr * a.C1P + col] = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- G = V^T V on the matrix core (A and B fragments coincide), then T row by row
+    {
+      xk_d4 g = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4 * NT; ++s4) {
+        const double v = Vs[(4 * s4 + (lane >> 4)) * LDV + (lane & 15)];
+        g = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, g, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Gs[((lane >> 4) + 4 * r) * LDV + (lane & 15)] = g[r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) {
+      // row `lane` of T:  T(i,i) = tau_i,  T(i,j) = -tau_j sum_{m=i}^{j-1} T(i,m) G(m,j)
+      double trow[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < j; ++m) acc = fma((m >= lane) ? trow[m] : 0.0, Gs[m * LDV + j], acc);
+        trow[j] = (j == lane) ? taus[j] : ((j > lane) ? -taus[j] * acc : 0.0);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Ts[lane * LDV + j] = trow[j];
+    }
+    XK_QSTAMP(6);
+  }
+  // ================= trailing blocks: wave w >= 1 owns columns c0 + 16 w .. +15 =================
+  const int li = lane & 15, lq = lane >> 4;
+  const int bcol = a.c0 + 16 * wave + li;
+  const bool bmine = wave >= 1 && bcol < a.C1;
+  xk_d4 acc[NT];
+  if (wave >= 1) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = lq + 4 * r;
+        acc[m][r] = (bmine && grp[m] && rr < gvalid[m]) ? grp[m][(size_t)rr * a.C1P + bcol] : 0.0;
+      }
+  }
+  if (wave == 1) XK_QSTAMP(7);
+  __syncthreads();
+  if (wave == 1) XK_QSTAMP(8);
+  if (wave == 0 || a.c0 + 16 * wave >= a.C1) return;
+  {
+    xk_d4 W = {0.0, 0.0, 0.0, 0.0}, Y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(16 * m + 4 * r + lq) * LDV + li], acc[m][r], W, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      Y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[(4 * q + lq) * LDV + li], W[q], Y, 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Vs[(16 * m + li) * LDV + 4 * q + lq], Y[q], acc[m], 0, 0, 0);
+  }
+  if (wave == 1) XK_QSTAMP(9);
+  if (!bmine) return;
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    if (!grp[m]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = lq + 4 * r;
+      double v = acc[m][r];
+      if (root_out && m == 0) {
+        if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + bcol] = v;
+        v = 0.0;
+      }
+      grp[m][(size_t)rr * a.C1P + bcol] = v;
+    }
   }
 }
 
