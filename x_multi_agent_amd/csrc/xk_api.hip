@@ -379,12 +379,30 @@ static int launch_caqr(xk_handle *h, hipEvent_t mid) {
     const int threads_mfma = 64 * (1 + (h->C1 - c0 - 16 + 15) / 16);
     a.csplit = 1;
     a.chalf = trail;
+    // (splitting the per-tile kernel's columns as well was measured and does not pay: it already runs on every CU)
     if (valu) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<16, false>), dim3(ntiles, 1), dim3(round_up(4 * (16 + trail), 64)), 0, h->stream, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_mfma<4, false>), dim3(ntiles), dim3(threads_mfma), 0, h->stream, a);
+    if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
+    static const bool arity8 = getenv("XK_CAQR_ARITY8") != nullptr;
+    if (valu && !arity8) {
+      // 20-way strip merges, 8 lanes per column, 64 columns per workgroup -> two levels up to 400 tiles
+      static const int chalf_env = getenv("XK_CAQR_CHALF") ? atoi(getenv("XK_CAQR_CHALF")) : 8;
+      a.chalf = chalf_env;
+      a.csplit = std::max(1, (trail + a.chalf - 1) / a.chalf);
+      int stride = 1;
+      do {
+        a.stride = stride;
+        a.final_level = (20 * stride >= ntiles) ? 1 : 0;
+        const int grid = (ntiles + 20 * stride - 1) / (20 * stride);
+        hipLaunchKernelGGL(xk_caqr_strip20, dim3(grid, a.csplit), dim3(8 * (16 + a.chalf)), 0, h->stream, a);
+        ++launches;
+        stride *= 20;
+      } while (stride < ntiles);
+      continue;
+    }
     a.csplit = csplit;
     a.chalf = (csplit == 1) ? trail : round_up((trail + 1) / 2, 16);
     const int threads = valu ? round_up(4 * (16 + a.chalf), 64) : threads_mfma;
-    if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
     int stride = 1;
     do {
       a.stride = stride;

@@ -74,8 +74,9 @@ __device__ __forceinline__ double xk_dpp_quad(double x) {
 }
 template <int SPLIT>
 __device__ __forceinline__ double xk_group_sum(double x) {
-  x += xk_dpp_quad<0xB1>(x);                 // quad_perm [1,0,3,2]: lane ^ 1
-  if (SPLIT == 4) x += xk_dpp_quad<0x4E>(x); // quad_perm [2,3,0,1]: lane ^ 2
+  x += xk_dpp_quad<0xB1>(x);                  // quad_perm [1,0,3,2]: lane ^ 1
+  if (SPLIT >= 4) x += xk_dpp_quad<0x4E>(x);  // quad_perm [2,3,0,1]: lane ^ 2
+  if (SPLIT == 8) x += xk_dpp_quad<0x141>(x); // row_half_mirror: the other quad of the 8-lane group
   return x;
 }
 
@@ -481,7 +482,7 @@ struct XkCaqrArgs {
 template <int KK, int RPL>
 __device__ __forceinline__ double xk_caqr_pivot(const double (&b)[RPL]) { return b[KK]; }
 
-template <int RPL, bool STRIP>
+template <int RPL, bool STRIP, bool CSPLIT = STRIP>
 __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
   constexpr int RPLP = RPL + 2;
   __shared__ __attribute__((aligned(16))) double ubuf[2 * 4 * RPLP];
@@ -493,10 +494,10 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
   // (Only the strip merges are split; the per-tile kernel keeps the plain map -- two extra live
   // values there cost the 80-VGPR step that lets two of its workgroups share a CU.)
   const int cidx = (int)threadIdx.x / 4, part = threadIdx.x & 3;
-  const int col = (!STRIP || cidx < 16) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
+  const int col = (!CSPLIT || cidx < 16) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
   const int ntl = *a.ntl;
-  const bool mine = col < a.C1 && (!STRIP || cidx < 16 || cidx - 16 < a.chalf);
-  const bool wr = mine && (!STRIP || cidx >= 16 || blockIdx.y == 0);   // the panel is written by split 0 only
+  const bool mine = col < a.C1 && (!CSPLIT || cidx < 16 || cidx - 16 < a.chalf);
+  const bool wr = mine && (!CSPLIT || cidx >= 16 || blockIdx.y == 0);   // the panel is written by split 0 only
   // ---- which rows does this lane hold?
   double *rowp[RPL / 16];   // base pointer of each 16-row group (nullptr = absent -> zeros)
   int nvalid[RPL / 16];     // valid rows within the group
@@ -626,6 +627,126 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
       v = 0.0;
     }
     rowp[g][(size_t)rr * a.C1P + col] = v;
+  }
+}
+
+// 20-way strip merge: 8 lanes per column, 40 rows per lane (lane `part` holds strips part, part+8
+// and half of strip 16 + part/2), so 320 rows = 20 strips are merged per workgroup and 400 tiles
+// need only TWO merge levels per panel instead of three (20^2 = 400).  512 threads = 64 columns
+// per workgroup: the 16 panel columns (factored redundantly by every column split) + 48 trailing.
+__global__ __launch_bounds__(512) void xk_caqr_strip20(XkCaqrArgs a) {
+  constexpr int RPL = 40, RPLP = RPL + 2, NP = 8;
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
+  const int col = (cidx < 16) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
+  const int ntl = *a.ntl;
+  const bool mine = col < a.C1 && (cidx < 16 || cidx - 16 < a.chalf);
+  const bool wr = mine && (cidx >= 16 || blockIdx.y == 0);
+  const int base = blockIdx.x * 20 * a.stride;
+  if (base >= ntl) return;
+  // three row groups per lane: 16 rows of strip `part`, 16 rows of strip 8+part, 8 rows of strip 16+part/2
+  double *gp[3];
+  {
+    const int u0 = part, u1 = 8 + part, u2 = 16 + (part >> 1);
+    const int p0 = base + u0 * a.stride, p1 = base + u1 * a.stride, p2 = base + u2 * a.stride;
+    gp[0] = (p0 < ntl) ? a.A + (size_t)a.tile_list[p0] * 64 * a.C1P : nullptr;
+    gp[1] = (p1 < ntl) ? a.A + (size_t)a.tile_list[p1] * 64 * a.C1P : nullptr;
+    gp[2] = (p2 < ntl) ? a.A + ((size_t)a.tile_list[p2] * 64 + 8 * (part & 1)) * a.C1P : nullptr;
+  }
+  double b[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int g = r < 16 ? 0 : (r < 32 ? 1 : 2), rr = r < 16 ? r : (r < 32 ? r - 16 : r - 32);
+    b[r] = (mine && gp[g]) ? gp[g][(size_t)rr * a.C1P + col] : 0.0;
+  }
+  const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    if (kk < nsteps) {   // uniform
+      const int pb = kk & 1;
+      xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
+      double *scp = sc + pb * 4;
+      if (col == a.c0 + kk) {
+#pragma unroll
+        for (int r = 0; r < RPL; r += 2) {
+          xk_d2 tt = {b[r], b[r + 1]};
+          useg[r >> 1] = tt;
+        }
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const double x = ((part != 0) || (r > kk)) ? b[r] : 0.0;
+          if ((r & 3) == 0) s0 = fma(x, x, s0); else if ((r & 3) == 1) s1 = fma(x, x, s1);
+          else if ((r & 3) == 2) s2 = fma(x, x, s2); else s3 = fma(x, x, s3);
+        }
+        const double tail = xk_group_sum<8>((s0 + s1) + (s2 + s3));
+        if (part == 0) {
+          const double c0v = b[kk];
+          double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+          if (tail > 2.2250738585072014e-308) {
+            const double n2 = fma(c0v, c0v, tail);
+            double y = __builtin_amdgcn_rsq(n2);
+            y = y * fma(-0.5 * n2 * y, y, 1.5);
+            y = y * fma(-0.5 * n2 * y, y, 1.5);
+            const double ab = n2 * y;
+            beta = (c0v >= 0) ? -ab : ab;
+            vp = c0v - beta;
+            y2 = y * y;
+            tden = fma(fabs(c0v), y, 1.0);
+          }
+          xk_d2 s01 = {y2, tden};
+          *reinterpret_cast<xk_d2 *>(scp) = s01;
+          scp[2] = vp;
+          b[kk] = beta;
+        }
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+          if ((part != 0) || (r > kk)) b[r] = 0.0;
+      }
+      __syncthreads();
+      const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
+      const double vp = scp[2];
+      xk_d2 u[RPL / 2];
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+      if (col > a.c0 + kk && mine && s01[0] != 0.0) {
+        double rt = __builtin_amdgcn_rcp(s01[1]);
+        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+        if (part == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (r < kk) u[r >> 1][r & 1] = 0.0;
+            else if (r == kk) u[r >> 1][r & 1] = vp;
+          }
+        }
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int r = 0; r < RPL / 2; ++r) {
+          if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+          else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+        }
+        const double w = -(s01[0] * rt) * xk_group_sum<8>((d0 + d1) + (d2 + d3));
+#pragma unroll
+        for (int r = 0; r < RPL / 2; ++r) {
+          b[2 * r] = fma(w, u[r][0], b[2 * r]);
+          b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+        }
+      }
+    }
+  }
+  if (!wr) return;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    const int g = r < 16 ? 0 : (r < 32 ? 1 : 2), rr = r < 16 ? r : (r < 32 ? r - 16 : r - 32);
+    if (!gp[g]) continue;
+    double v = b[r];
+    if (a.final_level && part == 0 && g == 0) {
+      if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + col] = v;
+      v = 0.0;
+    }
+    gp[g][(size_t)rr * a.C1P + col] = v;
   }
 }
 
