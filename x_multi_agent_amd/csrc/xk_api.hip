@@ -394,7 +394,7 @@ static int launch_caqr(xk_handle *h, hipEvent_t mid) {
         a.stride = stride;
         a.final_level = (20 * stride >= ntiles) ? 1 : 0;
         const int grid = (ntiles + 20 * stride - 1) / (20 * stride);
-        hipLaunchKernelGGL(xk_caqr_strip20, dim3(grid, a.csplit), dim3(8 * (16 + a.chalf)), 0, h->stream, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_strip20<16>), dim3(grid, a.csplit), dim3(16 * (16 + a.chalf)), 0, h->stream, a);
         ++launches;
         stride *= 20;
       } while (stride < ntiles);

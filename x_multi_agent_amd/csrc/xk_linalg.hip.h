@@ -76,7 +76,8 @@ template <int SPLIT>
 __device__ __forceinline__ double xk_group_sum(double x) {
   x += xk_dpp_quad<0xB1>(x);                  // quad_perm [1,0,3,2]: lane ^ 1
   if (SPLIT >= 4) x += xk_dpp_quad<0x4E>(x);  // quad_perm [2,3,0,1]: lane ^ 2
-  if (SPLIT == 8) x += xk_dpp_quad<0x141>(x); // row_half_mirror: the other quad of the 8-lane group
+  if (SPLIT >= 8) x += xk_dpp_quad<0x141>(x); // row_half_mirror: the other quad of the 8-lane group
+  if (SPLIT == 16) x += xk_dpp_quad<0x140>(x); // row_mirror: the other half of the 16-lane row
   return x;
 }
 
@@ -348,7 +349,7 @@ struct XkCholDiagArgs {
 // carries column t of the inverse in registers through a forward substitution.
 __global__ __launch_bounds__(64) void xk_chol_diag(XkCholDiagArgs a) {
   constexpr int B = XK_CHOL_NB;
-  __shared__ double Lc[B][B + 1];  // Lc[k][i] = L(i,k)  (column k contiguous)
+  __shared__ __attribute__((aligned(16))) double Lc[B][B + 2];  // Lc[k][i] = L(i,k)  (column k contiguous)
   __shared__ double dinv[B];
   const int t = threadIdx.x, nb = a.nb;
   double row[B];
@@ -361,16 +362,25 @@ __global__ __launch_bounds__(64) void xk_chol_diag(XkCholDiagArgs a) {
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < B; ++k) {
-    const double piv = __shfl(row[k], k, 64);
+    // pivot from lane k (uniform); 1/sqrt from the hardware seed + two Newton steps
+    const long long pq = __builtin_bit_cast(long long, row[k]);
+    const int plo = __builtin_amdgcn_readlane((int)(pq & 0xffffffffLL), k), phi = __builtin_amdgcn_readlane((int)(pq >> 32), k);
+    const double piv = __builtin_bit_cast(double, ((long long)phi << 32) | (unsigned int)plo);
     if (!(piv > 0.0)) bad = true;
-    const double inv = 1.0 / sqrt(piv);
+    double inv = __builtin_amdgcn_rsq(piv);
+    inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
     const double lik = row[k] * inv;  // L(t,k) for t >= k (garbage above the diagonal, never used)
     if (t < B) Lc[k][t] = lik;
     if (t == k) dinv[k] = inv;        // 1 / L(k,k)
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
+    // column k of L, rows k+1.. as wide broadcast reads, then the FMAs
+    xk_d2 lc[B / 2];
 #pragma unroll
-    for (int j = k + 1; j < B; ++j) row[j] = fma(-lik, Lc[k][j], row[j]);  // A(t,j) -= L(t,k) L(j,k)
+    for (int jj = (k + 1) / 2; jj < B / 2; ++jj) lc[jj] = *reinterpret_cast<const xk_d2 *>(&Lc[k][2 * jj]);
+#pragma unroll
+    for (int j = k + 1; j < B; ++j) row[j] = fma(-lik, lc[j >> 1][j & 1], row[j]);  // A(t,j) -= L(t,k) L(j,k)
   }
   if (bad) {
     if (t == 0) *a.status = 2;
@@ -378,13 +388,16 @@ __global__ __launch_bounds__(64) void xk_chol_diag(XkCholDiagArgs a) {
     return;
   }
   // forward substitution for column t of L^-1:  x_i = (delta_it - sum_{m<i} L(i,m) x_m) / L(i,i)
+  // row i of L is gathered from the column store once per i (uniform addresses -> broadcasts)
   double x[B];
 #pragma unroll
   for (int i = 0; i < B; ++i) {
-    double sum = (i == t) ? 1.0 : 0.0;
+    double s0 = (i == t) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
-    for (int m = 0; m < i; ++m) sum = fma(-Lc[m][i], x[m], sum);
-    x[i] = sum * dinv[i];
+    for (int m = 0; m < i; ++m) {
+      if (m & 1) s1 = fma(-Lc[m][i], x[m], s1); else s0 = fma(-Lc[m][i], x[m], s0);
+    }
+    x[i] = (s0 + s1) * dinv[i];
   }
   if (t < B) {
 #pragma unroll
@@ -630,12 +643,14 @@ __global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
   }
 }
 
-// 20-way strip merge: 8 lanes per column, 40 rows per lane (lane `part` holds strips part, part+8
-// and half of strip 16 + part/2), so 320 rows = 20 strips are merged per workgroup and 400 tiles
-// need only TWO merge levels per panel instead of three (20^2 = 400).  512 threads = 64 columns
-// per workgroup: the 16 panel columns (factored redundantly by every column split) + 48 trailing.
-__global__ __launch_bounds__(512) void xk_caqr_strip20(XkCaqrArgs a) {
-  constexpr int RPL = 40, RPLP = RPL + 2, NP = 8;
+// 20-way strip merge: 320 rows = 20 strips per workgroup, so 400 tiles need only TWO merge levels
+// per panel (20^2 = 400).  NP lanes share a column (NP = 16: 20 rows per lane -- one whole strip
+// plus 4 rows of strips 16..19; NP = 8: 40 rows per lane).  The trailing columns are split over
+// gridDim.y workgroups of `chalf` columns; every split factors the 16 panel columns redundantly.
+template <int NP>
+__global__ __launch_bounds__(1024) void xk_caqr_strip20(XkCaqrArgs a) {
+  constexpr int RPL = 320 / NP, RPLP = RPL + 2;
+  constexpr int TR = RPL - (NP == 8 ? 32 : 16);   // rows of the tail strips (16..19) per lane: 8 or 4
   __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
   const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
@@ -645,19 +660,25 @@ __global__ __launch_bounds__(512) void xk_caqr_strip20(XkCaqrArgs a) {
   const bool wr = mine && (cidx >= 16 || blockIdx.y == 0);
   const int base = blockIdx.x * 20 * a.stride;
   if (base >= ntl) return;
-  // three row groups per lane: 16 rows of strip `part`, 16 rows of strip 8+part, 8 rows of strip 16+part/2
-  double *gp[3];
+  // row groups of this lane: [strip part] (+ [strip 8+part] when NP = 8) + TR rows of a tail strip
+  constexpr int NG = (NP == 8) ? 3 : 2;
+  double *gp[NG];
   {
-    const int u0 = part, u1 = 8 + part, u2 = 16 + (part >> 1);
-    const int p0 = base + u0 * a.stride, p1 = base + u1 * a.stride, p2 = base + u2 * a.stride;
+    const int p0 = base + part * a.stride;
     gp[0] = (p0 < ntl) ? a.A + (size_t)a.tile_list[p0] * 64 * a.C1P : nullptr;
-    gp[1] = (p1 < ntl) ? a.A + (size_t)a.tile_list[p1] * 64 * a.C1P : nullptr;
-    gp[2] = (p2 < ntl) ? a.A + ((size_t)a.tile_list[p2] * 64 + 8 * (part & 1)) * a.C1P : nullptr;
+    if (NP == 8) {
+      const int p1 = base + (8 + part) * a.stride;
+      gp[1] = (p1 < ntl) ? a.A + (size_t)a.tile_list[p1] * 64 * a.C1P : nullptr;
+    }
+    const int per = 16 / TR;                       // lanes per tail strip
+    const int p2 = base + (16 + part / per) * a.stride;
+    gp[NG - 1] = (p2 < ntl) ? a.A + ((size_t)a.tile_list[p2] * 64 + TR * (part % per)) * a.C1P : nullptr;
   }
   double b[RPL];
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    const int g = r < 16 ? 0 : (r < 32 ? 1 : 2), rr = r < 16 ? r : (r < 32 ? r - 16 : r - 32);
+    const int g = (r < 16) ? 0 : ((NP == 8 && r < 32) ? 1 : NG - 1);
+    const int rr = (r < 16) ? r : ((NP == 8 && r < 32) ? r - 16 : r - (RPL - TR));
     b[r] = (mine && gp[g]) ? gp[g][(size_t)rr * a.C1P + col] : 0.0;
   }
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
@@ -680,7 +701,7 @@ __global__ __launch_bounds__(512) void xk_caqr_strip20(XkCaqrArgs a) {
           if ((r & 3) == 0) s0 = fma(x, x, s0); else if ((r & 3) == 1) s1 = fma(x, x, s1);
           else if ((r & 3) == 2) s2 = fma(x, x, s2); else s3 = fma(x, x, s3);
         }
-        const double tail = xk_group_sum<8>((s0 + s1) + (s2 + s3));
+        const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
         if (part == 0) {
           const double c0v = b[kk];
           double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
@@ -727,7 +748,7 @@ __global__ __launch_bounds__(512) void xk_caqr_strip20(XkCaqrArgs a) {
           if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
           else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
         }
-        const double w = -(s01[0] * rt) * xk_group_sum<8>((d0 + d1) + (d2 + d3));
+        const double w = -(s01[0] * rt) * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
 #pragma unroll
         for (int r = 0; r < RPL / 2; ++r) {
           b[2 * r] = fma(w, u[r][0], b[2 * r]);
@@ -739,7 +760,8 @@ __global__ __launch_bounds__(512) void xk_caqr_strip20(XkCaqrArgs a) {
   if (!wr) return;
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    const int g = r < 16 ? 0 : (r < 32 ? 1 : 2), rr = r < 16 ? r : (r < 32 ? r - 16 : r - 32);
+    const int g = (r < 16) ? 0 : ((NP == 8 && r < 32) ? 1 : NG - 1);
+    const int rr = (r < 16) ? r : ((NP == 8 && r < 32) ? r - 16 : r - (RPL - TR));
     if (!gp[g]) continue;
     double v = b[r];
     if (a.final_level && part == 0 && g == 0) {
