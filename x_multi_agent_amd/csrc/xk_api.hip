@@ -32,7 +32,8 @@ struct xk_handle {
   double *d_P, *d_Pout;
   double *d_chi95, *d_chi90;
   double *d_A;
-  int *d_tile_rows, *d_tile_list, *d_ntl;
+  int *d_tile_rows;
+  double *d_panel[2];   // CAQR: merged 16 x 16 panel blocks of the odd / even merge levels
   bool caqr;            // compression path: CAQR (C1 <= 192, tiles <= 64 rows) or the binary TSQR tree
   int *d_inl, *d_inl_s, *d_gn;
   double *d_gam, *d_gam_s, *d_gpf;
@@ -138,8 +139,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
   HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
-  HIPCHK(h, dalloc(&h->d_tile_list, (size_t)h->ntiles_max + 8));
-  HIPCHK(h, dalloc(&h->d_ntl, (size_t)4));
+  for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max / 20 + 2) * 256));
   HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_inl_s, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_gn, (size_t)k_max));
@@ -175,7 +175,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->d_q, h->d_p, h->d_obs, h->d_trk_off, h->d_feat, h->d_zlast, h->d_anchor, h->d_tsz,
-                  h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_tile_list, h->d_ntl, h->d_inl, h->d_inl_s,
+                  h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_panel[0], h->d_panel[1], h->d_inl, h->d_inl_s,
                   h->d_gn, h->d_gam, h->d_gam_s, h->d_gpf, h->d_R, h->d_Maug, h->d_X, h->d_Linv, h->d_corr,
                   h->d_ct, h->d_tmpH, h->d_tmpS, h->d_tmpP, h->d_rdiag, h->d_tmpz, h->d_status, h->d_payload,
                   h->d_ci};
@@ -355,63 +355,49 @@ static int pick_nleaf(xk_handle *h, int ntiles) {
 
 // CAQR: panels of 16 columns; per panel one in-place tile factorisation on every tile, then 8-way
 // strip merges (<= 3 levels for <= 512 tiles); the root strip of each panel is 16 rows of R.
+template <int RPL>
+static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_merge<RPL>), dim3(groups, csplit), dim3(16 * (16 + a.chalf)), 0, h->stream, a);
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static int launch_caqr(xk_handle *h, hipEvent_t mid) {
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   const int ntiles = h->K + slam_tiles;
-  if (ntiles > 1024) return fail(h, XK_ECAPACITY, "CAQR path supports at most 1024 tiles");
   hipMemsetAsync(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P, h->stream);
-  hipLaunchKernelGGL(xk_compact_tiles, dim3(1), dim3(1024), 0, h->stream, h->d_tile_rows, ntiles, h->d_tile_list, h->d_ntl);
   XkCaqrArgs a;
-  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.tile_list = h->d_tile_list; a.ntl = h->d_ntl;
+  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles;
   a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
+  // first-level arity: 40 strips per workgroup once 20 x 20 no longer covers the stack in two levels
+  static const int arity1_env = env_int("XK_CAQR_ARITY1", 0);
+  const int arity1 = arity1_env ? arity1_env : (ntiles > 400 ? 40 : 20);
+  static const int chalf = env_int("XK_CAQR_CHALF", 8);
   int launches = 0;
   for (int c0 = 0; c0 < h->C1; c0 += 16) {
-    a.c0 = c0; a.stride = 1; a.final_level = 0;
-    // default: broadcast-per-step kernels.  XK_CAQR_MFMA=1 selects the matrix-core variant (panel on one
-    // wave + compact-WY trailing update as fp64 MFMAs): parity-identical, but measured 2x SLOWER because the
-    // single-wave panel chain (1.25 k cycles/step) and the T recurrence dominate.
-    static const bool valu = getenv("XK_CAQR_MFMA") == nullptr;
-    // MFMA kernels: wave 0 = panel, one wave per trailing 16-column block
-    // column split of the strip merges: while more than 96 trailing columns are live, two workgroups
-    // share them (the per-tile kernel already runs on every CU and stays unsplit)
     const int trail = std::max(0, h->C1 - c0 - 16);
-    const int csplit = (valu && trail > 96 && !getenv("XK_CAQR_NOSPLIT")) ? 2 : 1;
-    const int threads_mfma = 64 * (1 + (h->C1 - c0 - 16 + 15) / 16);
-    a.csplit = 1;
-    a.chalf = trail;
-    // (splitting the per-tile kernel's columns as well was measured and does not pay: it already runs on every CU)
-    if (valu) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<16, false>), dim3(ntiles, 1), dim3(round_up(4 * (16 + trail), 64)), 0, h->stream, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_mfma<4, false>), dim3(ntiles), dim3(threads_mfma), 0, h->stream, a);
+    a.c0 = c0; a.stride = 1; a.final_level = 0; a.chalf = trail; a.pin = nullptr; a.pout = nullptr;
+    hipLaunchKernelGGL(xk_caqr_tile, dim3(ntiles), dim3(round_up(4 * (16 + trail), 64)), 0, h->stream, a);
     if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
-    static const bool arity8 = getenv("XK_CAQR_ARITY8") != nullptr;
-    if (valu && !arity8) {
-      // 20-way strip merges, 8 lanes per column, 64 columns per workgroup -> two levels up to 400 tiles
-      static const int chalf_env = getenv("XK_CAQR_CHALF") ? atoi(getenv("XK_CAQR_CHALF")) : 8;
-      a.chalf = chalf_env;
-      a.csplit = std::max(1, (trail + a.chalf - 1) / a.chalf);
-      int stride = 1;
-      do {
-        a.stride = stride;
-        a.final_level = (20 * stride >= ntiles) ? 1 : 0;
-        const int grid = (ntiles + 20 * stride - 1) / (20 * stride);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_strip20<16>), dim3(grid, a.csplit), dim3(16 * (16 + a.chalf)), 0, h->stream, a);
-        ++launches;
-        stride *= 20;
-      } while (stride < ntiles);
-      continue;
-    }
-    a.csplit = csplit;
-    a.chalf = (csplit == 1) ? trail : round_up((trail + 1) / 2, 16);
-    const int threads = valu ? round_up(4 * (16 + a.chalf), 64) : threads_mfma;
-    int stride = 1;
+    a.chalf = chalf;
+    const int csplit = std::max(1, (trail + a.chalf - 1) / a.chalf);
+    int stride = 1, level = 0;
     do {
+      const int left = (ntiles + stride - 1) / stride;             // strips still alive at this level
+      const int arity = (stride == 1) ? arity1 : (left > 20 ? 40 : 20);
       a.stride = stride;
-      a.final_level = (8 * stride >= ntiles) ? 1 : 0;
-      const int grid = (ntiles + 8 * stride - 1) / (8 * stride);
-      if (valu) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_panel<32, true>), dim3(grid, csplit), dim3(threads), 0, h->stream, a);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_mfma<8, true>), dim3(grid), dim3(threads), 0, h->stream, a);
+      a.final_level = (left <= arity) ? 1 : 0;
+      const int groups = (left + arity - 1) / arity;
+      a.pin = (stride == 1) ? nullptr : h->d_panel[level & 1];
+      a.pout = h->d_panel[(level + 1) & 1];
+      ++level;
+      if (arity == 40) launch_merge<40>(h, a, groups, csplit);
+      else launch_merge<20>(h, a, groups, csplit);
       ++launches;
-      stride *= 8;
+      stride *= arity;
     } while (stride < ntiles);
   }
   h->nleaf = ntiles;
@@ -1217,12 +1203,14 @@ extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
 }
 
 #ifdef XK_FEAT_PROBE
-extern "C" int xk_debug_feature_phases(xk_handle *h, double sigma_img, long long *out8) {
-  hipMalloc((void **)&g_feat_dbg, 64);
-  hipMemset(g_feat_dbg, 0, 64);
+extern "C" int xk_debug_feature_phases(xk_handle *h, double sigma_img, long long *out, int n_out) {
+  // out[12k ..]: 8 clock64 phase stamps, wall start, wall end, (XCC_ID << 32 | HW_ID) of workgroup k
+  const size_t bytes = sizeof(long long) * (size_t)(12 * h->K);
+  hipMalloc((void **)&g_feat_dbg, bytes);
+  hipMemset(g_feat_dbg, 0, bytes);
   int rc = launch_build(h, sigma_img);
   hipStreamSynchronize(h->stream);
-  hipMemcpy(out8, g_feat_dbg, 64, hipMemcpyDeviceToHost);
+  hipMemcpy(out, g_feat_dbg, std::min(bytes, sizeof(long long) * (size_t)n_out), hipMemcpyDeviceToHost);
   hipFree(g_feat_dbg);
   g_feat_dbg = nullptr;
   return rc;

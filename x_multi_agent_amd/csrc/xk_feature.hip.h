@@ -23,9 +23,16 @@
 typedef double xk_f2 __attribute__((ext_vector_type(2)));
 #define XK_FEAT_THREADS 256
 #ifdef XK_FEAT_PROBE
-#define XK_STAMP(i) do { __syncthreads(); if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
+#define XK_STAMP(i) do { __syncthreads(); if (a.dbg && threadIdx.x == 0) a.dbg[12 * (size_t)blockIdx.x + i] = clock64(); } while (0)
+// per-workgroup record dbg[12k ..]: 8 phase stamps (clock64), wall-clock start/end, placement (XCC_ID, HW_ID)
+#define XK_WG_BEGIN() const long long xk_w0 = wall_clock64()
+#define XK_WG_END() do { if (a.dbg && threadIdx.x == 0) { long long *e = a.dbg + 12 * (size_t)blockIdx.x + 8; e[0] = xk_w0; e[1] = wall_clock64(); \
+    unsigned xcc, hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); \
+    e[2] = ((long long)xcc << 32) | hw; } } while (0)
 #else
 #define XK_STAMP(i)
+#define XK_WG_BEGIN()
+#define XK_WG_END()
 #endif
 
 struct XkFeatArgs {
@@ -107,7 +114,9 @@ __device__ inline void xk_null4(double a[4][4], double x[4]) {
           ga += a[i][p] * a[i][q];
         }
         const double lim = sqrt(al * be);
-        if (fabs(ga) > 1e-300 && fabs(ga) > 1e-17 * lim) {
+        // columns already orthogonal to working precision are left alone: rotating on rounding noise
+        // never converges (a handful of tracks used to burn all 30 sweeps, 4x the phase time)
+        if (fabs(ga) > 1e-300 && fabs(ga) > 4.4e-16 * lim) {
           off = fmax(off, fabs(ga) / (lim > 0 ? lim : 1.0));
           const double zeta = (be - al) / (2.0 * ga);
           const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -123,7 +132,7 @@ __device__ inline void xk_null4(double a[4][4], double x[4]) {
           }
         }
       }
-    if (off < 1e-16) break;
+    if (off < 1e-15) break;
   }
   double bn = 1e300;
   x[0] = x[1] = x[2] = x[3] = 0.0;
@@ -235,6 +244,7 @@ static inline size_t xk_feature_lds_bytes(int n_poses) {
 
 __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  XK_WG_BEGIN();
   const int tid = threadIdx.x, k = blockIdx.x;
   const int np = a.n_poses, Lmax = np;
   const int ldm = 2 * Lmax + 1;
@@ -685,7 +695,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
     }
     if (tid < 3) ur[tid] = res[tid];
   }
-  if (scal[11] == 0.0 || !a.A) return;
+  if (scal[11] == 0.0 || !a.A) { XK_WG_END(); return; }
 
   // ---- tile write: rows 3.. of Q^T [J | res] over the active columns (:431-432,468-479)
   double *tile = a.A + (size_t)k * a.DB * a.C1P;
@@ -719,6 +729,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
     }
   }
   XK_STAMP(7);
+  XK_WG_END();
 }
 
 // ----------------------------------------------------------------------------

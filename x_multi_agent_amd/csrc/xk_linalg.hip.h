@@ -465,565 +465,255 @@ __global__ void xk_copy2d(XkCopyArgs a) {
 // Communication-avoiding QR (CAQR) of the tile stack: the compression path for systems with
 // C1 <= 192 columns and tiles of at most 64 rows.
 //
-// The binary TSQR tree above serialises 7 merges of ~350 Householder steps each on ONE
+// The binary TSQR tree above serialises ~9 merges of ~350 Householder steps each on ONE
 // workgroup.  CAQR walks the columns in panels of 16 instead; per panel
-//   (1) every tile factors its own 64 x 16 panel IN PLACE (pivot rows = its rows 0..15) and
-//       applies the 16 reflectors to its trailing columns           -- grid = #tiles
-//   (2) the 16-row strips [R_loc | C_loc] (rows 0..15 of each tile) are merged 8 at a time by
-//       the same in-place QR on the stacked 128 x 16 triangles      -- 3 levels for <= 512 tiles
+//   (1) xk_caqr_tile: every tile factors its own 64 x 16 panel IN PLACE (pivot rows = its rows
+//       0..15) and applies the 16 reflectors to its trailing columns          -- grid = #tiles
+//   (2) xk_caqr_merge: the 16-row strips [R_loc | C_loc] (rows 0..15 of each tile) are merged A at
+//       a time by the same in-place QR on the stacked 16A x 16 panel; A = 20 or 40, so 400 tiles
+//       need two levels                                                       -- grid = groups x column splits
 //   (3) the root strip is the next 16 rows of the global R; it is moved out and zeroed.
-// The dependent chain is 12 panels x 4 launches of 16 steps, and step (1) runs on every CU.
+// The dependent chain is 12 panels x 3 launches of 16 steps, and step (1) runs on every CU.
 //
-// Lane layout as in xk_qr_pass: 4 lanes per column, lane `part` holds RPL consecutive rows of the
-// block in registers (RPL = 16: one tile; RPL = 32: eight strips).  The pivot row of step kk is
-// register kk of the part-0 lane; the 16 steps are fully unrolled so that index is static.  The
-// broadcast vector u has u[<kk] = 0, u[kk] = 1, so the update code is identical for every lane.
+// Tiles are addressed by position (tile t = rows [64 t, 64 t + 64) of A): no compaction list, so a
+// workgroup's first loads are the data themselves -- a launch is short enough (~15 us) that every
+// dependent round trip to HBM/MALL (~1 us each) shows.  Tiles of rejected tracks are all-zero rows.
+//
+// Lane layout as in xk_qr_pass: NP lanes per column, lane `part` holds RPL consecutive rows of the
+// stacked block in registers.  The pivot row of step kk is register kk of the part-0 lane; the 16
+// steps are fully unrolled so that index is static.  The broadcast vector u has u[<kk] = 0 and
+// u[kk] = v_pivot for the part-0 lane, so the update code is identical for every lane.
 // ----------------------------------------------------------------------------
 struct XkCaqrArgs {
   double *A;              // tiles [ntiles][64][C1P] row-major (in place)
-  const int *tile_rows;   // valid rows per tile before panel 0
-  const int *tile_list;   // compacted list of tiles that hold data
-  const int *ntl;         // device: number of entries in tile_list
+  const int *tile_rows;   // valid rows per tile before panel 0 (0 = rejected track)
+  int ntiles;
   int C1P, C1, c0;        // panel = columns [c0, min(c0+16, C1))
-  int stride;             // strip mode: group g merges list positions g*8*stride + u*stride
-  int final_level;        // strip mode: root strip -> Rout, then zeroed
+  int stride;             // merge: group g merges tiles g*A*stride + u*stride, u = 0..A-1
+  int final_level;        // merge: root strip -> Rout, then zeroed
   double *Rout;           // [C1P][C1P] row-major
-  int csplit, chalf;      // trailing columns split over gridDim.y workgroups of `chalf` columns each
-  long long *dbg;         // optional: s_memtime stamps of workgroup 0 (probe builds only)
+  int chalf;              // merge: trailing columns split over gridDim.y workgroups of `chalf` columns each
+  const double *pin;      // merge: 16 x 16 panel blocks of the previous level [group][16][16] (null: read the tiles)
+  double *pout;           // merge: panel block of this group for the next level
+  long long *dbg;         // optional: clock stamps of workgroup 0 (probe builds only)
 };
 
-template <int KK, int RPL>
-__device__ __forceinline__ double xk_caqr_pivot(const double (&b)[RPL]) { return b[KK]; }
-
-template <int RPL, bool STRIP, bool CSPLIT = STRIP>
-__global__ __launch_bounds__(768) void xk_caqr_panel(XkCaqrArgs a) {
+// One Householder step of the in-place panel QR shared by the tile and merge kernels.
+//   b[RPL]   this lane's rows of its column;  rel = column index relative to the panel start
+//            (trailing columns: anything >= 16);  live = the column exists
+//   Un-normalised reflectors  H = I - tt v v^T,  v = [c0 - beta; x_below],  tt = 1/(|beta|(|beta|+|c0|))
+//   = y^2 / (1 + |c0| y) with y = 1/|beta| from ONE rsq + Newton.  The owner publishes its raw column
+//   BEFORE the scalar chain (the LDS write latency hides behind rsq/Newton) and only three scalars
+//   after it; the division by t = 1 + |c0| y is done by every consumer, overlapped with its LDS reads.
+// (Several columns per lane -- fewer LDS broadcast reads, independent FMA chains -- was measured and is
+//  slower at every width tried: a step is bound by the owner -> barrier -> consumer latency chain.)
+template <int KK, int NP, int RPL>
+__device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool live, int part, double *ubuf, double *sc) {
   constexpr int RPLP = RPL + 2;
-  __shared__ __attribute__((aligned(16))) double ubuf[2 * 4 * RPLP];
-  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
-  // Column map: the 16 panel columns first (every column-split workgroup factors the panel
-  // redundantly -- the step chain is sequential anyway), then this workgroup's share of the
-  // trailing columns.  Splitting halves the LDS broadcast traffic per CU, which is what bounds
-  // a step while more than ~100 columns are live.
-  // (Only the strip merges are split; the per-tile kernel keeps the plain map -- two extra live
-  // values there cost the 80-VGPR step that lets two of its workgroups share a CU.)
-  const int cidx = (int)threadIdx.x / 4, part = threadIdx.x & 3;
-  const int col = (!CSPLIT || cidx < 16) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
-  const int ntl = *a.ntl;
-  const bool mine = col < a.C1 && (!CSPLIT || cidx < 16 || cidx - 16 < a.chalf);
-  const bool wr = mine && (!CSPLIT || cidx >= 16 || blockIdx.y == 0);   // the panel is written by split 0 only
-  // ---- which rows does this lane hold?
-  double *rowp[RPL / 16];   // base pointer of each 16-row group (nullptr = absent -> zeros)
-  int nvalid[RPL / 16];     // valid rows within the group
-  if (!STRIP) {
-    if ((int)blockIdx.x >= ntl) return;
-    const int t = a.tile_list[blockIdx.x];
-    const int rows = (a.c0 == 0) ? a.tile_rows[t] : 64;
-    rowp[0] = a.A + ((size_t)t * 64 + part * 16) * a.C1P;
-    nvalid[0] = rows - part * 16;
-  } else {
-    const int base = blockIdx.x * 8 * a.stride;
-    if (base >= ntl) return;
+  constexpr int pb = KK & 1;
+  xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
+  double *scp = sc + pb * 4;
+  if (rel == KK) {
 #pragma unroll
-    for (int g = 0; g < RPL / 16; ++g) {
-      const int pos = base + (part * (RPL / 16) + g) * a.stride;
-      rowp[g] = (pos < ntl) ? a.A + (size_t)a.tile_list[pos] * 64 * a.C1P : nullptr;
-      nvalid[g] = 16;
+    for (int r = 0; r < RPL; r += 2) {
+      xk_d2 tt = {b[r], b[r + 1]};
+      useg[r >> 1] = tt;
+    }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const double v = ((part != 0) || (r > KK)) ? b[r] : 0.0;
+      if ((r & 3) == 0) s0 = fma(v, v, s0); else if ((r & 3) == 1) s1 = fma(v, v, s1);
+      else if ((r & 3) == 2) s2 = fma(v, v, s2); else s3 = fma(v, v, s3);
+    }
+    const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
+    if (part == 0) {
+      const double c0v = b[KK];
+      double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+      if (tail > 2.2250738585072014e-308) {
+        const double n2 = fma(c0v, c0v, tail);
+        double y = __builtin_amdgcn_rsq(n2);             // ~ 1/|beta|
+        y = y * fma(-0.5 * n2 * y, y, 1.5);
+        y = y * fma(-0.5 * n2 * y, y, 1.5);
+        const double ab = n2 * y;                        // |beta|
+        beta = (c0v >= 0) ? -ab : ab;
+        vp = c0v - beta;
+        y2 = y * y;
+        tden = fma(fabs(c0v), y, 1.0);
+      }
+      xk_d2 s01 = {y2, tden};
+      *reinterpret_cast<xk_d2 *>(scp) = s01;
+      scp[2] = vp;
+      b[KK] = beta;
+    }
+#pragma unroll
+    for (int r = 0; r < RPL; ++r)
+      if ((part != 0) || (r > KK)) b[r] = 0.0;
+  }
+  __syncthreads();
+  const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
+  const double vp = scp[2];
+  xk_d2 u[RPL / 2];
+#pragma unroll
+  for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+  if (rel > KK && live && s01[0] != 0.0) {
+    double rt = __builtin_amdgcn_rcp(s01[1]);
+    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+    if (part == 0) {   // rows above the pivot are not part of the reflector; the pivot entry is vp
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r < KK) u[r >> 1][r & 1] = 0.0;
+        else if (r == KK) u[r >> 1][r & 1] = vp;
+      }
+    }
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+      else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+    }
+    const double w = -(s01[0] * rt) * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
     }
   }
+}
+
+template <int NP, int RPL>
+__device__ __forceinline__ void xk_caqr_steps(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc) {
+#define XK_STEP(K) if (K < nsteps) xk_caqr_step<K, NP, RPL>(b, rel, live, part, ubuf, sc);
+  XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
+  XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
+#undef XK_STEP
+}
+
+// (1) per-tile panel step: 4 lanes per column, 16 rows per lane, all live columns in one workgroup
+// (the kernel must stay at <= 80 VGPRs so that two 12-wave workgroups share a CU).
+__global__ __launch_bounds__(768) void xk_caqr_tile(XkCaqrArgs a) {
+  constexpr int NP = 4, RPL = 16, RPLP = RPL + 2;
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
+  const int col = a.c0 + cidx;
+  const bool mine = col < a.C1;
+  const int t = blockIdx.x;
+  double *rowp = a.A + ((size_t)t * 64 + part * RPL) * a.C1P + col;
   double b[RPL];
 #ifdef XK_CAQR_PROBE
-  long long t0 = clock64();
+  const long long t0 = clock64();
 #endif
+  // the loads do not wait for the row count: rows past it are masked after they arrive
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) {
-    const int g = r / 16, rr = r % 16;
-    b[r] = (mine && rowp[g] && rr < nvalid[g]) ? rowp[g][(size_t)rr * a.C1P + col] : 0.0;
+  for (int r = 0; r < RPL; ++r) b[r] = mine ? rowp[(size_t)r * a.C1P] : 0.0;
+  if (a.c0 == 0) {
+    const int nvalid = a.tile_rows[t] - part * RPL;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) b[r] = (r < nvalid) ? b[r] : 0.0;
   }
 #ifdef XK_CAQR_PROBE
   double sink = 0; for (int r = 0; r < RPL; ++r) sink += b[r];
   asm volatile("" :: "v"(sink));
-  long long t1 = clock64();
+  const long long t1 = clock64(), w1 = wall_clock64();
 #endif
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
-  // Un-normalised reflectors  H = I - tt v v^T,  v = [c0 - beta; x_below],  tt = 1/(|beta|(|beta|+|c0|))
-  //   = y^2 / (1 + |c0| y) with y = 1/|beta| from ONE rsq + Newton.  The owner publishes its raw column
-  // BEFORE the scalar chain (the LDS write latency hides behind rsq/Newton) and only three scalars
-  // after it; the division by t = 1 + |c0| y is done by every consumer, overlapped with its LDS reads.
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    if (kk < nsteps) {   // uniform
-      const int pb = kk & 1;
-      xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
-      double *scp = sc + pb * 4;
-      if (col == a.c0 + kk) {
-#pragma unroll
-        for (int r = 0; r < RPL; r += 2) {
-          xk_d2 tt = {b[r], b[r + 1]};
-          useg[r >> 1] = tt;
-        }
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          const double x = ((part != 0) || (r > kk)) ? b[r] : 0.0;
-          if (r & 1) s1 = fma(x, x, s1); else s0 = fma(x, x, s0);
-        }
-        const double tail = xk_group_sum<4>(s0 + s1);
-        const double c0v = xk_dpp_quad<0x00>(b[kk]);   // quad_perm [0,0,0,0]: pivot from the part-0 lane
-        double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
-        if (tail > 2.2250738585072014e-308) {
-          const double n2 = fma(c0v, c0v, tail);
-          double y = __builtin_amdgcn_rsq(n2);             // ~ 1/|beta|
-          y = y * fma(-0.5 * n2 * y, y, 1.5);
-          y = y * fma(-0.5 * n2 * y, y, 1.5);
-          const double ab = n2 * y;                        // |beta|
-          const double ac = fabs(c0v);
-          beta = (c0v >= 0) ? -ab : ab;
-          vp = c0v - beta;
-          y2 = y * y;
-          tden = fma(ac, y, 1.0);
-        }
-        if (part == 0) {
-          xk_d2 s01 = {y2, tden};
-          *reinterpret_cast<xk_d2 *>(scp) = s01;
-          scp[2] = vp;
-        }
-#pragma unroll
-        for (int r = 0; r < RPL; ++r)
-          if ((part != 0) || (r > kk)) b[r] = 0.0;
-        if (part == 0) b[kk] = beta;
-      }
-      __syncthreads();
-      const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-      const double vp = scp[2];
-      xk_d2 u[RPL / 2];
-#pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-      if (col > a.c0 + kk && mine && s01[0] != 0.0) {
-        double rt = __builtin_amdgcn_rcp(s01[1]);
-        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-        if (part == 0) {   // rows above the pivot are not part of the reflector; the pivot entry is vp
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) {
-            if (r < kk) u[r >> 1][r & 1] = 0.0;
-            else if (r == kk) u[r >> 1][r & 1] = vp;
-          }
-        }
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) {
-          if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
-          else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
-        }
-        const double w = -(s01[0] * rt) * xk_group_sum<4>((d0 + d1) + (d2 + d3));
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) {
-          b[2 * r] = fma(w, u[r][0], b[2 * r]);
-          b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
-        }
-      }
-    }
-  }
+  xk_caqr_steps<NP, RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
 #ifdef XK_CAQR_PROBE
-  long long t2 = clock64();
-  if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[3] = nsteps; }
+  const long long t2 = clock64();
+  if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[2] = wall_clock64() - w1; a.dbg[3] = nsteps; }
 #endif
-  // ---- write back in place; the root strip of the last level becomes rows c0.. of R
-  if (!wr) return;
+  if (!mine) return;
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) {
-    const int g = r / 16, rr = r % 16;
-    if (!rowp[g]) continue;
-    double v = b[r];
-    if (STRIP && a.final_level && part == 0 && g == 0) {
-      if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + col] = v;
-      v = 0.0;
-    }
-    rowp[g][(size_t)rr * a.C1P + col] = v;
-  }
+  for (int r = 0; r < RPL; ++r) rowp[(size_t)r * a.C1P] = b[r];
 }
 
-// 20-way strip merge: 320 rows = 20 strips per workgroup, so 400 tiles need only TWO merge levels
-// per panel (20^2 = 400).  NP lanes share a column (NP = 16: 20 rows per lane -- one whole strip
-// plus 4 rows of strips 16..19; NP = 8: 40 rows per lane).  The trailing columns are split over
-// gridDim.y workgroups of `chalf` columns; every split factors the 16 panel columns redundantly.
-template <int NP>
-__global__ __launch_bounds__(1024) void xk_caqr_strip20(XkCaqrArgs a) {
-  constexpr int RPL = 320 / NP, RPLP = RPL + 2;
-  constexpr int TR = RPL - (NP == 8 ? 32 : 16);   // rows of the tail strips (16..19) per lane: 8 or 4
+// (2) A-way strip merge, A = RPL strips (16 lanes per column, RPL = 20 or 40 rows per lane).
+// The trailing columns are split over gridDim.y workgroups of `chalf` columns; every split factors
+// the 16 panel columns redundantly (the step chain is sequential anyway).  Because the splits of a
+// group run unsynchronised, nobody may overwrite what another split still has to read: a split
+// writes only its own trailing columns in place, and the merged 16 x 16 panel block goes to a
+// per-level scratch (`pout`, read back as `pin` by the next level; the last level writes R).  The
+// panel columns left behind in the tiles are dead -- no later panel reads them.
+template <int RPL>
+__global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArgs a) {
+  constexpr int NP = 16, RPLP = RPL + 2, ARITY = NP * RPL / 16;
+  static_assert(RPL >= 16 && RPL % 4 == 0, "the part-0 lane must hold the 16 pivot rows");
   __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+#ifdef XK_CAQR_PROBE
+  const long long w0 = wall_clock64();
+#endif
   const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
-  const int col = (cidx < 16) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
-  const int ntl = *a.ntl;
-  const bool mine = col < a.C1 && (cidx < 16 || cidx - 16 < a.chalf);
-  const bool wr = mine && (cidx >= 16 || blockIdx.y == 0);
-  const int base = blockIdx.x * 20 * a.stride;
-  if (base >= ntl) return;
-  // row groups of this lane: [strip part] (+ [strip 8+part] when NP = 8) + TR rows of a tail strip
-  constexpr int NG = (NP == 8) ? 3 : 2;
+  const bool panel = cidx < 16;
+  const int col = panel ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
+  const bool mine = col < a.C1 && (panel || cidx - 16 < a.chalf);
+  const int base = blockIdx.x * ARITY * a.stride;
+  // Row groups of this lane: FG whole strips (strip g*16 + part -> registers 16g..16g+15) and TR rows of
+  // one of the TR tail strips (16/TR lanes share a tail strip).  A group is addressed by one base pointer
+  // and a uniform row stride: the tiles, or the previous level's 16 x 16 panel blocks for panel columns.
+  constexpr int FG = RPL / 16, TR = RPL - 16 * FG, NG = FG + 1, PER = 16 / TR;
+  static_assert(TR > 0 && 16 % TR == 0, "lane layout");
+  const bool from_pin = panel && a.pin;
+  const size_t rs = from_pin ? 16 : (size_t)a.C1P;
   double *gp[NG];
-  {
-    const int p0 = base + part * a.stride;
-    gp[0] = (p0 < ntl) ? a.A + (size_t)a.tile_list[p0] * 64 * a.C1P : nullptr;
-    if (NP == 8) {
-      const int p1 = base + (8 + part) * a.stride;
-      gp[1] = (p1 < ntl) ? a.A + (size_t)a.tile_list[p1] * 64 * a.C1P : nullptr;
-    }
-    const int per = 16 / TR;                       // lanes per tail strip
-    const int p2 = base + (16 + part / per) * a.stride;
-    gp[NG - 1] = (p2 < ntl) ? a.A + ((size_t)a.tile_list[p2] * 64 + TR * (part % per)) * a.C1P : nullptr;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int s = (g < FG) ? g * 16 + part : 16 * FG + part / PER;
+    const int r0 = (g < FG) ? 0 : TR * (part % PER);
+    const int pos = base + s * a.stride;
+    gp[g] = (pos >= a.ntiles) ? nullptr
+            : from_pin ? const_cast<double *>(a.pin) + ((size_t)(blockIdx.x * ARITY + s) * 16 + r0) * 16 + cidx
+                       : a.A + ((size_t)pos * 64 + r0) * a.C1P + col;
   }
   double b[RPL];
 #pragma unroll
   for (int r = 0; r < RPL; ++r) {
-    const int g = (r < 16) ? 0 : ((NP == 8 && r < 32) ? 1 : NG - 1);
-    const int rr = (r < 16) ? r : ((NP == 8 && r < 32) ? r - 16 : r - (RPL - TR));
-    b[r] = (mine && gp[g]) ? gp[g][(size_t)rr * a.C1P + col] : 0.0;
+    const int g = (r < 16 * FG) ? r / 16 : FG, rr = (r < 16 * FG) ? r % 16 : r - 16 * FG;
+    b[r] = (mine && gp[g]) ? gp[g][rr * rs] : 0.0;
   }
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
-#pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    if (kk < nsteps) {   // uniform
-      const int pb = kk & 1;
-      xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
-      double *scp = sc + pb * 4;
-      if (col == a.c0 + kk) {
-#pragma unroll
-        for (int r = 0; r < RPL; r += 2) {
-          xk_d2 tt = {b[r], b[r + 1]};
-          useg[r >> 1] = tt;
-        }
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL; ++r) {
-          const double x = ((part != 0) || (r > kk)) ? b[r] : 0.0;
-          if ((r & 3) == 0) s0 = fma(x, x, s0); else if ((r & 3) == 1) s1 = fma(x, x, s1);
-          else if ((r & 3) == 2) s2 = fma(x, x, s2); else s3 = fma(x, x, s3);
-        }
-        const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
-        if (part == 0) {
-          const double c0v = b[kk];
-          double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
-          if (tail > 2.2250738585072014e-308) {
-            const double n2 = fma(c0v, c0v, tail);
-            double y = __builtin_amdgcn_rsq(n2);
-            y = y * fma(-0.5 * n2 * y, y, 1.5);
-            y = y * fma(-0.5 * n2 * y, y, 1.5);
-            const double ab = n2 * y;
-            beta = (c0v >= 0) ? -ab : ab;
-            vp = c0v - beta;
-            y2 = y * y;
-            tden = fma(fabs(c0v), y, 1.0);
-          }
-          xk_d2 s01 = {y2, tden};
-          *reinterpret_cast<xk_d2 *>(scp) = s01;
-          scp[2] = vp;
-          b[kk] = beta;
-        }
-#pragma unroll
-        for (int r = 0; r < RPL; ++r)
-          if ((part != 0) || (r > kk)) b[r] = 0.0;
-      }
-      __syncthreads();
-      const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-      const double vp = scp[2];
-      xk_d2 u[RPL / 2];
-#pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-      if (col > a.c0 + kk && mine && s01[0] != 0.0) {
-        double rt = __builtin_amdgcn_rcp(s01[1]);
-        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-        rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-        if (part == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            if (r < kk) u[r >> 1][r & 1] = 0.0;
-            else if (r == kk) u[r >> 1][r & 1] = vp;
-          }
-        }
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) {
-          if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
-          else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
-        }
-        const double w = -(s01[0] * rt) * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) {
-          b[2 * r] = fma(w, u[r][0], b[2 * r]);
-          b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
-        }
-      }
-    }
+#ifdef XK_CAQR_PROBE
+  double sink = 0; for (int r = 0; r < RPL; ++r) sink += b[r];
+  asm volatile("" :: "v"(sink));
+  const long long t1 = clock64(), w1 = wall_clock64();
+#endif
+  xk_caqr_steps<NP, RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
+#ifdef XK_CAQR_PROBE
+  const long long w2 = wall_clock64();
+  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    a.dbg[1] = clock64() - t1; a.dbg[2] = w2 - w1; a.dbg[3] = nsteps;
+    a.dbg[4] = w0; a.dbg[5] = w1; a.dbg[6] = w2;
   }
-  if (!wr) return;
+#endif
+  if (!mine) return;
+  if (panel) {
+    // the merged panel block: rows 0..15 of the stack, held by the part-0 lanes; split 0 publishes it
+    if (part == 0 && blockIdx.y == 0) {
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) {
-    const int g = (r < 16) ? 0 : ((NP == 8 && r < 32) ? 1 : NG - 1);
-    const int rr = (r < 16) ? r : ((NP == 8 && r < 32) ? r - 16 : r - (RPL - TR));
-    if (!gp[g]) continue;
-    double v = b[r];
-    if (a.final_level && part == 0 && g == 0) {
-      if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + col] = v;
-      v = 0.0;
-    }
-    gp[g][(size_t)rr * a.C1P + col] = v;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// CAQR panel step on the matrix cores.
-//
-// Same in-place block QR as xk_caqr_panel (block = one 64-row tile, NT = 4, or eight 16-row strips,
-// NT = 8), but only the 16 panel columns go through the step-by-step reflector broadcast: wave 0
-// factors the (16*NT) x 16 panel on its own (wave-local LDS exchange, no workgroup barrier), forms
-// the compact-WY factor T (T^-1 = striu(V^T V) + diag(1/tau), V^T V by MFMA) and publishes V, T.
-// Every other wave owns ONE 16-column block of the trailing matrix, resident in the fp64 MFMA C/D
-// layout (lane l, register r <-> row 16m + (l>>4) + 4r, column l&15), and applies
-//      W = V^T A        (4*NT MFMAs)     A fragment (m, r) IS the B operand of K-slice (m, r)
-//      Y = T^T W        (4 MFMAs)        W registers are the B operands of the next product
-//      A -= V Y         (4*NT MFMAs)     Y registers likewise
-// so no fragment ever moves between lanes.
-// ----------------------------------------------------------------------------
-template <int NT, bool STRIP>
-__global__ __launch_bounds__(768) void xk_caqr_mfma(XkCaqrArgs a) {
-  constexpr int ROWS = 16 * NT, RPL = 4 * NT, RPLP = RPL + 2, LDV = 17;
-  __shared__ __attribute__((aligned(16))) double Vs[ROWS * LDV];   // explicit V (unit diagonal, zeros above)
-  __shared__ __attribute__((aligned(16))) double Ts[16 * LDV];     // T (upper triangular)
-  __shared__ __attribute__((aligned(16))) double Gs[16 * LDV];     // V^T V
-  __shared__ __attribute__((aligned(16))) double ubuf[2 * 4 * RPLP];
-  __shared__ double taus[16];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ntl = *a.ntl;
-  // ---- row sources: 16-row groups of the block
-  double *grp[NT];
-  int gvalid[NT];
-  if (!STRIP) {
-    if ((int)blockIdx.x >= ntl) return;
-    const int t = a.tile_list[blockIdx.x];
-    const int rows = (a.c0 == 0) ? a.tile_rows[t] : 64;
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      grp[m] = a.A + ((size_t)t * 64 + 16 * m) * a.C1P;
-      gvalid[m] = rows - 16 * m;
+      for (int r = 0; r < 16; ++r) {
+        if (a.final_level) { if (a.c0 + r < a.C1) a.Rout[(size_t)(a.c0 + r) * a.C1P + col] = b[r]; }
+        else a.pout[((size_t)blockIdx.x * 16 + r) * 16 + cidx] = b[r];
+      }
     }
   } else {
-    const int base = blockIdx.x * 8 * a.stride;
-    if (base >= ntl) return;
-#pragma unroll
-    for (int m = 0; m < NT; ++m) {
-      const int pos = base + m * a.stride;
-      grp[m] = (pos < ntl) ? a.A + (size_t)a.tile_list[pos] * 64 * a.C1P : nullptr;
-      gvalid[m] = 16;
-    }
-  }
-  const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
-  const bool root_out = STRIP && a.final_level;
-
-#ifdef XK_CAQR_PROBE
-  long long q0 = clock64();
-#define XK_QSTAMP(i) do { if (a.dbg && blockIdx.x == 0 && lane == 0) a.dbg[i] = clock64() - q0; } while (0)
-#else
-#define XK_QSTAMP(i)
-#endif
-  if (wave == 0) {
-    // ================= panel factorisation: 4 lanes per column, RPL rows per lane =================
-    const int pj = lane >> 2, part = lane & 3, col = a.c0 + pj;
-    const bool mine = pj < nsteps;
-    double b[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
-      const int row = part * RPL + r, m = row >> 4, rr = row & 15;
-      b[r] = (mine && grp[m] && rr < gvalid[m]) ? grp[m][(size_t)rr * a.C1P + col] : 0.0;
-    }
-    XK_QSTAMP(4);
-#pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int pb = kk & 1;
-      xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
-      double tau = 0.0;
-      if (kk < nsteps) {
-        if (pj == kk) {
-          double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) {
-            const double x = ((part != 0) || (r > kk)) ? b[r] : 0.0;
-            if (r & 1) s1 = fma(x, x, s1); else s0 = fma(x, x, s0);
-          }
-          const double tail = xk_group_sum<4>(s0 + s1);
-          const double c0v = xk_dpp_quad<0x00>(b[kk]);
-          double scale, beta;
-          if (tail <= 2.2250738585072014e-308) { tau = 0.0; scale = 0.0; beta = c0v; }
-          else {
-            beta = xk_sqrt(fma(c0v, c0v, tail));
-            if (c0v >= 0) beta = -beta;
-            tau = (beta - c0v) * xk_rcp(beta);
-            scale = xk_rcp(c0v - beta);
-          }
-#pragma unroll
-          for (int r = 0; r < RPL; r += 2) {
-            double u0 = b[r] * scale, u1 = b[r + 1] * scale;
-            if (part == 0) {
-              u0 = (r < kk) ? 0.0 : (r == kk ? 1.0 : u0);
-              u1 = (r + 1 < kk) ? 0.0 : (r + 1 == kk ? 1.0 : u1);
-            }
-            xk_d2 tt = {u0, u1};
-            useg[r >> 1] = tt;
-            Vs[(part * RPL + r) * LDV + kk] = u0;      // explicit V for the MFMA phase
-            Vs[(part * RPL + r + 1) * LDV + kk] = u1;
-          }
-          if (part == 0) taus[kk] = tau;
-#pragma unroll
-          for (int r = 0; r < RPL; ++r)
-            if ((part != 0) || (r > kk)) b[r] = 0.0;
-          if (part == 0) b[kk] = beta;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // wave-local exchange: no workgroup barrier needed
-        __builtin_amdgcn_wave_barrier();
-        const double tk = taus[kk];
-        xk_d2 u[RPL / 2];
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-        if (pj > kk && mine && tk != 0.0) {
-          double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-          for (int r = 0; r < RPL / 2; ++r) {
-            if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
-            else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
-          }
-          const double w = -tk * xk_group_sum<4>((d0 + d1) + (d2 + d3));
-#pragma unroll
-          for (int r = 0; r < RPL / 2; ++r) {
-            b[2 * r] = fma(w, u[r][0], b[2 * r]);
-            b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      } else {
-        // panel narrower than 16 (last panel): H_kk = I
-        if (pj == kk) {
-#pragma unroll
-          for (int r = 0; r < RPL; ++r) Vs[(part * RPL + r) * LDV + kk] = 0.0;
-          if (part == 0) taus[kk] = 0.0;
-        }
-      }
-    }
-    XK_QSTAMP(5);
-    // panel columns back in place (R in the pivot rows, zeros below); root strip -> R
-    if (mine) {
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) {
-        const int row = part * RPL + r, m = row >> 4, rr = row & 15;
-        if (!grp[m]) continue;
-        double v = b[r];
-        if (root_out && m == 0) {
-          if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + col] = v;
-          v = 0.0;
-        }
-        grp[m][(size_t)rr * a.C1P + col] = v;
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    // ---- G = V^T V on the matrix core (A and B fragments coincide), then T row by row
-    {
-      xk_d4 g = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4 * NT; ++s4) {
-        const double v = Vs[(4 * s4 + (lane >> 4)) * LDV + (lane & 15)];
-        g = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, g, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Gs[((lane >> 4) + 4 * r) * LDV + (lane & 15)] = g[r];
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) {
-      // row `lane` of T:  T(i,i) = tau_i,  T(i,j) = -tau_j sum_{m=i}^{j-1} T(i,m) G(m,j)
-      double trow[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < j; ++m) acc = fma((m >= lane) ? trow[m] : 0.0, Gs[m * LDV + j], acc);
-        trow[j] = (j == lane) ? taus[j] : ((j > lane) ? -taus[j] * acc : 0.0);
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) Ts[lane * LDV + j] = trow[j];
-    }
-    XK_QSTAMP(6);
-  }
-  // ================= trailing blocks: wave w >= 1 owns columns c0 + 16 w .. +15 =================
-  const int li = lane & 15, lq = lane >> 4;
-  const int bcol = a.c0 + 16 * wave + li;
-  const bool bmine = wave >= 1 && bcol < a.C1;
-  xk_d4 acc[NT];
-  if (wave >= 1) {
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = lq + 4 * r;
-        acc[m][r] = (bmine && grp[m] && rr < gvalid[m]) ? grp[m][(size_t)rr * a.C1P + bcol] : 0.0;
-      }
-  }
-  if (wave == 1) XK_QSTAMP(7);
-  __syncthreads();
-  if (wave == 1) XK_QSTAMP(8);
-  if (wave == 0 || a.c0 + 16 * wave >= a.C1) return;
-  {
-    xk_d4 W = {0.0, 0.0, 0.0, 0.0}, Y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        W = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(16 * m + 4 * r + lq) * LDV + li], acc[m][r], W, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      Y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[(4 * q + lq) * LDV + li], W[q], Y, 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < NT; ++m)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Vs[(16 * m + li) * LDV + 4 * q + lq], Y[q], acc[m], 0, 0, 0);
-  }
-  if (wave == 1) XK_QSTAMP(9);
-  if (!bmine) return;
-#pragma unroll
-  for (int m = 0; m < NT; ++m) {
-    if (!grp[m]) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = lq + 4 * r;
-      double v = acc[m][r];
-      if (root_out && m == 0) {
-        if (a.c0 + rr < a.C1) a.Rout[(size_t)(a.c0 + rr) * a.C1P + bcol] = v;
+      const int g = (r < 16 * FG) ? r / 16 : FG, rr = (r < 16 * FG) ? r % 16 : r - 16 * FG;
+      if (!gp[g]) continue;
+      double v = b[r];
+      if (a.final_level && part == 0 && r < 16) {   // stacked rows 0..15 of the root group = rows c0.. of R
+        if (a.c0 + r < a.C1) a.Rout[(size_t)(a.c0 + r) * a.C1P + col] = v;
         v = 0.0;
       }
-      grp[m][(size_t)rr * a.C1P + bcol] = v;
+      gp[g][rr * rs] = v;
     }
   }
-}
-
-// Deterministic compaction of the tiles that hold data (inlier tracks / SLAM tiles).
-__global__ __launch_bounds__(1024) void xk_compact_tiles(const int *tile_rows, int ntiles, int *tile_list, int *ntl) {
-  __shared__ int cnt[1024];
-  const int t = threadIdx.x;
-  // each thread scans a contiguous chunk so the order is the tile order
-  const int per = (ntiles + 1023) / 1024, lo = t * per, hi = min(ntiles, lo + per);
-  int c = 0;
-  for (int i = lo; i < hi; ++i) c += tile_rows[i] > 0;
-  cnt[t] = c;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = (t >= o) ? cnt[t - o] : 0;
-    __syncthreads();
-    cnt[t] += v;
-    __syncthreads();
+#ifdef XK_CAQR_PROBE
+  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    a.dbg[7] = wall_clock64();
   }
-  int at = cnt[t] - c;
-  for (int i = lo; i < hi; ++i)
-    if (tile_rows[i] > 0) tile_list[at++] = i;
-  if (t == 1023) *ntl = cnt[1023];
+#endif
 }
