@@ -7,4 +7,4 @@ import csv
 rows=list(csv.DictReader(open("gpurun_out/ks/k_kernel_stats.csv")))
 for r in rows[:7]: print(f"{r['Name'][:52]:52s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:8.2f} total_ms {float(r['TotalDurationNs'])/1e6:8.2f}")
 PY
-tail -1 gpurun_out/ks.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['stages_ms'])"
+grep "^{" gpurun_out/ks.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['stages_ms'])"

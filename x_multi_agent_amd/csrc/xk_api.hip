@@ -43,7 +43,7 @@ struct xk_handle {
   double sigma_img;
   // update workspace
   int CM, LDA;
-  double *d_Maug, *d_X, *d_Linv, *d_corr, *d_ct, *d_tmpH, *d_tmpS, *d_tmpP, *d_rdiag, *d_tmpz;
+  double *d_Maug, *d_X, *d_corr, *d_ct, *d_tmpH, *d_tmpS, *d_tmpP, *d_rdiag, *d_tmpz;
   int *d_status;
   // CI / payload
   double *d_payload;
@@ -149,7 +149,6 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_R, (size_t)h->nleaf_max * h->C1P * h->C1P));
   HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_X, (size_t)h->CM * h->LDA));
-  HIPCHK(h, dalloc(&h->d_Linv, (size_t)XK_CHOL_NB * XK_CHOL_NB));
   HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n));
   HIPCHK(h, dalloc(&h->d_ct, (size_t)h->n));
   HIPCHK(h, dalloc(&h->d_tmpH, (size_t)h->CM * h->n));
@@ -176,7 +175,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   hipStreamSynchronize(h->stream);
   void *ptrs[] = {h->d_q, h->d_p, h->d_obs, h->d_trk_off, h->d_feat, h->d_zlast, h->d_anchor, h->d_tsz,
                   h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_panel[0], h->d_panel[1], h->d_inl, h->d_inl_s,
-                  h->d_gn, h->d_gam, h->d_gam_s, h->d_gpf, h->d_R, h->d_Maug, h->d_X, h->d_Linv, h->d_corr,
+                  h->d_gn, h->d_gam, h->d_gam_s, h->d_gpf, h->d_R, h->d_Maug, h->d_X, h->d_corr,
                   h->d_ct, h->d_tmpH, h->d_tmpS, h->d_tmpP, h->d_rdiag, h->d_tmpz, h->d_status, h->d_payload,
                   h->d_ci};
   for (void *p : ptrs)
@@ -496,30 +495,13 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     XkZArgs z{u.T, u.str, u.stc, c, u.kdim, u.col0, u.z, u.sz, u.ct, h->d_Maug + c + n, (long)LDA};
     hipLaunchKernelGGL(xk_zprime, dim3((c + 63) / 64), dim3(64), 0, h->stream, z);
   }
-  // blocked Cholesky with the right-hand sides carried along
+  // blocked Cholesky with the right-hand sides carried along: one launch per 32-column block step
   const int ncols = c + n + 1;
   for (int kb = 0; kb < c; kb += XK_CHOL_NB) {
     const int nb = std::min(XK_CHOL_NB, c - kb);
-    XkCholDiagArgs d{h->d_Maug, LDA, kb, nb, h->d_Linv, h->d_status};
-    hipLaunchKernelGGL(xk_chol_diag, dim3(1), dim3(64), 0, h->stream, d);
-    const int rest = ncols - (kb + nb);
-    memset(&g, 0, sizeof(g));
-    g.A = h->d_Linv; g.sar = XK_CHOL_NB; g.sac = 1;
-    g.B = h->d_Maug + (size_t)kb * LDA + kb + nb; g.sbr = LDA; g.sbc = 1;
-    g.C = h->d_X + (size_t)kb * LDA + kb + nb; g.scr = LDA; g.scc = 1;
-    g.D = g.C; g.sdr = LDA; g.sdc = 1;
-    g.M = nb; g.N = rest; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.mode = 0;
-    gemm(h, g);
-    const int mrem = c - kb - nb;
-    if (mrem > 0) {
-      memset(&g, 0, sizeof(g));
-      g.A = h->d_X + (size_t)kb * LDA + kb + nb; g.sar = 1; g.sac = LDA;
-      g.B = g.A; g.sbr = LDA; g.sbc = 1;
-      g.C = h->d_Maug + (size_t)(kb + nb) * LDA + kb + nb; g.scr = LDA; g.scc = 1;
-      g.D = g.C; g.sdr = LDA; g.sdc = 1;
-      g.M = mrem; g.N = rest; g.K = nb; g.alpha = -1.0; g.beta = 1.0; g.mode = 0;
-      gemm(h, g);
-    }
+    const int rest = ncols - (kb + nb), mrem = c - kb - nb;
+    XkCholStepArgs d{h->d_Maug, LDA, kb, nb, c, ncols, h->d_X, (rest + 15) / 16, h->d_status};
+    hipLaunchKernelGGL(xk_chol_step, dim3(d.ncb * (1 + (mrem + 15) / 16)), dim3(64), 0, h->stream, d);
   }
   // P+ = sym(P - X^T X),  X = L^-1 W                   (I-KH)P, (P+P^T)/2
   if (u.cov_update) {

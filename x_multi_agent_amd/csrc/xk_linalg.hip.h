@@ -327,82 +327,171 @@ __global__ __launch_bounds__(256) void xk_gemm_f64(XkGemmArgs g) {
 
 // ----------------------------------------------------------------------------
 // Blocked Cholesky of the augmented row-major matrix  Maug = [S | W | z]
-// (c x (c + nrhs)).  Per block step kb:
-//   xk_chol_diag   : factor the nb x nb diagonal block S_kk = L L^T (LDS, one
-//                    workgroup) and write Linv = L^-1
-//   gemm           : X[kb:kb+nb, kb+nb:] = Linv * Maug[kb:kb+nb, kb+nb:]
-//   gemm           : Maug[kb+nb:, kb+nb:] -= X[kb:kb+nb, S cols]^T * X[kb:kb+nb, kb+nb:]
+// (c x (c + nrhs)), ONE launch per block step kb (xk_chol_step):
+//   X[kb:kb+nb, kb+nb:]     = L_kk^-1 * Maug[kb:kb+nb, kb+nb:]
+//   Maug[kb+nb:, kb+nb:]   -= X[kb:kb+nb, S cols]^T * X[kb:kb+nb, kb+nb:]
 // After the last step X[:, c:] = L^-1 [W | z].
+//
+// A block step used to be three dependent launches (diagonal factor, row scaling, trailing update)
+// of 4-15 us each for a few MFLOP.  Now every workgroup is ONE wave that owns one 16 x 16 tile of
+// the step's output and factors the 32 x 32 diagonal block itself: the factorisation is redundant
+// across workgroups, but it is 32 dependent steps whoever runs it, and this way nothing waits for
+// a launch.  Lane t keeps row t of the block AND row t of L^-1 in registers (static indexing, fully
+// unrolled); column k of L and row k of L^-1 travel through LDS as wave-wide broadcasts.  The tile
+// products run on the matrix cores: X_i = L^-1 B_i lands in the MFMA C/D layout, whose registers
+// are exactly the A / B operands of X_i^T X_j, so no fragment moves between lanes.
 // ----------------------------------------------------------------------------
 #define XK_CHOL_NB 32
 
-struct XkCholDiagArgs {
-  const double *Maug;
-  int ld, kb, nb;
-  double *Linv;  // [XK_CHOL_NB][XK_CHOL_NB] row-major
-  int *status;   // set to 2 (XK_ESINGULAR) if a pivot is not positive
+struct XkCholStepArgs {
+  double *Maug;      // [c][ld] row-major
+  int ld, kb, nb;    // diagonal block rows/cols [kb, kb+nb)
+  int c, ncols;      // rows of Maug, columns in use (c + n + 1)
+  double *X;         // same shape / ld as Maug
+  int ncb;           // column tiles of the trailing range [kb+nb, ncols)
+  int *status;       // set to 2 (XK_ESINGULAR) if a pivot is not positive
+#ifdef XK_CHOL_PROBE
+  long long *dbg;    // clock64 stamps of the last workgroup
+#endif
 };
 
-// One wave.  Lane t keeps row t of the block in registers (static indexing, fully unrolled);
-// column k of L is published through LDS and read back as wave-wide broadcasts, so there is no
-// workgroup barrier and no per-element index arithmetic.  L^-1 is built the same way: lane t
-// carries column t of the inverse in registers through a forward substitution.
-__global__ __launch_bounds__(64) void xk_chol_diag(XkCholDiagArgs a) {
-  constexpr int B = XK_CHOL_NB;
-  __shared__ __attribute__((aligned(16))) double Lc[B][B + 2];  // Lc[k][i] = L(i,k)  (column k contiguous)
-  __shared__ double dinv[B];
-  const int t = threadIdx.x, nb = a.nb;
-  double row[B];
-  // read the upper triangle (row-oriented updates keep it current): A(t,j) = M(min,max)
+#ifdef XK_CHOL_PROBE
+#define XK_CSTAMP(i) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.dbg[i] = clock64(); } while (0)
+#else
+#define XK_CSTAMP(i)
+#endif
+
+__global__ __launch_bounds__(64) void xk_chol_step(XkCholStepArgs a) {
+  constexpr int B = XK_CHOL_NB, LDL = B + 1;
+  // comb[k][j]: j <= k -> row k of L^-1 (unscaled), j > k -> L(j,k): the one broadcast row of step k
+  __shared__ __attribute__((aligned(16))) double comb[B][B + 2];
+  __shared__ double Ls[B * LDL];                                 // L^-1, row-major, for the MFMA gathers
+  const int t = threadIdx.x, nb = a.nb, kb = a.kb;
+  const int rb = blockIdx.x / a.ncb, cb = blockIdx.x % a.ncb;    // rb = 0: X tile; rb >= 1: trailing row block rb-1
+  const int c0 = kb + nb;                                        // first trailing row / column
+  if (rb >= 1 && 16 * cb + 15 < 16 * (rb - 1)) return;           // below the diagonal of S: never read
+  XK_CSTAMP(0);
+  // ---- operands of the tile products: independent of the factorisation, so their HBM latency is
+  // hidden behind it.  MFMA 16x16x4 layouts: A/B operand lane l <-> (index l&15, k = l>>4).
+  const int li = t & 15, lk = t >> 4;
+  const int colj = c0 + 16 * cb + li;            // this lane's column of the tile
+  const int rowi = c0 + 16 * (rb > 0 ? rb - 1 : 0) + li;   // as a COLUMN of Maug it carries X_i
+  const bool cj_ok = colj < a.ncols, ci_ok = rb > 0 && rowi < a.c;
+  double bj[B / 4], bi[B / 4], cold[4];
+#pragma unroll
+  for (int q = 0; q < B / 4; ++q) {
+    const int k = 4 * q + lk;
+    bj[q] = (cj_ok && k < nb) ? a.Maug[(size_t)(kb + k) * a.ld + colj] : 0.0;
+    bi[q] = (ci_ok && k < nb) ? a.Maug[(size_t)(kb + k) * a.ld + rowi] : 0.0;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = c0 + 16 * (rb - 1) + lk + 4 * r;
+    cold[r] = (rb > 0 && cj_ok && i < a.c) ? a.Maug[(size_t)i * a.ld + colj] : 0.0;
+  }
+  // ---- factor the diagonal block and invert the factor.  Lanes 0..31: lane t keeps row t of the
+  // block (Cholesky, row-oriented); lanes 32..63: lane 32+t keeps row t of L^-1, built by applying the
+  // same eliminations to the identity.  Both halves run the SAME 32 FMAs per step on v[] against the
+  // broadcast row comb[k][]: positions j > k carry column k of L (used by the Cholesky half),
+  // positions j <= k carry row k of L^-1 (used by the inverse half).
+  const bool inv_half = t >= B;
+  const int tt = t & (B - 1);
+  double v[B];
+  // the upper triangle is current (row-oriented updates): A(t,j) = M(min,max); identity padding past nb
 #pragma unroll
   for (int j = 0; j < B; ++j) {
-    const int r = t < j ? t : j, c = t < j ? j : t;
-    row[j] = (t < nb && j < nb) ? a.Maug[(size_t)(a.kb + r) * a.ld + a.kb + c] : ((t == j) ? 1.0 : 0.0);
+    const int r = tt < j ? tt : j, cc = tt < j ? j : tt;
+    const double av = (!inv_half && tt < nb && j < nb) ? a.Maug[(size_t)(kb + r) * a.ld + kb + cc] : ((tt == j) ? 1.0 : 0.0);
+    v[j] = av;
   }
+  XK_CSTAMP(1);
   bool bad = false;
+  // Row k of L^-1 is final, up to the factor 1/L(k,k), as soon as step k-1 has updated it: its lane
+  // publishes it UNSCALED at the end of step k-1, off the pivot -> column -> update chain.
+  if (t == B) comb[0][0] = 1.0;
 #pragma unroll
   for (int k = 0; k < B; ++k) {
     // pivot from lane k (uniform); 1/sqrt from the hardware seed + two Newton steps
-    const long long pq = __builtin_bit_cast(long long, row[k]);
+    const long long pq = __builtin_bit_cast(long long, v[k]);
     const int plo = __builtin_amdgcn_readlane((int)(pq & 0xffffffffLL), k), phi = __builtin_amdgcn_readlane((int)(pq >> 32), k);
     const double piv = __builtin_bit_cast(double, ((long long)phi << 32) | (unsigned int)plo);
     if (!(piv > 0.0)) bad = true;
     double inv = __builtin_amdgcn_rsq(piv);
     inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
     inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
-    const double lik = row[k] * inv;  // L(t,k) for t >= k (garbage above the diagonal, never used)
-    if (t < B) Lc[k][t] = lik;
-    if (t == k) dinv[k] = inv;        // 1 / L(k,k)
+    const double lik = v[k] * inv;     // Cholesky half: L(t,k) for t >= k
+    if (!inv_half && t > k) comb[k][t] = lik;
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
-    // column k of L, rows k+1.. as wide broadcast reads, then the FMAs
-    xk_d2 lc[B / 2];
+    // Cholesky half:  A(t,j) -= L(t,k) L(j,k)           for j > k  (entries j <= k are dead)
+    // inverse half:   W(t,j) -= L(t,k)/L(k,k) Wraw(k,j)  for j <= k, t > k;  W(k,:) = Wraw(k,:)/L(k,k)
+    // (the owner of row k scales it in the same FMA: bc[j] IS its own v[j], and v - (1 - 1/l) v = v / l)
+    const double ltk = !inv_half ? 0.0 : (tt > k) ? comb[k][tt] * inv : (tt == k) ? 1.0 - inv : 0.0;
+    const double m_hi = inv_half ? 0.0 : lik;
+    xk_d2 bc[B / 2];
 #pragma unroll
-    for (int jj = (k + 1) / 2; jj < B / 2; ++jj) lc[jj] = *reinterpret_cast<const xk_d2 *>(&Lc[k][2 * jj]);
+    for (int jj = 0; jj < B / 2; ++jj) bc[jj] = *reinterpret_cast<const xk_d2 *>(&comb[k][2 * jj]);
 #pragma unroll
-    for (int j = k + 1; j < B; ++j) row[j] = fma(-lik, lc[j >> 1][j & 1], row[j]);  // A(t,j) -= L(t,k) L(j,k)
+    for (int j = 0; j < B; ++j) v[j] = fma((j <= k) ? -ltk : -m_hi, bc[j >> 1][j & 1], v[j]);
+    if (k + 1 < B && t == B + k + 1) {
+#pragma unroll
+      for (int j = 0; j <= k + 1; ++j) comb[k + 1][j] = v[j];
+    }
+    // pin this step's results here: the optimiser otherwise sinks the FMAs towards their first use
+    // (the pivot of step j), keeps every step's broadcast operands live meanwhile, and spills
+#pragma unroll
+    for (int j = 0; j < B; ++j) asm volatile("" : "+v"(v[j]));
   }
+  XK_CSTAMP(2);
   if (bad) {
-    if (t == 0) *a.status = 2;
-    for (int idx = t; idx < B * B; idx += 64) a.Linv[idx] = 0.0;
+    if (blockIdx.x == 0 && t == 0) *a.status = 2;
     return;
   }
-  // forward substitution for column t of L^-1:  x_i = (delta_it - sum_{m<i} L(i,m) x_m) / L(i,i)
-  // row i of L is gathered from the column store once per i (uniform addresses -> broadcasts)
-  double x[B];
+  if (inv_half) {
 #pragma unroll
-  for (int i = 0; i < B; ++i) {
-    double s0 = (i == t) ? 1.0 : 0.0, s1 = 0.0;
+    for (int j = 0; j < B; ++j) Ls[tt * LDL + j] = (j <= tt) ? v[j] : 0.0;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  XK_CSTAMP(3);
+  // ---- X_j = L^-1 * B_j for the column tile (and X_i for the row block), on the matrix cores
+  typedef double xk_d4 __attribute__((ext_vector_type(4)));
+  xk_d4 xj[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, xi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int m = 0; m < i; ++m) {
-      if (m & 1) s1 = fma(-Lc[m][i], x[m], s1); else s0 = fma(-Lc[m][i], x[m], s0);
+  for (int q = 0; q < B / 4; ++q) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      if (4 * q >= 16 * tm + 16) continue;       // L^-1 is lower triangular: rows 16tm.. only see k < 16tm+16
+      const double lv = Ls[(16 * tm + li) * LDL + 4 * q + lk];
+      xj[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, bj[q], xj[tm], 0, 0, 0);
+      if (rb > 0) xi[tm] = __builtin_amdgcn_mfma_f64_16x16x4f64(lv, bi[q], xi[tm], 0, 0, 0);
     }
-    x[i] = (s0 + s1) * dinv[i];
   }
-  if (t < B) {
+  XK_CSTAMP(4);
+  if (rb == 0) {
+    if (!cj_ok) return;
 #pragma unroll
-    for (int i = 0; i < B; ++i) a.Linv[i * B + t] = (i < nb && t < nb && t <= i) ? x[i] : 0.0;
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * tm + lk + 4 * r;
+        if (k < nb) a.X[(size_t)(kb + k) * a.ld + colj] = xj[tm][r];
+      }
+    return;
   }
+  // C(i,j) -= sum_k X(k,i) X(k,j): register r of row-tile tm is K-slice 16tm + 4r of both operands
+  xk_d4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xi[tm][r], xj[tm][r], acc, 0, 0, 0);
+  if (!cj_ok) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = c0 + 16 * (rb - 1) + lk + 4 * r;
+    if (i < a.c) a.Maug[(size_t)i * a.ld + colj] = cold[r] - acc[r];
+  }
+  XK_CSTAMP(5);
 }
 
 // corr[i] = sum_k X[k][xoff+i] * y[k] - ct[i]      (K z' - corr_tot, updater.cpp:126)
@@ -502,11 +591,18 @@ struct XkCaqrArgs {
 //   b[RPL]   this lane's rows of its column;  rel = column index relative to the panel start
 //            (trailing columns: anything >= 16);  live = the column exists
 //   Un-normalised reflectors  H = I - tt v v^T,  v = [c0 - beta; x_below],  tt = 1/(|beta|(|beta|+|c0|))
-//   = y^2 / (1 + |c0| y) with y = 1/|beta| from ONE rsq + Newton.  The owner publishes its raw column
-//   BEFORE the scalar chain (the LDS write latency hides behind rsq/Newton) and only three scalars
-//   after it; the division by t = 1 + |c0| y is done by every consumer, overlapped with its LDS reads.
-// (Several columns per lane -- fewer LDS broadcast reads, independent FMA chains -- was measured and is
-//  slower at every width tried: a step is bound by the owner -> barrier -> consumer latency chain.)
+//   = y^2 / (1 + |c0| y) with y = 1/|beta| from ONE rsq + Newton.
+//
+// Cost model (measured, tools/exp/clock_probe.hip): a wave issues at most one instruction every 4
+// clocks, so a step costs (instructions on the owner's path + instructions on a consumer's path) x 4
+// clocks plus two LDS round trips -- neither FMA throughput nor LDS bandwidth.  Hence:
+//   * the owner publishes its raw column BEFORE the scalar chain, then patches the part-0 segment
+//     (zeros above the pivot, v_pivot at it) so that no consumer has to;
+//   * the eliminated entries are never zeroed in registers: rows below the pivot of a finished
+//     column are dead, the write-back masks the few that are not;
+//   * the division by t = 1 + |c0| y is left to the consumers, overlapped with their LDS reads.
+// (Several columns per lane -- fewer LDS reads, independent FMA chains -- is slower at every width
+//  tried: it lengthens exactly these per-wave instruction streams.)
 template <int KK, int NP, int RPL>
 __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool live, int part, double *ubuf, double *sc) {
   constexpr int RPLP = RPL + 2;
@@ -541,18 +637,21 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
         y2 = y * y;
         tden = fma(fabs(c0v), y, 1.0);
       }
+      // entries 0..KK of the reflector: rows above the pivot do not take part, the pivot entry is vp
+#pragma unroll
+      for (int q = 0; q <= KK / 2; ++q) {
+        xk_d2 pp;
+        pp[0] = (2 * q < KK) ? 0.0 : vp;                                        // 2q == KK otherwise
+        pp[1] = (2 * q + 1 < KK) ? 0.0 : (2 * q + 1 == KK) ? vp : b[2 * q + 1];
+        useg[q] = pp;
+      }
       xk_d2 s01 = {y2, tden};
       *reinterpret_cast<xk_d2 *>(scp) = s01;
-      scp[2] = vp;
       b[KK] = beta;
     }
-#pragma unroll
-    for (int r = 0; r < RPL; ++r)
-      if ((part != 0) || (r > KK)) b[r] = 0.0;
   }
   __syncthreads();
   const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-  const double vp = scp[2];
   xk_d2 u[RPL / 2];
 #pragma unroll
   for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
@@ -560,13 +659,6 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
     double rt = __builtin_amdgcn_rcp(s01[1]);
     rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
     rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-    if (part == 0) {   // rows above the pivot are not part of the reflector; the pivot entry is vp
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (r < KK) u[r >> 1][r & 1] = 0.0;
-        else if (r == KK) u[r >> 1][r & 1] = vp;
-      }
-    }
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) {
@@ -625,8 +717,12 @@ __global__ __launch_bounds__(768) void xk_caqr_tile(XkCaqrArgs a) {
   if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[2] = wall_clock64() - w1; a.dbg[3] = nsteps; }
 #endif
   if (!mine) return;
+  // panel columns: the strip (rows 0..15, part 0) is the next level's input -- upper triangle of the panel
+  // block, zeros below it; their rows 16..63 are dead (no later panel reads a finished column)
+  const bool pcol = cidx < nsteps;
+  if (pcol && part != 0) return;
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) rowp[(size_t)r * a.C1P] = b[r];
+  for (int r = 0; r < RPL; ++r) rowp[(size_t)r * a.C1P] = (pcol && r > cidx) ? 0.0 : b[r];
 }
 
 // (2) A-way strip merge, A = RPL strips (16 lanes per column, RPL = 20 or 40 rows per lane).
@@ -693,8 +789,9 @@ __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
     if (part == 0 && blockIdx.y == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (a.final_level) { if (a.c0 + r < a.C1) a.Rout[(size_t)(a.c0 + r) * a.C1P + col] = b[r]; }
-        else a.pout[((size_t)blockIdx.x * 16 + r) * 16 + cidx] = b[r];
+        const double v = (r > cidx) ? 0.0 : b[r];   // eliminated entries are not zeroed in registers
+        if (a.final_level) { if (a.c0 + r < a.C1) a.Rout[(size_t)(a.c0 + r) * a.C1P + col] = v; }
+        else a.pout[((size_t)blockIdx.x * 16 + r) * 16 + cidx] = v;
       }
     }
   } else {
