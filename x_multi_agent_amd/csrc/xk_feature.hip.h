@@ -100,8 +100,12 @@ __device__ inline void xk_null4(double a[4][4], double x[4]) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+  // Reciprocals and inverse square roots from the hardware seeds + two Newton steps: the IEEE division /
+  // sqrt expansions were most of a rotation's ~180 instructions, and a wave issues one per 4 clocks.
+  auto rsq = [](double z) { double y = __builtin_amdgcn_rsq(z); y = y * fma(-0.5 * z * y, y, 1.5); return y * fma(-0.5 * z * y, y, 1.5); };
+  auto rcp = [](double z) { double y = __builtin_amdgcn_rcp(z); y = fma(y, fma(-z, y, 1.0), y); return fma(y, fma(-z, y, 1.0), y); };
   for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = 0.0;
+    bool rotated = false;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -113,14 +117,14 @@ __device__ inline void xk_null4(double a[4][4], double x[4]) {
           be += a[i][q] * a[i][q];
           ga += a[i][p] * a[i][q];
         }
-        const double lim = sqrt(al * be);
-        // columns already orthogonal to working precision are left alone: rotating on rounding noise
-        // never converges (a handful of tracks used to burn all 30 sweeps, 4x the phase time)
-        if (fabs(ga) > 1e-300 && fabs(ga) > 4.4e-16 * lim) {
-          off = fmax(off, fabs(ga) / (lim > 0 ? lim : 1.0));
-          const double zeta = (be - al) / (2.0 * ga);
-          const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        // columns already orthogonal to working precision (|ga| <= 1e-15 |a_p||a_q|) are left alone:
+        // rotating on rounding noise never converges (a handful of tracks used to burn all 30 sweeps)
+        if (ga * ga > 1e-30 * (al * be) && fabs(ga) > 1e-300) {
+          rotated = true;
+          const double zeta = (be - al) * rcp(2.0 * ga);
+          const double s1 = fma(zeta, zeta, 1.0);
+          const double t = (zeta >= 0 ? 1.0 : -1.0) * rcp(fabs(zeta) + s1 * rsq(s1));
+          const double c = rsq(fma(t, t, 1.0)), s = c * t;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const double ap = a[i][p], aq = a[i][q];
@@ -132,7 +136,7 @@ __device__ inline void xk_null4(double a[4][4], double x[4]) {
           }
         }
       }
-    if (off < 1e-15) break;
+    if (!rotated) break;
   }
   double bn = 1e300;
   x[0] = x[1] = x[2] = x[3] = 0.0;
@@ -236,10 +240,54 @@ __device__ __forceinline__ void xk_chol_gate(double *Mm, int ldm, int d, int tid
 #undef XK_S
 }
 
+// The same gate for d <= 63 on ONE wave: lane t keeps row t of [S; r] in registers (static indexing, fully
+// unrolled), column k travels through LDS as a wave-wide broadcast.  A wave issues one instruction per 4
+// clocks whatever it does, so what counts is the instruction count of a step: ~16 wide LDS reads + ~32 FMAs
+// here against ~150 LDS operations per wave for the 2-D version above (8 us instead of 37 us at d = 57).
+__device__ __forceinline__ void xk_chol_gate_wave(const double *Mm, int ldm, int d, int lane, double *scal, double *colbuf /*[2][66]*/) {
+  constexpr int B = 63;   // columns
+  typedef double xk_g2 __attribute__((ext_vector_type(2)));
+  double v[B + 1];
+#pragma unroll
+  for (int j = 0; j < B; ++j) v[j] = (lane <= d && j <= lane && j < d) ? Mm[(size_t)(3 + lane) * ldm + 3 + j] : 0.0;
+  v[B] = 0.0;
+  double g = 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < B; ++k) {
+    if (k < d && !bad) {   // uniform
+      const long long pq = __builtin_bit_cast(long long, v[k]);
+      const int plo = __builtin_amdgcn_readlane((int)(pq & 0xffffffffLL), k), phi = __builtin_amdgcn_readlane((int)(pq >> 32), k);
+      const double piv = __builtin_bit_cast(double, ((long long)phi << 32) | (unsigned int)plo);
+      if (!(piv > 0.0)) { bad = true; }
+      double rp = __builtin_amdgcn_rcp(piv);
+      rp = fma(rp, fma(-piv, rp, 1.0), rp);
+      rp = fma(rp, fma(-piv, rp, 1.0), rp);
+      double *cb = colbuf + (k & 1) * 66;
+      cb[lane] = v[k];                       // S(lane, k): meaningful for lane > k, the only ones read
+      const double m = v[k] * rp;            // S(t,k) / S(k,k)
+      g = fma(v[k] * v[k], rp, g);           // lane d: gamma += S(d,k)^2 / S(k,k)
+      __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      // pairs from the even index at or below k+1 (the extra entry v[k] is dead by now)
+#pragma unroll
+      for (int j = (k + 1) & ~1; j < B + 1; j += 2) {
+        const xk_g2 c = *reinterpret_cast<const xk_g2 *>(cb + j);
+        v[j] = fma(-m, c[0], v[j]);
+        v[j + 1] = fma(-m, c[1], v[j + 1]);
+      }
+#pragma unroll
+      for (int j = k + 1; j < B; ++j) asm volatile("" : "+v"(v[j]));
+    }
+  }
+  if (lane == d) scal[12] = g;
+  if (lane == 0 && bad) scal[10] = 1.0;
+}
+
 // LDS size in bytes for n_poses window poses.
 static inline size_t xk_feature_lds_bytes(int n_poses) {
   const int L = n_poses, m2 = 2 * L, ldm = m2 + 1;
-  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64);
+  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 134);
 }
 
 __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a) {
@@ -644,8 +692,14 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   // matrix (no index arithmetic in the loop).
   for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)m2 * ldm + 3 + j] = res[3 + j];
   __syncthreads();
-  if (d < 64) xk_chol_gate<4>(Mm, ldm, d, tid, scal);
-  else xk_chol_gate<8>(Mm, ldm, d, tid, scal);
+  if (d < 64) {
+    // (the broadcast buffer is read two doubles at a time: 16-byte aligned)
+    double *colbuf = scal + 32 + 12 * Lmax + 64;
+    colbuf += ((size_t)colbuf >> 3) & 1;
+    if (tid < 64) xk_chol_gate_wave(Mm, ldm, d, tid, scal, colbuf);
+  } else {
+    xk_chol_gate<8>(Mm, ldm, d, tid, scal);
+  }
   __syncthreads();
   if (tid == 0) {
     const double g = scal[12];
