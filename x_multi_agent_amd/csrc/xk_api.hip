@@ -147,6 +147,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_gam_s, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_R, (size_t)h->nleaf_max * h->C1P * h->C1P));
+  HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->nleaf_max * h->C1P * h->C1P));
   HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_X, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n));
@@ -367,7 +368,7 @@ static int env_int(const char *name, int dflt) {
 static int launch_caqr(xk_handle *h, hipEvent_t mid) {
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   const int ntiles = h->K + slam_tiles;
-  hipMemsetAsync(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P, h->stream);
+  // (d_R was zeroed at creation; the merges rewrite the whole upper trapezoid every update and nothing else)
   XkCaqrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles;
   a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
@@ -442,7 +443,7 @@ static int launch_tsqr(xk_handle *h, hipEvent_t mid = nullptr) {
 static void gemm(xk_handle *h, const XkGemmArgs &g) {
   const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
   if (tiles <= 0) return;
-  hipLaunchKernelGGL(xk_gemm_f64, dim3((tiles + 3) / 4), dim3(256), 0, h->stream, g);
+  hipLaunchKernelGGL(xk_gemm_f64, dim3(tiles), dim3(64), 0, h->stream, g);
 }
 
 struct UpdateSpec {
@@ -474,7 +475,10 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
   g.B = u.Pin + u.col0; g.sbr = 1; g.sbc = n;
   g.C = h->d_Maug + c; g.scr = LDA; g.scc = 1;
   g.D = g.C; g.sdr = LDA; g.sdc = 1;
-  g.M = c; g.N = n; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 0;
+  g.M = c; g.N = n + 1; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 0;
+  // extra column: z' = res + H corr_tot  (updater.cpp:126) lands next to W in the augmented matrix
+  g.xcol = 1; g.bx = u.ct ? u.ct + u.col0 : nullptr; g.sbx = 1; g.dx = u.z; g.sdx = u.sz;
+  g.cx = h->d_Maug + c + n; g.scx = LDA;
   gemm(h, g);
   if (u.S) {
     XkCopyArgs cp{u.S, h->d_Maug, c, c, u.ssr, u.ssc, (long)LDA, 1};
@@ -489,11 +493,6 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     g.M = c; g.N = c; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 1;
     g.diag = u.rdiag; g.diag_scalar = u.rscalar;
     gemm(h, g);
-  }
-  // z' = res + H corr_tot
-  {
-    XkZArgs z{u.T, u.str, u.stc, c, u.kdim, u.col0, u.z, u.sz, u.ct, h->d_Maug + c + n, (long)LDA};
-    hipLaunchKernelGGL(xk_zprime, dim3((c + 63) / 64), dim3(64), 0, h->stream, z);
   }
   // blocked Cholesky with the right-hand sides carried along: one launch per 32-column block step
   const int ncols = c + n + 1;
@@ -510,13 +509,15 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     g.B = h->d_X + c; g.sbr = LDA; g.sbc = 1;
     g.D = u.Pin; g.sdr = 1; g.sdc = n;
     g.C = u.Pout; g.scr = 1; g.scc = n;
-    g.M = n; g.N = n; g.K = c; g.alpha = -1.0; g.beta = 1.0; g.mode = 2;
+    g.M = n; g.N = n + 1; g.K = c; g.alpha = -1.0; g.beta = 1.0; g.mode = 2;
+    // extra column: corr = X^T (L^-1 z') - corr_tot   (K z' - corr_tot, updater.cpp:126)
+    g.xcol = 1; g.bx = h->d_X + c + n; g.sbx = LDA; g.ex = u.ct; g.cx = h->d_corr; g.scx = 1;
     gemm(h, g);
-  } else if (u.Pout != u.Pin) {
-    hipMemcpyAsync(u.Pout, u.Pin, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream);
+  } else {
+    if (u.Pout != u.Pin) hipMemcpyAsync(u.Pout, u.Pin, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream);
+    XkCorrArgs cr{h->d_X, LDA, c, n, c, c + n, u.ct, h->d_corr};
+    hipLaunchKernelGGL(xk_corr, dim3((n + 63) / 64), dim3(64), 0, h->stream, cr);
   }
-  XkCorrArgs cr{h->d_X, LDA, c, n, c, c + n, u.ct, h->d_corr};
-  hipLaunchKernelGGL(xk_corr, dim3((n + 63) / 64), dim3(64), 0, h->stream, cr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "update launch", e);
   return XK_OK;

@@ -253,8 +253,8 @@ __global__ __launch_bounds__(MAXT) void xk_tsqr_merge(XkQrArgs a) {
 }
 
 // ----------------------------------------------------------------------------
-// Generic strided fp64 GEMM on v_mfma_f64_16x16x4_f64, one wave per 16x16
-// output tile, four waves per workgroup.  n <= ~350 here, so every operand is
+// Generic strided fp64 GEMM on v_mfma_f64_16x16x4_f64, one single-wave workgroup per 16x16
+// output tile.  n <= ~350 here, so every operand is
 // L2-resident; operands are read straight into the MFMA fragment layout
 // (A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15]; C/D: col =
 // lane&15, row = (lane>>4) + 4*reg -- the f64 map, not the f32 one).
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(MAXT) void xk_tsqr_merge(XkQrArgs a) {
 //   mode 0: C = alpha*A*B + beta*D
 //   mode 1: as 0, plus diag[i] (or diag_scalar) added on the diagonal
 //   mode 2: C = 0.5*((D + alpha*AB) + (D + alpha*AB)^T)   (A*B symmetric)
+// xcol: column N-1 is a vector product with its own operands and destination (see XkGemmArgs)
 // ----------------------------------------------------------------------------
 typedef double xk_d4 __attribute__((ext_vector_type(4)));
 
@@ -274,37 +275,49 @@ struct XkGemmArgs {
   int mode;
   const double *diag;
   double diag_scalar;
+  // optional extra column (index N-1) riding along so that a matrix-vector product does not need its own
+  // launch:  cx[i] = sum_k A[i][k] bx[k] + dx[i] - ex[i]   (bx / dx / ex may be null = 0)
+  int xcol;
+  const double *bx, *dx, *ex;
+  long sbx, sdx;
+  double *cx;
+  long scx;
 };
 
-__global__ __launch_bounds__(256) void xk_gemm_f64(XkGemmArgs g) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tiles_n = (g.N + 15) >> 4, tiles_m = (g.M + 15) >> 4;
-  const int t = blockIdx.x * 4 + wave;
-  if (t >= tiles_m * tiles_n) return;
+__global__ __launch_bounds__(64) void xk_gemm_f64(XkGemmArgs g) {
+  const int lane = threadIdx.x;
+  const int tiles_n = (g.N + 15) >> 4;
+  const int t = blockIdx.x;
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
   const int li = lane & 15, lk = lane >> 4;
   const int arow = tm * 16 + li, bcol = tn * 16 + li;
-  const bool aok = arow < g.M, bok = bcol < g.N;
-  const double *ap = g.A + (long)arow * g.sar, *bp = g.B + (long)bcol * g.sbc;
+  const bool xc = g.xcol && bcol == g.N - 1;                    // this lane feeds the extra column
+  const bool aok = arow < g.M, bok = xc ? g.bx != nullptr : bcol < g.N;
+  const double *ap = g.A + (long)arow * g.sar, *bp = xc ? g.bx : g.B + (long)bcol * g.sbc;
+  const long sbr = xc ? g.sbx : g.sbr;
   xk_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int K4 = g.K & ~3;
-  int k0 = 0;
-  for (; k0 + 16 <= K4; k0 += 16) {
-    double av[4], bv[4];
+  // K in chunks of 64 with the NEXT chunk's 32 loads in flight while this one feeds the matrix core: a
+  // tile is one wave with nothing else to hide the ~1 us operand latency behind (these GEMMs are a few
+  // MFLOP each; they are latency, not throughput).
+  constexpr int CH = 16;   // MFMA steps per chunk
+  double av[2][CH], bv[2][CH];
+  auto load = [&](int buf, int k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < CH; ++u) {
       const int k = k0 + 4 * u + lk;
-      av[u] = aok ? ap[(long)k * g.sac] : 0.0;
-      bv[u] = bok ? bp[(long)k * g.sbr] : 0.0;
+      av[buf][u] = (aok && k < g.K) ? ap[(long)k * g.sac] : 0.0;
+      bv[buf][u] = (bok && k < g.K) ? bp[(long)k * sbr] : 0.0;
     }
+  };
+  load(0, 0);
+  for (int k0 = 0; k0 < g.K; k0 += 8 * CH) {
+    if (k0 + 4 * CH < g.K) load(1, k0 + 4 * CH);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
-  }
-  for (; k0 < g.K; k0 += 4) {
-    const int k = k0 + lk;
-    const double av = (aok && k < g.K) ? ap[(long)k * g.sac] : 0.0;
-    const double bv = (bok && k < g.K) ? bp[(long)k * g.sbr] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+    if (k0 + 4 * CH >= g.K) break;
+    if (k0 + 8 * CH < g.K) load(0, k0 + 8 * CH);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
   }
   const int col = tn * 16 + li;
   if (col >= g.N) return;
@@ -312,6 +325,10 @@ __global__ __launch_bounds__(256) void xk_gemm_f64(XkGemmArgs g) {
   for (int r = 0; r < 4; ++r) {
     const int row = tm * 16 + lk + 4 * r;
     if (row >= g.M) continue;
+    if (xc) {
+      g.cx[(long)row * g.scx] = acc[r] + (g.dx ? g.dx[(long)row * g.sdx] : 0.0) - (g.ex ? g.ex[row] : 0.0);
+      continue;
+    }
     double v = g.alpha * acc[r];
     if (g.mode == 2) {
       const double d1 = g.D[(long)row * g.sdr + (long)col * g.sdc];
@@ -514,26 +531,6 @@ __global__ void xk_corr(XkCorrArgs a) {
   }
   for (; k < a.c; ++k) s0 = fma(a.X[(size_t)k * a.ld + a.xoff + i], a.X[(size_t)k * a.ld + a.yoff], s0);
   a.corr[i] = ((s0 + s1) + (s2 + s3)) - (a.ct ? a.ct[i] : 0.0);
-}
-
-// z'[k] = z[k] + sum_j T[k][j] * ct[col0 + j]     (res + H corr_tot, updater.cpp:126)
-struct XkZArgs {
-  const double *T;
-  long str, stc;
-  int c, kdim, col0;
-  const double *z;
-  long sz;
-  const double *ct;  // may be null
-  double *out;
-  long so;
-};
-__global__ void xk_zprime(XkZArgs a) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= a.c) return;
-  double s = a.z[(long)k * a.sz];
-  if (a.ct)
-    for (int j = 0; j < a.kdim; ++j) s += a.T[(long)k * a.str + (long)j * a.stc] * a.ct[a.col0 + j];
-  a.out[(long)k * a.so] = s;
 }
 
 // strided copy / scale helpers
