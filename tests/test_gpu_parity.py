@@ -56,6 +56,14 @@ CASES_VS_ORACLE = {
     "window_not_full": lambda: synth.make_scenario(30, 100, 10, seed=903, n_poses=17),
     "large_prior": lambda: synth.make_scenario(30, 200, 0, seed=904, prior_scale=100.0),
     "max_window_n64": lambda: synth.make_scenario(64, 40, 0, seed=905),
+    # CAQR tree shapes: one tile, exactly one / one-and-a-bit merge groups, the 40-way first level (> 400 tiles),
+    # and a stack where most tiles are rejected (all-zero tiles inside the merge groups)
+    "caqr_1_tile": lambda: synth.make_scenario(8, 1, 0, seed=906, outlier_frac=0.0),
+    "caqr_20_tiles": lambda: synth.make_scenario(8, 20, 0, seed=907),
+    "caqr_21_tiles": lambda: synth.make_scenario(8, 21, 0, seed=908),
+    "caqr_401_tiles": lambda: synth.make_scenario(8, 401, 0, seed=909),
+    "caqr_450_tiles_40way": lambda: synth.make_scenario(10, 450, 0, seed=910),
+    "caqr_mostly_rejected": lambda: synth.make_scenario(12, 120, 0, seed=911, outlier_frac=0.7),
 }
 
 
