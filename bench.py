@@ -6,13 +6,13 @@
 One process per GPU (the driver launches N>1 through torch.distributed.run);
 rank r is agent r with its own synthetic window/tracks/prior (seed
 0x5EED0000 + 1000*config + agent).  A step = one Updater::update()-equivalent
-visual update (per-feature build -> TSQR compression -> Kalman update) on
+visual update (per-feature build -> CAQR compression -> Kalman update) on
 inputs already resident in HBM; P stays on the device.  Every CI_EVERY steps
 the agents exchange their SimpleState payloads (state + full covariance) with
 one RCCL all-gather.  value = (N * K updates) / max-over-ranks wall time.
 
 The JSON line also carries
-  roofline      fp64 compute roofline of the dominant stage (TSQR kernels),
+  roofline      fp64 compute roofline of the dominant stage (CAQR kernels),
                 timed with HIP events on the engine's stream
   cpu_baseline  the C restatement of the reference path (oracle/xk_oracle.c),
                 single thread, timed on this box's host cores (rank 0, N=1)
@@ -191,14 +191,14 @@ def main():
         f_feat, f_qr, f_upd = alg_flops(N, K, M)
         f_alg = f_feat + f_qr + f_upd
         st = tm["stages"]
-        qr_keys = [k for k in st if k.startswith("xk_tsqr") or k.startswith("xk_caqr")]
+        qr_keys = [k for k in st if k.startswith("xk_caqr")]
         qr_ms = sum(st[k]["ms"] for k in qr_keys)
         dom = max(st.items(), key=lambda kv: kv[1]["ms"])
         traffic = None
         pmc = os.path.join(HERE, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("tsqr_bytes_per_update")
+                traffic = json.load(open(pmc)).get("qr_bytes_per_update")
             except Exception:
                 traffic = None
         ach = f_qr / (qr_ms * 1e-3) / 1e12

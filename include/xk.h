@@ -89,7 +89,7 @@ int xk_download_P(xk_handle *h, double *P, int ldp, int n);
 int xk_msckf_build(xk_handle *h, double sigma_img, int *inlier_msckf, double *gamma_msckf,
                    int *inlier_slam, double *gamma_slam);
 
-/* Householder TSQR of the device-resident stacked [H|res]; replaces
+/* Householder QR (communication-avoiding, panel by panel) of the device-resident stacked [H|res]; replaces
  * VioUpdater::applyQRDecomposition (vio_updater.cpp:487-512).  Optional host
  * outputs: T_H (n x n, ldt; upper-trapezoidal, zero core columns) and z (n).
  * T_H^T T_H and T_H^T z equal the reference's up to rounding; the rows
@@ -201,8 +201,8 @@ int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, const doubl
 /* ---- measurement ----------------------------------------------------- */
 
 #define XK_NSTAGE 6
-/* stage order: 0 msckf_feature, 1 slam_rows, 2 tsqr_leaf, 3 tsqr_merge,
- * 4 kalman_gemm (all xk_gemm_f64 launches of the update), 5 kalman_chol_misc */
+/* stage order: 0 msckf_feature, 1 slam_rows, 2 caqr_panel0 (first per-tile panel launch), 3 caqr_rest,
+ * 4 kalman_update, 5 unused */
 typedef struct {
   float total_ms;               /* one staged update, HIP events on the handle's stream */
   float stage_ms[XK_NSTAGE];    /* per update, summed over the stage's launches */

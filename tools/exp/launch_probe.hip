@@ -7,9 +7,9 @@
 #include "../../x_multi_agent_amd/csrc/xk_linalg.hip.h"
 int main() {
   const int C1 = 181, C1P = 192, nt = 400, NL = 24;
-  double *A, *R; int *rows; long long *dbg;
+  double *A, *R, *P0, *P1; int *rows; long long *dbg;
   hipMalloc(&A, sizeof(double) * (size_t)nt * 64 * C1P); hipMalloc(&R, sizeof(double) * C1P * C1P);
-  hipMalloc(&rows, 4 * nt); hipMalloc(&dbg, 64 * NL);
+  hipMalloc(&rows, 4 * nt); hipMalloc(&P0, 8 * 256 * (nt + 2)); hipMalloc(&P1, 8 * 256 * (nt + 2)); hipMemset(P0, 0, 8 * 256 * (nt + 2)); hipMalloc(&dbg, 64 * NL);
   std::vector<double> hA((size_t)nt * 64 * C1P);
   for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((i * 2654435761u) % 1000) / 1000.0 - 0.5;
   std::vector<int> hr(nt, 57);
@@ -19,7 +19,7 @@ int main() {
     const int trail = C1 - c0 - 16;
     for (int rep = 0; rep < 2; ++rep) {
       for (int i = 0; i < NL; ++i) {
-        XkCaqrArgs a{A, rows, nt, C1P, C1, c0, (i & 1) ? 20 : 1, 0, R, 8, nullptr, R, dbg + 8 * i};
+        XkCaqrArgs a{A, rows, nt, 64, C1P, C1, c0, (i & 1) ? 20 : 1, 0, R, 8, P0, P1, dbg + 8 * i};
         hipLaunchKernelGGL(xk_caqr_merge<20>, dim3((i & 1) ? 1 : 20, (trail + 7) / 8), dim3(384), 0, 0, a);
       }
       hipDeviceSynchronize();

@@ -7,9 +7,9 @@
 #include "../../x_multi_agent_amd/csrc/xk_linalg.hip.h"
 int main() {
   const int C1 = 181, C1P = 192, nt = 400;
-  double *A, *R; int *rows; long long *dbg;
+  double *A, *R, *P0, *P1; int *rows; long long *dbg;
   hipMalloc(&A, sizeof(double) * (size_t)nt * 64 * C1P); hipMalloc(&R, sizeof(double) * C1P * C1P);
-  hipMalloc(&rows, 4 * nt); hipMalloc(&dbg, 64);
+  hipMalloc(&rows, 4 * nt); hipMalloc(&P0, 8 * 256 * (nt + 2)); hipMalloc(&P1, 8 * 256 * (nt + 2)); hipMemset(P0, 0, 8 * 256 * (nt + 2)); hipMalloc(&dbg, 64);
   std::vector<double> hA((size_t)nt * 64 * C1P);
   for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((i * 2654435761u) % 1000) / 1000.0 - 0.5;
   std::vector<int> hr(nt, 57);
@@ -22,7 +22,7 @@ int main() {
   for (int c0 : {0, 96, 160}) {
     const int trail = C1 - c0 - 16 > 0 ? C1 - c0 - 16 : 0;
     for (int mode = 0; mode < 3; ++mode) {
-      XkCaqrArgs a{A, rows, nt, C1P, C1, c0, 1, 0, R, 8, nullptr, R, dbg};
+      XkCaqrArgs a{A, rows, nt, 64, C1P, C1, c0, 1, 0, R, 8, P0, P1, dbg};
       float ms; long long d[4];
       const int reps = 200;
       int threads, gx, gy = 1;
@@ -30,7 +30,7 @@ int main() {
       else { gy = (trail + 7) / 8; if (gy < 1) gy = 1; threads = 16 * 24; a.stride = mode == 1 ? 1 : 20; gx = mode == 1 ? 20 : 1; }
       for (int rep = 0; rep < reps + 20; ++rep) {
         if (rep == 20) hipEventRecord(e0);
-        if (mode == 0) hipLaunchKernelGGL(xk_caqr_tile, dim3(gx), dim3(threads), 0, 0, a);
+        if (mode == 0) { a.chalf = trail; hipLaunchKernelGGL((xk_caqr_tile<16, false>), dim3(gx), dim3(threads), 0, 0, a); a.chalf = 8; }
         else hipLaunchKernelGGL(xk_caqr_merge<20>, dim3(gx, gy), dim3(threads), 0, 0, a);
       }
       hipEventRecord(e1); hipEventSynchronize(e1);

@@ -53,12 +53,12 @@ if pmc:
     res = {"note": "FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts 64 B per 128-B "
                    "request for wide coalesced reads (MI355X_MICROARCH.md HBM section) -> fetch_bytes_corrected = 2x.",
            "updates_in_run": updates, "kernels": pmc}
-    tsqr = [k for k in pmc if "tsqr" in k or "caqr" in k]
+    tsqr = [k for k in pmc if "caqr" in k]
     f = sum(pmc[k].get("FETCH_SIZE", {}).get("sum", 0.0) for k in tsqr) * 1024.0
     w = sum(pmc[k].get("WRITE_SIZE", {}).get("sum", 0.0) for k in tsqr) * 1024.0
-    res["tsqr_fetch_bytes_per_update_raw"] = f / updates
-    res["tsqr_write_bytes_per_update"] = w / updates
-    res["tsqr_bytes_per_update"] = (2.0 * f + w) / updates
+    res["qr_fetch_bytes_per_update_raw"] = f / updates
+    res["qr_write_bytes_per_update"] = w / updates
+    res["qr_bytes_per_update"] = (2.0 * f + w) / updates
     json.dump(res, open(os.path.join(PROF, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 for name in ("fp64_peak.json",):
     p = os.path.join(OUT, name)

@@ -23,7 +23,7 @@ struct xk_handle {
   hipStream_t stream;
   hipEvent_t ev[16];
   // capacities
-  int N, Mmax, Kmax, n, na, C1, C1P, DB, NBT, ntiles_max, nleaf_max, qr_threads;
+  int N, Mmax, Kmax, n, na, C1, C1P, DB, ntiles_max;
   // staged problem
   int n_poses, K, M;
   size_t obs_cap;
@@ -33,8 +33,7 @@ struct xk_handle {
   double *d_chi95, *d_chi90;
   double *d_A;
   int *d_tile_rows;
-  double *d_panel[2];   // CAQR: merged 16 x 16 panel blocks of the odd / even merge levels
-  bool caqr;            // compression path: CAQR (C1 <= 192, tiles <= 64 rows) or the binary TSQR tree
+  double *d_panel[2];   // CAQR: 16 x 16 panel blocks of the even (tiles, level 2, ..) / odd merge levels
   int *d_inl, *d_inl_s, *d_gn;
   double *d_gam, *d_gam_s, *d_gpf;
   double *d_R;
@@ -105,17 +104,12 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   h->n = XK_CORE + 6 * n_poses_max + 3 * n_feat_max;
   h->na = h->n - XK_CORE;
   h->C1 = h->na + 1;
-  h->qr_threads = round_up(h->C1, 64);
-  if (h->qr_threads > 512) { free(h); return XK_ECAPACITY; }
-  h->C1P = h->qr_threads;
+  h->C1P = round_up(h->C1, 64);
+  if (h->C1P > 512) { free(h); return XK_ECAPACITY; }
   const int dmax = 2 * n_poses_max - 3;
-  h->NBT = dmax <= 20 ? 20 : dmax <= 40 ? 40 : dmax <= 60 ? 60 : dmax <= 100 ? 100 : 60;
-  h->DB = round_up(dmax, 4);
-  h->caqr = (dmax <= 64 && h->C1 <= 192 && !getenv("XK_FORCE_TSQR"));
-  if (h->caqr) h->DB = 64;   // CAQR works on 64-row tiles in place
+  h->DB = dmax <= 64 ? 64 : 128;   // rows per tile slot (one track per tile; SLAM rows are packed DB per tile)
   const int slam_tiles = (2 * n_feat_max + h->DB - 1) / h->DB;
   h->ntiles_max = k_max + slam_tiles;
-  h->nleaf_max = 256;
   h->CM = round_up(h->n + 1, 16);
   h->LDA = h->CM + round_up(h->n + 1, 16);
   HIPCHK(h, hipSetDevice(device));
@@ -139,15 +133,15 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
   HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
-  for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max / 20 + 2) * 256));
+  for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max + 2) * 256));
   HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_inl_s, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_gn, (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_gam, (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_gam_s, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
-  HIPCHK(h, dalloc(&h->d_R, (size_t)h->nleaf_max * h->C1P * h->C1P));
-  HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->nleaf_max * h->C1P * h->C1P));
+  HIPCHK(h, dalloc(&h->d_R, (size_t)h->C1P * h->C1P));
+  HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
   HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_X, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n));
@@ -308,53 +302,6 @@ static int launch_build(xk_handle *h, double sigma_img) {
   return XK_OK;
 }
 
-template <int NB, int SPLIT, int MAXT, bool RLDS>
-static void launch_tsqr_t(xk_handle *h, XkQrArgs &a, int *levels, hipEvent_t mid) {
-  // packed destination triangle in LDS (RLDS): C1*(C1+1)/2 doubles
-  const size_t lds = RLDS ? sizeof(double) * ((size_t)a.C1 * (a.C1 + 1) / 2 + 2) : 0;
-  const int threads = round_up(SPLIT * a.C1, 64);
-  static bool attr_done = false;
-  if (RLDS && !attr_done) {
-    hipFuncSetAttribute((const void *)xk_tsqr_leaf<NB, SPLIT, MAXT, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    hipFuncSetAttribute((const void *)xk_tsqr_merge<NB, SPLIT, MAXT, RLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_leaf<NB, SPLIT, MAXT, RLDS>), dim3(a.nleaf), dim3(threads), lds, h->stream, a);
-  if (mid) hipEventRecord(mid, h->stream);
-  int lv = 0;
-  for (int s = 1; s < a.nleaf; s *= 2) {
-    a.stride = s;
-    const int grid = (a.nleaf + 2 * s - 1) / (2 * s);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_tsqr_merge<NB, SPLIT, MAXT, RLDS>), dim3(grid), dim3(threads), lds, h->stream, a);
-    ++lv;
-  }
-  *levels = lv;
-}
-
-template <int SPLIT, int MAXT, bool RLDS>
-static void launch_tsqr_nb(xk_handle *h, XkQrArgs &a, int *levels, hipEvent_t mid, int nb) {
-  switch (nb) {
-    case 16: launch_tsqr_t<16, SPLIT, MAXT, RLDS>(h, a, levels, mid); break;
-    case 32: launch_tsqr_t<32, SPLIT, MAXT, RLDS>(h, a, levels, mid); break;
-    default: launch_tsqr_t<64, SPLIT, MAXT, RLDS>(h, a, levels, mid); break;
-  }
-}
-
-static int pick_nleaf(xk_handle *h, int ntiles) {
-  const char *env = getenv("XK_NLEAF");
-  int nl;
-  if (env && atoi(env) > 0) nl = atoi(env);
-  else {
-    nl = 1;
-    while (nl * 2 * 3 <= ntiles && nl * 2 <= h->nleaf_max) nl *= 2;  // >= 3 tiles per leaf
-  }
-  if (nl > h->nleaf_max) nl = h->nleaf_max;
-  if (nl > ntiles) nl = ntiles > 0 ? ntiles : 1;
-  return nl;
-}
-
-// CAQR: panels of 16 columns; per panel one in-place tile factorisation on every tile, then 8-way
-// strip merges (<= 3 levels for <= 512 tiles); the root strip of each panel is 16 rows of R.
 template <int RPL>
 static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_merge<RPL>), dim3(groups, csplit), dim3(16 * (16 + a.chalf)), 0, h->stream, a);
@@ -365,23 +312,37 @@ static int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-static int launch_caqr(xk_handle *h, hipEvent_t mid) {
+// QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
+static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
+  if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   const int ntiles = h->K + slam_tiles;
   // (d_R was zeroed at creation; the merges rewrite the whole upper trapezoid every update and nothing else)
   XkCaqrArgs a;
-  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles;
+  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles; a.TS = h->DB;
   a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
   // first-level arity: 40 strips per workgroup once 20 x 20 no longer covers the stack in two levels
   static const int arity1_env = env_int("XK_CAQR_ARITY1", 0);
   const int arity1 = arity1_env ? arity1_env : (ntiles > 400 ? 40 : 20);
   static const int chalf = env_int("XK_CAQR_CHALF", 8);
+  // per-tile kernel: 4 lanes per column, at most 192 (64-row tiles) / 128 (128-row tiles) columns per workgroup
+  const int tile_cols = (h->DB == 64) ? 192 : 128;
   int launches = 0;
   for (int c0 = 0; c0 < h->C1; c0 += 16) {
     const int trail = std::max(0, h->C1 - c0 - 16);
-    a.c0 = c0; a.stride = 1; a.final_level = 0; a.chalf = trail; a.pin = nullptr; a.pout = nullptr;
-    hipLaunchKernelGGL(xk_caqr_tile, dim3(ntiles), dim3(round_up(4 * (16 + trail), 64)), 0, h->stream, a);
+    a.c0 = c0; a.stride = 1; a.final_level = 0; a.pin = nullptr; a.pout = h->d_panel[0];
+    const int tsplit = std::max(1, (trail + (tile_cols - 16) - 1) / (tile_cols - 16));
+    a.chalf = (trail + tsplit - 1) / tsplit;
+    const dim3 tgrid(ntiles, tsplit), tblock(round_up(4 * (16 + a.chalf), 64));
+    if (h->DB == 64) {
+      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, false>), tgrid, tblock, 0, h->stream, a);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, true>), tgrid, tblock, 0, h->stream, a);
+    } else {
+      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, false>), tgrid, tblock, 0, h->stream, a);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, true>), tgrid, tblock, 0, h->stream, a);
+    }
     if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
+    if (c0 > 0) ++launches;                                        // (the first tile launch is timed as its own stage)
     a.chalf = chalf;
     const int csplit = std::max(1, (trail + a.chalf - 1) / a.chalf);
     int stride = 1, level = 0;
@@ -391,7 +352,7 @@ static int launch_caqr(xk_handle *h, hipEvent_t mid) {
       a.stride = stride;
       a.final_level = (left <= arity) ? 1 : 0;
       const int groups = (left + arity - 1) / arity;
-      a.pin = (stride == 1) ? nullptr : h->d_panel[level & 1];
+      a.pin = h->d_panel[level & 1];
       a.pout = h->d_panel[(level + 1) & 1];
       ++level;
       if (arity == 40) launch_merge<40>(h, a, groups, csplit);
@@ -405,38 +366,6 @@ static int launch_caqr(xk_handle *h, hipEvent_t mid) {
   h->have_R = true;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
-  return XK_OK;
-}
-
-static int launch_tsqr(xk_handle *h, hipEvent_t mid = nullptr) {
-  if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
-  if (h->caqr) return launch_caqr(h, mid);
-  const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
-  XkQrArgs a;
-  a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = h->K + slam_tiles;
-  a.DB = h->DB; a.C1P = h->C1P; a.C1 = h->C1; a.R = h->d_R; a.stride = 1;
-  a.nleaf = pick_nleaf(h, a.ntiles);
-  int lv = 0;
-  // Row block per pass: the smallest of {16, 32, 64} covering the tallest tile; taller tiles
-  // (window > 33 poses) take several passes.  Lanes per column: 4 while 4*C1 threads fit a
-  // workgroup of 768 (C1 <= 192), else 2 (C1 <= 352 at 704 threads, C1 <= 512 at 1024).
-  const int dmax = 2 * h->N - 3;
-  const int nb = dmax <= 16 ? 16 : dmax <= 32 ? 32 : 64;
-  // the packed triangle plus the broadcast buffers must fit the 160 KB LDS of a CU
-  const bool rlds = sizeof(double) * ((size_t)a.C1 * (a.C1 + 1) / 2 + 512) <= 156 * 1024 && !getenv("XK_NO_RLDS");
-  if (a.C1 <= 192) {
-    if (rlds) launch_tsqr_nb<4, 768, true>(h, a, &lv, mid, nb);
-    else launch_tsqr_nb<4, 768, false>(h, a, &lv, mid, nb);
-  } else if (a.C1 <= 352) {
-    launch_tsqr_nb<2, 704, false>(h, a, &lv, mid, nb);
-  } else {
-    launch_tsqr_nb<2, 1024, false>(h, a, &lv, mid, nb > 32 ? 32 : nb);
-  }
-  h->nleaf = a.nleaf;
-  h->nlevels = lv;
-  h->have_R = true;
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(h, XK_EDEVICE, "tsqr launch", e);
   return XK_OK;
 }
 
@@ -571,7 +500,7 @@ extern "C" int xk_msckf_build(xk_handle *h, double sigma_img, int *inlier_msckf,
 extern "C" int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z) {
   if (!h) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  int rc = launch_tsqr(h);
+  int rc = launch_compress(h);
   if (rc != XK_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (T_H || z) {
@@ -623,7 +552,7 @@ extern "C" int xk_visual_update_staged(xk_handle *h, double sigma_img, double *c
   }
   int rc = launch_build(h, sigma_img);
   if (rc != XK_OK) return rc;
-  rc = launch_tsqr(h);
+  rc = launch_compress(h);
   if (rc != XK_OK) return rc;
   UpdateSpec u = compressed_spec(h, nullptr, 1);
   rc = launch_update(h, u);
@@ -729,8 +658,8 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
   if (!h || !out || steps <= 0 || warmup < 0) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   memset(out, 0, sizeof(*out));
-  const char *names[XK_NSTAGE] = {"xk_msckf_feature", "xk_slam_rows", h->caqr ? "xk_caqr_panel0" : "xk_tsqr_leaf",
-                                  h->caqr ? "xk_caqr_rest" : "xk_tsqr_merge",
+  const char *names[XK_NSTAGE] = {"xk_msckf_feature", "xk_slam_rows", "xk_caqr_panel0",
+                                  "xk_caqr_rest",
                                   "xk_kalman_update", "(unused)"};
   for (int s = 0; s < XK_NSTAGE; ++s) snprintf(out->stage_name[s], sizeof(out->stage_name[s]), "%s", names[s]);
   double acc[XK_NSTAGE] = {0, 0, 0, 0, 0, 0}, tot = 0;
@@ -739,7 +668,7 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
     int rc = launch_build(h, sigma_img);
     if (rc != XK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    rc = launch_tsqr(h, h->ev[2]);
+    rc = launch_compress(h, h->ev[2]);
     if (rc != XK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
     UpdateSpec u = compressed_spec(h, nullptr, 1);
@@ -1125,7 +1054,7 @@ extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
   for (int it = 0; it < steps; ++it) {
     int rc = launch_build(h, sigma_img);
     if (rc != XK_OK) return rc;
-    rc = launch_tsqr(h);
+    rc = launch_compress(h);
     if (rc != XK_OK) return rc;
     UpdateSpec u = compressed_spec(h, nullptr, 1);
     rc = launch_update(h, u);

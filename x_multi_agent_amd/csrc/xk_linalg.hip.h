@@ -1,70 +1,17 @@
-// xk_linalg.hip.h -- Householder TSQR, fp64-MFMA GEMM and blocked Cholesky
+// xk_linalg.hip.h -- Householder CAQR, fp64-MFMA GEMM and blocked Cholesky
 // kernels for the EKF update (gfx950).
 //
-//   TSQR            replaces VioUpdater::applyQRDecomposition
+//   CAQR            replaces VioUpdater::applyQRDecomposition
 //                   (src/x/vio/vio_updater.cpp:487-512)
 //   GEMM / Cholesky replace the Eigen products and S.inverse() of
 //                   Updater::applyUpdate / applyCI (src/x/ekf/updater.cpp:117-161)
 #pragma once
 #include <hip/hip_runtime.h>
 
-// ----------------------------------------------------------------------------
-// TSQR: structured Householder update  R <- qr([R; B])
-//
-// One thread owns one column.  A row block B (up to NB rows) lives in the
-// owning thread's registers; R lives in global memory (L2-resident), row k is
-// touched exactly once per pass, at step k, with a coalesced read/write.  At
-// step k the owner of column k publishes its column and the reflector scalars
-// through LDS; every thread to its right applies the reflector to its own
-// column.  The reflector of step k only involves R[k][k] and B[:,k]
-// (rows of R below k are zero), i.e. v = [1; scale * B[:,k]].
-// ----------------------------------------------------------------------------
-// Access to the destination triangle R during a pass.
-//   XkRLds : R packed (row k holds columns k..C1-1) in LDS -- 132 KB at C1 = 181;
-//            loaded/stored to global once per kernel, every step's row access is an
-//            LDS access.
-//   XkRGlb : R in global memory (row-major, ld = C1P) with a 3-step register
-//            prefetch ring, for systems whose triangle does not fit the 160 KB LDS.
-struct XkRLds {
-  double *base;
-  int C1;
-  __device__ __forceinline__ int off(int k) const { return k * C1 - (k * (k - 1)) / 2 - k; }  // + j
-  __device__ __forceinline__ double ld(int k, int j) const { return base[off(k) + j]; }
-  __device__ __forceinline__ void st(int k, int j, double v) const { base[off(k) + j] = v; }
-};
-struct XkRGlb {
-  double *base;
-  int ldr;
-  __device__ __forceinline__ double ld(int k, int j) const { return base[(size_t)k * ldr + j]; }
-  __device__ __forceinline__ void st(int k, int j, double v) const { base[(size_t)k * ldr + j] = v; }
-};
-
 typedef double xk_d2 __attribute__((ext_vector_type(2)));
 
-// 1/x and sqrt(x) from the hardware seeds plus Newton steps (~1 ulp).  The IEEE-exact
-// division/sqrt sequences are long dependent chains and sit on the critical path of every
-// Householder step; the reflector only needs tau and v consistent to rounding.
-__device__ __forceinline__ double xk_rcp(double x) {
-  double y = __builtin_amdgcn_rcp(x);
-  y = fma(y, fma(-x, y, 1.0), y);
-  y = fma(y, fma(-x, y, 1.0), y);
-  return y;
-}
-__device__ __forceinline__ double xk_sqrt(double a) {
-  double y = __builtin_amdgcn_rsq(a);          // ~1/sqrt(a)
-  double h = 0.5 * y;
-  double g = a * y;                            // ~sqrt(a)
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  return fma(fma(-g, g, a), h, g);             // final residual correction
-}
-
-// Sum over the SPLIT (2 or 4) adjacent lanes that share a column, with quad-permute DPP moves
-// (no LDS round trip, unlike ds_bpermute-based shuffles).
+// Sum over the SPLIT (2, 4, 8 or 16) adjacent lanes that share a column, with DPP moves (no LDS round
+// trip, unlike ds_bpermute-based shuffles).
 template <int CTRL>
 __device__ __forceinline__ double xk_dpp_quad(double x) {
   const long long q = __builtin_bit_cast(long long, x);
@@ -79,177 +26,6 @@ __device__ __forceinline__ double xk_group_sum(double x) {
   if (SPLIT >= 8) x += xk_dpp_quad<0x141>(x); // row_half_mirror: the other quad of the 8-lane group
   if (SPLIT == 16) x += xk_dpp_quad<0x140>(x); // row_mirror: the other half of the 16-lane row
   return x;
-}
-
-// One pass of the structured Householder update R <- qr([R; B]).
-//   SPLIT lanes share a column: lane (col, part) holds rows [part*RPL, (part+1)*RPL) of that
-//   column in registers (RPL = NB / SPLIT); partial dot products are combined with an xor
-//   butterfly inside the lane group.  With SPLIT = 4 a 181-column system runs 12 waves per CU
-//   (3 per SIMD), so the dependent fp64 latencies of one wave hide behind the others.
-template <int NB, int SPLIT, typename RA>
-__device__ __forceinline__ void xk_qr_pass(double (&b)[NB / SPLIT], const RA &R, int C1, int kstart, bool first,
-                                           double *vbuf, double *sc /*[2][2]*/) {
-  constexpr int RPL = NB / SPLIT;      // rows per lane
-  constexpr int RPLP = RPL + 2;        // LDS stride of one part (bank spread)
-  static_assert(RPL % 2 == 0, "rows per lane must be even (16-byte LDS accesses)");
-  const int col = threadIdx.x / SPLIT, part = threadIdx.x % SPLIT;
-  const bool mine = col < C1;
-  double r0 = 0.0, r1 = 0.0, r2 = 0.0;  // prefetch ring: rows kstart..kstart+2
-  if (!first && mine) {
-    if (col >= kstart && kstart < C1) r0 = R.ld(kstart, col);
-    if (col >= kstart + 1 && kstart + 1 < C1) r1 = R.ld(kstart + 1, col);
-    if (col >= kstart + 2 && kstart + 2 < C1) r2 = R.ld(kstart + 2, col);
-  }
-  for (int k = kstart; k < C1; ++k) {
-    const int pb = k & 1;
-    const double rkj = r0;
-    r0 = r1;
-    r1 = r2;
-    r2 = (!first && mine && k + 3 < C1 && col >= k + 3) ? R.ld(k + 3, col) : 0.0;
-    xk_d2 *vseg = reinterpret_cast<xk_d2 *>(vbuf + (pb * SPLIT + part) * RPLP);
-    if (col == k) {
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-      for (int r = 0; r < RPL; r += 2) {
-        if (r & 2) { s2 = fma(b[r], b[r], s2); s3 = fma(b[r + 1], b[r + 1], s3); }
-        else { s0 = fma(b[r], b[r], s0); s1 = fma(b[r + 1], b[r + 1], s1); }
-        xk_d2 t = {b[r], b[r + 1]};
-        vseg[r >> 1] = t;
-      }
-      const double s = xk_group_sum<SPLIT>((s0 + s1) + (s2 + s3));
-      if (part == 0) {
-        double tau, scale, beta;
-        if (s <= 2.2250738585072014e-308) {
-          tau = 0.0; scale = 0.0; beta = rkj;
-        } else {
-#ifdef XK_EXP_NO_SQRT
-          beta = -(fabs(rkj) + s); tau = 1.5; scale = 0.25;
-#else
-          beta = xk_sqrt(fma(rkj, rkj, s));
-          if (rkj >= 0) beta = -beta;
-          tau = (beta - rkj) * xk_rcp(beta);
-          scale = xk_rcp(rkj - beta);
-#endif
-        }
-        sc[pb * 2] = tau;
-        sc[pb * 2 + 1] = scale;
-        if (first || tau != 0.0) R.st(k, k, beta);
-      }
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) b[r] = 0.0;
-    }
-#ifndef XK_EXP_NO_BARRIER
-    __syncthreads();
-#endif
-    const double tau = sc[pb * 2];
-    const double scale = sc[pb * 2 + 1];
-    xk_d2 v[RPL / 2];  // read unconditionally: overlaps the LDS latency with the scalars' read
-#pragma unroll
-    for (int r = 0; r < RPL / 2; ++r) v[r] = vseg[r];
-    if (col > k && mine) {
-      if (tau != 0.0) {
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) {
-          if (r & 1) { d2 = fma(v[r][0], b[2 * r], d2); d3 = fma(v[r][1], b[2 * r + 1], d3); }
-          else { d0 = fma(v[r][0], b[2 * r], d0); d1 = fma(v[r][1], b[2 * r + 1], d1); }
-        }
-        const double d = xk_group_sum<SPLIT>((d0 + d1) + (d2 + d3));
-        const double w = tau * fma(scale, d, rkj);
-        if (part == 0) R.st(k, col, rkj - w);
-        const double ws = -w * scale;
-#pragma unroll
-        for (int r = 0; r < RPL / 2; ++r) {
-          b[2 * r] = fma(ws, v[r][0], b[2 * r]);
-          b[2 * r + 1] = fma(ws, v[r][1], b[2 * r + 1]);
-        }
-      } else if (first && part == 0) {
-        R.st(k, col, 0.0);
-      }
-    }
-  }
-  __syncthreads();
-}
-
-struct XkQrArgs {
-  const double *A;       // tiles [ntiles][DB][C1P] row-major
-  const int *tile_rows;  // valid rows per tile, 0 = skip
-  int ntiles, DB, C1P, C1;
-  double *R;  // [nleaf][C1P][C1P] row-major upper-triangular factors
-  int nleaf;
-  int stride;  // merge: R[g*2*stride] <- qr([R[g*2*stride]; R[g*2*stride+stride]])
-};
-
-extern __shared__ __attribute__((aligned(16))) double xk_dyn_lds[];
-
-#define XK_QR_VBUF(NB, SPLIT) (2 * (SPLIT) * ((NB) / (SPLIT) + 2))
-
-// Leaf: workgroup g folds tiles g, g+nleaf, g+2*nleaf, ... into R[g].
-template <int NB, int SPLIT, int MAXT, bool RLDS>
-__global__ __launch_bounds__(MAXT) void xk_tsqr_leaf(XkQrArgs a) {
-  constexpr int RPL = NB / SPLIT;
-  __shared__ __attribute__((aligned(16))) double vbuf[XK_QR_VBUF(NB, SPLIT)];
-  __shared__ double sc[4];
-  const int g = blockIdx.x, col = threadIdx.x / SPLIT, part = threadIdx.x % SPLIT;
-  double *Rg = a.R + (size_t)g * a.C1P * a.C1P;
-  bool first = true;
-  double b[RPL];
-  XkRLds rl{xk_dyn_lds, a.C1};
-  XkRGlb rg{Rg, a.C1P};
-  for (int t = g; t < a.ntiles; t += a.nleaf) {
-    const int rows = a.tile_rows[t];
-    if (rows == 0) continue;
-    const double *tile = a.A + (size_t)t * a.DB * a.C1P;
-    for (int r0 = 0; r0 < rows; r0 += NB) {
-#pragma unroll
-      for (int r = 0; r < RPL; ++r) {
-        const int row = r0 + part * RPL + r;
-        b[r] = (row < rows && col < a.C1) ? tile[(size_t)row * a.C1P + col] : 0.0;
-      }
-      if (RLDS) xk_qr_pass<NB, SPLIT>(b, rl, a.C1, 0, first, vbuf, sc);
-      else xk_qr_pass<NB, SPLIT>(b, rg, a.C1, 0, first, vbuf, sc);
-      first = false;
-    }
-  }
-  if (part != 0 || col >= a.C1) return;
-  if (first) {  // no data at all: define R = 0 so the merges stay well formed
-    for (int k = 0; k <= col; ++k) Rg[(size_t)k * a.C1P + col] = 0.0;
-  } else if (RLDS) {
-    for (int k = 0; k <= col; ++k) Rg[(size_t)k * a.C1P + col] = rl.ld(k, col);
-  }
-}
-
-// Merge: the source triangle is fed as row blocks; rows [r0, r0+NB) have
-// leading zeros up to column r0, so the pass starts at step r0.
-template <int NB, int SPLIT, int MAXT, bool RLDS>
-__global__ __launch_bounds__(MAXT) void xk_tsqr_merge(XkQrArgs a) {
-  constexpr int RPL = NB / SPLIT;
-  __shared__ __attribute__((aligned(16))) double vbuf[XK_QR_VBUF(NB, SPLIT)];
-  __shared__ double sc[4];
-  const int g = blockIdx.x, col = threadIdx.x / SPLIT, part = threadIdx.x % SPLIT;
-  const int dst = g * 2 * a.stride, src = dst + a.stride;
-  if (src >= a.nleaf) return;
-  double *Rd = a.R + (size_t)dst * a.C1P * a.C1P;
-  const double *Rs = a.R + (size_t)src * a.C1P * a.C1P;
-  double b[RPL];
-  XkRLds rl{xk_dyn_lds, a.C1};
-  XkRGlb rg{Rd, a.C1P};
-  if (RLDS) {
-    if (part == 0 && col < a.C1)
-      for (int k = 0; k <= col; ++k) rl.st(k, col, Rd[(size_t)k * a.C1P + col]);
-    __syncthreads();
-  }
-  for (int r0 = 0; r0 < a.C1; r0 += NB) {
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-      const int row = r0 + part * RPL + r;
-      b[r] = (row < a.C1 && col >= row && col < a.C1) ? Rs[(size_t)row * a.C1P + col] : 0.0;
-    }
-    if (RLDS) xk_qr_pass<NB, SPLIT>(b, rl, a.C1, r0, false, vbuf, sc);
-    else xk_qr_pass<NB, SPLIT>(b, rg, a.C1, r0, false, vbuf, sc);
-  }
-  if (RLDS && part == 0 && col < a.C1)
-    for (int k = 0; k <= col; ++k) Rd[(size_t)k * a.C1P + col] = rl.ld(k, col);
 }
 
 // ----------------------------------------------------------------------------
@@ -548,39 +324,46 @@ __global__ void xk_copy2d(XkCopyArgs a) {
 }
 
 // ----------------------------------------------------------------------------
-// Communication-avoiding QR (CAQR) of the tile stack: the compression path for systems with
-// C1 <= 192 columns and tiles of at most 64 rows.
+// Communication-avoiding QR (CAQR) of the tile stack  [H | res]  ->  R  (Householder only).
 //
-// The binary TSQR tree above serialises ~9 merges of ~350 Householder steps each on ONE
-// workgroup.  CAQR walks the columns in panels of 16 instead; per panel
-//   (1) xk_caqr_tile: every tile factors its own 64 x 16 panel IN PLACE (pivot rows = its rows
-//       0..15) and applies the 16 reflectors to its trailing columns          -- grid = #tiles
+// The columns are walked in panels of 16; per panel
+//   (1) xk_caqr_tile: every tile (64 or 128 rows) factors its own panel IN PLACE (pivot rows = its
+//       rows 0..15) and applies the 16 reflectors to its trailing columns   -- grid = #tiles x column splits
 //   (2) xk_caqr_merge: the 16-row strips [R_loc | C_loc] (rows 0..15 of each tile) are merged A at
 //       a time by the same in-place QR on the stacked 16A x 16 panel; A = 20 or 40, so 400 tiles
-//       need two levels                                                       -- grid = groups x column splits
-//   (3) the root strip is the next 16 rows of the global R; it is moved out and zeroed.
-// The dependent chain is 12 panels x 3 launches of 16 steps, and step (1) runs on every CU.
+//       need two levels                                                     -- grid = groups x column splits
+//   (3) the root strip of the last level is the next 16 rows of the global R.
+// The dependent chain is (C1/16) panels x 3 launches of 16 steps, and step (1) runs on every CU.
+// (A binary TSQR tree of whole triangles -- the first version of this stage -- serialises ~9 merges
+// of ~350 steps each on ONE workgroup: 2.5 ms where this takes 0.7 ms.)
 //
-// Tiles are addressed by position (tile t = rows [64 t, 64 t + 64) of A): no compaction list, so a
+// Column splits: a workgroup holds the 16 panel columns plus `chalf` trailing columns; the trailing
+// range is spread over gridDim.y workgroups, each of which factors the panel redundantly (the step
+// chain is sequential whoever runs it).  Splits run unsynchronised, so nobody overwrites what a
+// sibling still has to read: a split writes only its own trailing columns in place, and the
+// 16 x 16 panel block of a tile / merge group goes to a per-level scratch (`pout`) that the next
+// level reads as `pin` (the last level writes R).  The panel columns left in the tiles are dead.
+//
+// Tiles are addressed by position (tile t = rows [TS t, TS t + TS) of A): no compaction list, so a
 // workgroup's first loads are the data themselves -- a launch is short enough (~15 us) that every
 // dependent round trip to HBM/MALL (~1 us each) shows.  Tiles of rejected tracks are all-zero rows.
 //
-// Lane layout as in xk_qr_pass: NP lanes per column, lane `part` holds RPL consecutive rows of the
-// stacked block in registers.  The pivot row of step kk is register kk of the part-0 lane; the 16
-// steps are fully unrolled so that index is static.  The broadcast vector u has u[<kk] = 0 and
-// u[kk] = v_pivot for the part-0 lane, so the update code is identical for every lane.
+// Lane layout: NP lanes per column, lane `part` holds RPL rows of the stacked block in registers.
+// The pivot row of step kk is register kk of the part-0 lane; the 16 steps are fully unrolled so
+// that index is static.  The broadcast vector u has u[<kk] = 0 and u[kk] = v_pivot for the part-0
+// lane, so the update code is identical for every lane.
 // ----------------------------------------------------------------------------
 struct XkCaqrArgs {
-  double *A;              // tiles [ntiles][64][C1P] row-major (in place)
+  double *A;              // tiles [ntiles][tile_rows_max][C1P] row-major (in place)
   const int *tile_rows;   // valid rows per tile before panel 0 (0 = rejected track)
-  int ntiles;
+  int ntiles, TS;         // TS = rows per tile slot (64 or 128)
   int C1P, C1, c0;        // panel = columns [c0, min(c0+16, C1))
   int stride;             // merge: group g merges tiles g*A*stride + u*stride, u = 0..A-1
-  int final_level;        // merge: root strip -> Rout, then zeroed
+  int final_level;        // merge: root strip -> Rout
   double *Rout;           // [C1P][C1P] row-major
-  int chalf;              // merge: trailing columns split over gridDim.y workgroups of `chalf` columns each
-  const double *pin;      // merge: 16 x 16 panel blocks of the previous level [group][16][16] (null: read the tiles)
-  double *pout;           // merge: panel block of this group for the next level
+  int chalf;              // trailing columns per workgroup (gridDim.y workgroups cover the range)
+  const double *pin;      // merge: 16 x 16 panel blocks of the level below [block][16][16]
+  double *pout;           // panel block of this tile / merge group for the level above
   long long *dbg;         // optional: clock stamps of workgroup 0 (probe builds only)
 };
 
@@ -679,17 +462,20 @@ __device__ __forceinline__ void xk_caqr_steps(double (&b)[RPL], int rel, bool li
 #undef XK_STEP
 }
 
-// (1) per-tile panel step: 4 lanes per column, 16 rows per lane, all live columns in one workgroup
-// (the kernel must stay at <= 80 VGPRs so that two 12-wave workgroups share a CU).
-__global__ __launch_bounds__(768) void xk_caqr_tile(XkCaqrArgs a) {
-  constexpr int NP = 4, RPL = 16, RPLP = RPL + 2;
+// (1) per-tile panel step: 4 lanes per column, RPL = 16 (64-row tiles) or 32 (128-row tiles) rows per lane.
+// (RPL = 16 must stay at <= 80 VGPRs so that two 12-wave workgroups share a CU.)
+// CSPLIT: the trailing columns are spread over gridDim.y workgroups (systems wider than one workgroup).
+template <int RPL, bool CSPLIT>
+__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_tile(XkCaqrArgs a) {
+  constexpr int NP = 4, RPLP = RPL + 2;
   __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
   const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
-  const int col = a.c0 + cidx;
-  const bool mine = col < a.C1;
+  const bool panel = cidx < 16;
+  const int col = (!CSPLIT || panel) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
+  const bool mine = col < a.C1 && (!CSPLIT || panel || cidx - 16 < a.chalf);
   const int t = blockIdx.x;
-  double *rowp = a.A + ((size_t)t * 64 + part * RPL) * a.C1P + col;
+  double *rowp = a.A + ((size_t)t * a.TS + part * RPL) * a.C1P + col;
   double b[RPL];
 #ifdef XK_CAQR_PROBE
   const long long t0 = clock64();
@@ -711,24 +497,23 @@ __global__ __launch_bounds__(768) void xk_caqr_tile(XkCaqrArgs a) {
   xk_caqr_steps<NP, RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
 #ifdef XK_CAQR_PROBE
   const long long t2 = clock64();
-  if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[2] = wall_clock64() - w1; a.dbg[3] = nsteps; }
+  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[2] = wall_clock64() - w1; a.dbg[3] = nsteps; }
 #endif
   if (!mine) return;
-  // panel columns: the strip (rows 0..15, part 0) is the next level's input -- upper triangle of the panel
-  // block, zeros below it; their rows 16..63 are dead (no later panel reads a finished column)
-  const bool pcol = cidx < nsteps;
-  if (pcol && part != 0) return;
+  if (panel) {
+    // the strip's panel block (upper triangle, zeros below: eliminated entries are not zeroed in registers)
+    // is the next level's input; rows 16.. of a finished column are dead
+    if (part == 0 && (!CSPLIT || blockIdx.y == 0)) {
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) rowp[(size_t)r * a.C1P] = (pcol && r > cidx) ? 0.0 : b[r];
+      for (int r = 0; r < 16; ++r) a.pout[((size_t)t * 16 + r) * 16 + cidx] = (r > cidx) ? 0.0 : b[r];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) rowp[(size_t)r * a.C1P] = b[r];
+  }
 }
 
 // (2) A-way strip merge, A = RPL strips (16 lanes per column, RPL = 20 or 40 rows per lane).
-// The trailing columns are split over gridDim.y workgroups of `chalf` columns; every split factors
-// the 16 panel columns redundantly (the step chain is sequential anyway).  Because the splits of a
-// group run unsynchronised, nobody may overwrite what another split still has to read: a split
-// writes only its own trailing columns in place, and the merged 16 x 16 panel block goes to a
-// per-level scratch (`pout`, read back as `pin` by the next level; the last level writes R).  The
-// panel columns left behind in the tiles are dead -- no later panel reads them.
 template <int RPL>
 __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArgs a) {
   constexpr int NP = 16, RPLP = RPL + 2, ARITY = NP * RPL / 16;
@@ -745,11 +530,11 @@ __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
   const int base = blockIdx.x * ARITY * a.stride;
   // Row groups of this lane: FG whole strips (strip g*16 + part -> registers 16g..16g+15) and TR rows of
   // one of the TR tail strips (16/TR lanes share a tail strip).  A group is addressed by one base pointer
-  // and a uniform row stride: the tiles, or the previous level's 16 x 16 panel blocks for panel columns.
+  // and a uniform row stride: the tiles for trailing columns, the 16 x 16 panel blocks of the level below
+  // for panel columns.
   constexpr int FG = RPL / 16, TR = RPL - 16 * FG, NG = FG + 1, PER = 16 / TR;
   static_assert(TR > 0 && 16 % TR == 0, "lane layout");
-  const bool from_pin = panel && a.pin;
-  const size_t rs = from_pin ? 16 : (size_t)a.C1P;
+  const size_t rs = panel ? 16 : (size_t)a.C1P;
   double *gp[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -757,8 +542,8 @@ __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
     const int r0 = (g < FG) ? 0 : TR * (part % PER);
     const int pos = base + s * a.stride;
     gp[g] = (pos >= a.ntiles) ? nullptr
-            : from_pin ? const_cast<double *>(a.pin) + ((size_t)(blockIdx.x * ARITY + s) * 16 + r0) * 16 + cidx
-                       : a.A + ((size_t)pos * 64 + r0) * a.C1P + col;
+            : panel ? const_cast<double *>(a.pin) + ((size_t)(blockIdx.x * ARITY + s) * 16 + r0) * 16 + cidx
+                    : a.A + ((size_t)pos * a.TS + r0) * a.C1P + col;
   }
   double b[RPL];
 #pragma unroll
