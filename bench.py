@@ -142,21 +142,16 @@ def main():
     ci_stats = {"rounds": 0, "fused": 0}
 
     def exchange(step):
-        """CI round: all-gather the snapshots over RCCL, then fuse the shared tracks against them."""
+        """CI round: all-gather the snapshots over RCCL, then fuse the shared tracks against them on the device."""
         if world == 1:
             return
         eng.pack_payload_into(rank, float(step), dyn16, pay_dev.data_ptr())   # packed on the device ...
         ex.send.copy_(pay_dev)                                                # ... into the RCCL send buffer
-        allp = ex.all_gather().cpu().numpy()
-        allt = tex.all_gather().cpu().numpy()
-        others = []
-        for r in range(world):
-            if r == rank:
-                continue
-            u = fleet.unpack_payload(allp[r], N, M)
-            u["tracks"] = fleet.unpack_tracks(allt[r], N)
-            others.append(u)
-        fused, _ = fleet.ci_round(eng, sc, others, CI_TRACKS, CI_MSCKF_W)
+        allp, allt = ex.all_gather(), tex.all_gather()
+        if allp.device.type != "cuda":           # gloo functional mode: the exchange ran on host tensors
+            allp, allt = allp.cuda(dev), allt.cuda(dev)
+        # the gathered snapshots stay in HBM: every per-agent stage of the CI block is batched on the device
+        fused, _ = fleet.ci_round_device(eng, sc, rank, world, allp, allt, CI_TRACKS, CI_MSCKF_W)
         ci_stats["rounds"] += 1
         ci_stats["fused"] += fused
 

@@ -183,6 +183,20 @@ int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const double *C_q_
                       double *ci_gamma, double *H, int ldh, double *res, double *S, int lds, double *P_j,
                       int ldpj);
 
+/* Device-resident CI round (MsckfUpdate::preProcessOneTrack CI block, msckf_update.cpp:96-279, followed by
+ * Updater::applyCI per fused entry, updater.cpp:90-93,144-161) against the snapshots of the other agents as they
+ * sit in the RCCL receive buffer -- no host staging of the n x n covariances.
+ *   d_payloads   DEVICE [world][payload_stride]: xk_pack_payload layout of every agent (own slot unused)
+ *   d_tracks     DEVICE [world][n_tracks][1 + 2N]: per shared track the length, then the observations (x,y)
+ *   track_len    host [world][n_tracks], n_poses_valid host [world]: the lengths / window sizes found in the above
+ *   self_track   host [n_tracks]: index of each shared track among this handle's staged tracks
+ * The handle's staged window and its RESIDENT covariance are this agent's side.  Every entry is built from the
+ * same prior and applyCI overwrites P each time (the reference's behaviour): on return the resident covariance
+ * is the posterior of the last fused entry.  corrections (host, optional): [*n_fused][n]. */
+int xk_ci_round_device(xk_handle *h, const double *d_payloads, long payload_stride, int world, int self_rank,
+                       const double *d_tracks, int n_tracks, const int *track_len, const int *n_poses_valid,
+                       const int *self_track, double sigma_img, double ci_msckf_w, int *n_fused, double *corrections);
+
 /* ---- inter-agent payload (SimpleState, include/x/ekf/simple_state.h:33-35,
  * assembled at src/x/vio/vio.cpp:447-450) ------------------------------ */
 

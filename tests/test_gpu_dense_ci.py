@@ -218,3 +218,46 @@ def test_fleet_ci_round_two_agents_one_gpu(xk, oracle_c):
     assert rel(last, olast) <= 1e-8
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_device_ci_round_matches_host_abi_round(xk, world):
+    """xk_ci_round_device (payloads stay in HBM, agents batched) == xk_msckf_ci_track + xk_apply_ci per track."""
+    import torch
+    from x_multi_agent_amd import fleet
+    N, K, M = 10, 12, 0
+    n_tracks, w = 3, 0.04
+    scs = []
+    lm = None
+    for r in range(world):
+        sc = synth.make_scenario(N, K, M, seed=4100 + r, agent_offset=0.03 * r, landmarks=lm, outlier_frac=0.0)
+        lm = sc["landmarks_true"] if lm is None else lm
+        scs.append(sc)
+    dyn = np.zeros(16); dyn[9] = 1.0
+    pays = np.stack([fleet.pack_payload_host(r, 0.0, dyn, scs[r]["C_q_G"], scs[r]["G_p_C"], None, None, scs[r]["P"], N, M)
+                     for r in range(world)])
+    trks = np.stack([fleet.pack_tracks(scs[r], n_tracks, N).ravel() for r in range(world)])
+    rank = 1 % world
+    sc = scs[rank]
+    # host-ABI round (reference-shaped calls)
+    eng = xk.Engine(N, M, K)
+    eng.stage(sc)
+    others = []
+    for r in range(world):
+        if r == rank:
+            continue
+        u = fleet.unpack_payload(pays[r], N, M)
+        u["tracks"] = fleet.unpack_tracks(trks[r], N)
+        others.append(u)
+    fused_h, P_h = fleet.ci_round(eng, sc, others, n_tracks, w)
+    # device round on the same engine state (resident P = staged prior)
+    eng.stage(sc)
+    dp = torch.from_numpy(pays).cuda()
+    dt = torch.from_numpy(trks).cuda()
+    torch.cuda.synchronize()
+    fused_d, corr = fleet.ci_round_device(eng, sc, rank, world, dp, dt, n_tracks, w, want_corrections=True)
+    P_d = eng.download_P()
+    eng.close()
+    assert fused_d == fused_h and fused_h >= 1
+    assert corr.shape == (fused_d, 15 + 6 * N) and np.isfinite(corr).all()
+    assert rel(P_d, P_h) <= 1e-9, rel(P_d, P_h)

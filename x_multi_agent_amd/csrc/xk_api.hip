@@ -47,6 +47,10 @@ struct xk_handle {
   // CI / payload
   double *d_payload;
   double *d_ci;  // scratch for the CI kernels
+  double *d_ciws;          // workspace of the device-resident CI round (lazily allocated)
+  XkFeatBatch *d_batch;    // per-agent descriptors of the batched feature launch, [8 tracks][8 agents]
+  XkFeatBatch *h_batch;    // pinned staging of the same
+  int *h_trk_off;          // host copy of the staged track offsets
   // host pinned staging
   double *h_pin;
   size_t h_pin_doubles;
@@ -156,6 +160,8 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_ci, (size_t)4 * nn + 64 * (size_t)h->n + 1024));
   h->h_pin_doubles = nn + 8 * (size_t)h->n + 4 * (size_t)k_max + 4 * (size_t)n_feat_max + 1024;
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin, sizeof(double) * h->h_pin_doubles));
+  h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
+  if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 64)));
   HIPCHK(h, hipMemset(h->d_status, 0, sizeof(int) * 4));
   HIPCHK(h, hipMemset(h->d_tile_rows, 0, sizeof(int) * (size_t)h->ntiles_max));
@@ -175,6 +181,10 @@ extern "C" int xk_destroy(xk_handle *h) {
                   h->d_ci};
   for (void *p : ptrs)
     if (p) hipFree(p);
+  if (h->d_ciws) hipFree(h->d_ciws);
+  if (h->d_batch) hipFree(h->d_batch);
+  if (h->h_batch) hipHostFree(h->h_batch);
+  free(h->h_trk_off);
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
   for (auto &e : h->ev)
@@ -214,6 +224,7 @@ extern "C" int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *o
     HIPCHK(h, hipMemcpyAsync(h->d_obs, obs_xy, sizeof(double) * 2 * trk_off[K], hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
+  if (K > 0) memcpy(h->h_trk_off, trk_off, sizeof(int) * (K + 1));
   h->K = K;
   h->have_rows = h->have_R = false;
   // remember the longest track for validation against n_poses at build time
@@ -274,7 +285,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
-    a.gpf_in = nullptr; a.up_out = nullptr; a.dbg = g_feat_dbg;
+    a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = g_feat_dbg;
     const size_t lds = xk_feature_lds_bytes(h->n_poses);
     hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
   }
@@ -926,7 +937,7 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
     a.P = aP; a.n = n_i; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = nullptr; a.DB = 0; a.C1P = 0; a.na = n_i - XK_CORE;
     a.tile_rows = dint + 2; a.inlier = dint + 1; a.gamma = dscal + 2; a.gpf = dgpf + 4; a.gn_iters = dint + 3;
-    a.gpf_in = dgpf; a.up_out = up + i * upsz; a.dbg = nullptr;
+    a.gpf_in = dgpf; a.up_out = up + i * upsz; a.batch = nullptr; a.dbg = nullptr;
     hipLaunchKernelGGL(xk_msckf_feature, dim3(1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(np_i), h->stream, a);
     if (self) {
       int inl = 0;
@@ -1003,6 +1014,147 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
   HIPCHK(h, hipMemcpy2DAsync(P_j, sizeof(double) * ldpj, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   *has_ci = 1;
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Device-resident CI round: the gathered SimpleState payloads (and the observations of the shared
+// tracks) stay where RCCL put them.  Same arithmetic as xk_msckf_ci_track + xk_apply_ci per shared
+// track, with every per-agent stage batched over the agents and no host staging of the n x n
+// covariances.  One host synchronisation per track (the two gate decisions).
+// ---------------------------------------------------------------------------
+extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long payload_stride, int world, int self_rank,
+                                  const double *d_tracks, int n_tracks, const int *track_len, const int *n_poses_valid,
+                                  const int *self_track, double sigma_img, double ci_msckf_w, int *n_fused,
+                                  double *corrections) {
+  if (!h || !d_payloads || !d_tracks || !track_len || !n_poses_valid || !self_track || !n_fused) return XK_EINVAL;
+  const int k = world - 1, k1 = world, N = h->N, n = h->n, m = 3 * k;
+  *n_fused = 0;
+  if (world < 2) return XK_OK;
+  if (k > XK_CI_MAXK) return fail(h, XK_ECAPACITY, "more than 7 matched agents");
+  if (self_rank < 0 || self_rank >= world || n_tracks < 0 || n_tracks > 8) return XK_EINVAL;
+  if (payload_stride != xk_payload_doubles(N, h->Mmax)) return fail(h, XK_EINVAL, "payload layout differs from this handle's (N, M)");
+  if (h->n_poses < 2) return fail(h, XK_EINVAL, "window not staged");
+  if (check_w(ci_msckf_w) != XK_OK) return fail(h, XK_EINVAL, "The CI weights must be lower than 1.0 and larger 0.0");
+  if (m > h->CM) return fail(h, XK_ECAPACITY, "m exceeds the dense workspace");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t upsz = 3 * (size_t)n + 16;
+  const size_t Lcap = (size_t)k1 * 64;
+    if (!h->d_ciws) {
+    HIPCHK(h, hipMalloc((void **)&h->d_ciws, sizeof(double) * ((size_t)9 * 8 * 64 + 8 * upsz + (size_t)21 * 8 * n + 8 * XK_CI_MAXCHUNK * 576 + 2 * 576 + 512)));
+    HIPCHK(h, hipMalloc((void **)&h->d_batch, sizeof(XkFeatBatch) * 64));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_batch, sizeof(XkFeatBatch) * 64));
+    hipFuncSetAttribute((const void *)xk_ci_hph, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  }
+  double *ws = h->d_ciws;
+  double *dq = ws, *dp = dq + 4 * Lcap, *dobs = dp + 3 * Lcap, *up = dobs + 2 * Lcap;
+  double *Hs = up + k1 * upsz, *Si = Hs + (size_t)std::max(m, 1) * k1 * n, *S1 = Si + (size_t)k1 * XK_CI_MAXCHUNK * 576, *S2 = S1 + 576;
+  double *dres = S2 + 576, *dgpf = dres + 24, *dscal = dgpf + 8;   // dscal[0] ci gamma, [1] w_result, [2..] per-agent gamma
+  int *dint = (int *)(dscal + 16);   // [0..7] inlier per agent, [8..15] tile rows, [16..31] gn iters, [32..159] block columns, [192..] landmarks
+  // payload layout (fleet.py / xk_pack_payload): hdr[8] dyn[16] pos[3N] att[4N] feat[3M] anchors[M] cov[n*n]
+  const size_t o_pos = 24, o_att = o_pos + 3 * (size_t)N, o_cov = o_att + 4 * (size_t)N + 4 * (size_t)h->Mmax;
+  const size_t trk_stride = 1 + 2 * (size_t)N;
+  const double w0 = 1.0 - (double)k * ci_msckf_w, var_img = sigma_img * sigma_img;
+  int fused = 0;
+  for (int j = 0; j < n_tracks; ++j) {
+    const int st = self_track[j];
+    if (st < 0 || st >= h->K) return fail(h, XK_EINVAL, "shared track index outside the staged tracks");
+    // agent order: index 0 = self, 1.. = the others by rank
+    const double *aq[XK_CI_MAXK + 1], *ap[XK_CI_MAXK + 1], *aobs[XK_CI_MAXK + 1], *aP[XK_CI_MAXK + 1];
+    int anp[XK_CI_MAXK + 1], aL[XK_CI_MAXK + 1], Ltot = 0;
+    aq[0] = h->d_q; ap[0] = h->d_p; aobs[0] = h->d_obs + 2 * (size_t)h->h_trk_off[st]; aP[0] = h->d_P;
+    anp[0] = h->n_poses; aL[0] = h->h_trk_off[st + 1] - h->h_trk_off[st];
+    for (int r = 0, i = 1; r < world; ++r) {
+      if (r == self_rank) continue;
+      const double *base = d_payloads + (size_t)r * payload_stride;
+      aq[i] = base + o_att; ap[i] = base + o_pos; aP[i] = base + o_cov;
+      aobs[i] = d_tracks + ((size_t)r * n_tracks + j) * trk_stride + 1;
+      anp[i] = n_poses_valid[r]; aL[i] = track_len[r * n_tracks + j];
+      if (aL[i] < 2 || aL[i] > anp[i] || anp[i] > N) return fail(h, XK_EINVAL, "received track / window lengths inconsistent");
+      ++i;
+    }
+    for (int i = 0; i < k1; ++i) Ltot += aL[i];
+    // joint triangulation over the concatenated lists: matched agents first, self last (:113-149)
+    XkCiGatherArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.k1 = k1; ga.dq = dq; ga.dp = dp; ga.dobs = dobs;
+    for (int i = 0; i < k1; ++i) {
+      const int src = (i < k) ? i + 1 : 0;
+      ga.q[i] = aq[src]; ga.p[i] = ap[src]; ga.obs[i] = aobs[src]; ga.np[i] = anp[src]; ga.L[i] = aL[src];
+    }
+    hipLaunchKernelGGL(xk_ci_gather, dim3(1), dim3(64), 0, h->stream, ga);
+    XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint + 16};
+    hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, h->stream, ta);
+    // per-agent column-space rows, one workgroup per agent (:168-204)
+    XkFeatBatch *hb = h->h_batch + 8 * j, *db = h->d_batch + 8 * j;
+    int npmax = 0;
+    for (int i = 0; i < k1; ++i) {
+      hb[i].q = aq[i]; hb[i].p = ap[i]; hb[i].obs = aobs[i]; hb[i].P = aP[i];
+      hb[i].n_poses = anp[i]; hb[i].n_poses_max = N; hb[i].n = n; hb[i].L = aL[i]; hb[i].up_out = up + i * upsz;
+      npmax = std::max(npmax, anp[i]);
+    }
+    HIPCHK(h, hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, h->stream));
+    XkFeatArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = k1; a.var_img = var_img; a.chi95 = h->d_chi95; a.n = n; a.na = n - XK_CORE; a.n_poses = npmax; a.n_poses_max = N;
+    a.tile_rows = dint + 8; a.inlier = dint; a.gamma = dscal + 2; a.gpf = (double *)(dint + 192); a.gn_iters = dint + 24;
+    a.gpf_in = dgpf; a.batch = db;
+    hipLaunchKernelGGL(xk_msckf_feature, dim3(k1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(npmax), h->stream, a);
+    // null-space projection of the landmark and split into per-agent Jacobians (:207-223)
+    XkCiProjArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.k1 = k1; pa.res = dres;
+    for (int i = 0; i < k1; ++i) { pa.up[i] = up + i * upsz; pa.n[i] = n; pa.H[i] = Hs + (size_t)m * n * i; }
+    hipLaunchKernelGGL(xk_ci_project, dim3(1), dim3(256), 0, h->stream, pa);
+    // S_i = H_i P_i H_i^T for all agents, then the gate / CI combinations and gamma
+    XkCiHphArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.m = m; ha.S = Si;
+    for (int i = 0; i < k1; ++i) { ha.H[i] = pa.H[i]; ha.P[i] = aP[i]; ha.n[i] = n; }
+    const int nchunk = (n + XK_CI_CHUNK - 1) / XK_CI_CHUNK;
+    hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), h->stream, ha);
+    XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal};
+    hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(64), 0, h->stream, ca);
+    // the two gate decisions (own chi-square test :180, joint test :243-250)
+    HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[8], dint, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_pin, dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int dof = 2 * Ltot - 3;
+    if (dof >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
+    if (!h->h_pin_i[8] || !(h->h_pin[0] < XK_CHI2_095[dof])) continue;
+    // P_j: diagonal 3x3 blocks of the observed poses scaled by 1/w0 (:256-267), then applyCI (updater.cpp:144-161)
+    const int L = aL[0];
+    int *hc = h->h_pin_i + 16;
+    for (int i = 0; i < L; ++i) {
+      const int pos = h->n_poses - L + i;
+      hc[2 * i] = XK_CORE + 3 * pos;
+      hc[2 * i + 1] = XK_CORE + 3 * pos + 3 * N;
+    }
+    h->h_pin[1] = 1.0 / w0;
+    HIPCHK(h, hipMemcpyAsync(dint + 32, hc, sizeof(int) * 2 * L, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dscal + 1, h->h_pin + 1, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    XkScaleArgs sc{h->d_P, h->d_tmpP, n, 2 * L, dint + 32, dscal + 1};
+    hipLaunchKernelGGL(xk_scale_blocks, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, sc);
+    UpdateSpec u;
+    memset(&u, 0, sizeof(u));
+    u.T = pa.H[0]; u.str = 1; u.stc = m;
+    u.c = m; u.kdim = n; u.col0 = 0;
+    u.z = dres; u.sz = 1;
+    u.S = S2; u.ssr = 1; u.ssc = m;
+    u.Pin = h->d_tmpP; u.Pout = h->d_Pout; u.ct = nullptr; u.cov_update = 1;   // every entry starts from the same prior
+    int rc = launch_update(h, u);
+    if (rc != XK_OK) return rc;
+    if (corrections) HIPCHK(h, hipMemcpyAsync(corrections + (size_t)fused * n, h->d_corr, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // h_pin staging is reused by the next track
+    ++fused;
+  }
+  if (fused) {
+    int rc = read_status(h);
+    if (rc != XK_OK) return rc;
+    std::swap(h->d_P, h->d_Pout);   // applyCI overwrites P: the last fused entry is the resident covariance
+    h->have_rows = h->have_R = false;
+  }
+  *n_fused = fused;
   return XK_OK;
 }
 

@@ -221,54 +221,71 @@ struct XkCiProjArgs {
 };
 
 __global__ __launch_bounds__(256) void xk_ci_project(XkCiProjArgs a) {
-  __shared__ double Q[24][24];   // full Q of the 3(k+1) x 3 stack
-  __shared__ double rp[24];
+  __shared__ double Q[24][25];   // full Q of the 3(k+1) x 3 stack
+  __shared__ double V[24][3];    // the stack, then its reflectors (below the diagonal)
+  __shared__ double rp[24], taus[3];
   const int mr = 3 * a.k1, m = mr - 3, tid = threadIdx.x;
-  if (tid == 0) {
+  if (tid < mr) {                // row tid of the stacked [Hf_i | res_i]
+    const int i = tid / 3, r = tid % 3;
+    const double *uh = a.up[i] + 3 * (size_t)a.n[i];
+    for (int c = 0; c < 3; ++c) V[tid][c] = uh[r + 3 * c];
+    rp[tid] = uh[9 + r];
+  }
+  for (int e = tid; e < 24 * 24; e += 256) Q[e / 24][e % 24] = (e / 24 == e % 24) ? 1.0 : 0.0;
+  __syncthreads();
+  if (tid == 0) {                // Householder QR of the mr x 3 stack (Eigen convention), in registers
     double jf[24][3], tau[3];
-    for (int i = 0; i < a.k1; ++i) {
-      const double *uh = a.up[i] + 3 * (size_t)a.n[i];
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) jf[3 * i + r][c] = uh[r + 3 * c];
-        rp[3 * i + r] = uh[9 + r];
-      }
-    }
-    for (int kk = 0; kk < 3; ++kk) {   // Householder QR (Eigen convention)
+#pragma unroll
+    for (int r = 0; r < 24; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) jf[r][c] = (r < mr) ? V[r][c] : 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
       double tail = 0;
-      for (int r = kk + 1; r < mr; ++r) tail += jf[r][kk] * jf[r][kk];
+#pragma unroll
+      for (int r = kk + 1; r < 24; ++r) tail += jf[r][kk] * jf[r][kk];   // rows >= mr are zero
       const double c0 = jf[kk][kk];
       double bet, sc;
       if (tail <= 2.2250738585072014e-308) { tau[kk] = 0; bet = c0; sc = 0; }
       else { bet = sqrt(c0 * c0 + tail); if (c0 >= 0) bet = -bet; tau[kk] = (bet - c0) / bet; sc = 1.0 / (c0 - bet); }
-      for (int r = kk + 1; r < mr; ++r) jf[r][kk] *= sc;
+#pragma unroll
+      for (int r = kk + 1; r < 24; ++r) jf[r][kk] *= sc;
       jf[kk][kk] = bet;
+#pragma unroll
       for (int c2 = kk + 1; c2 < 3; ++c2) {
         double w = jf[kk][c2];
-        for (int r = kk + 1; r < mr; ++r) w += jf[r][kk] * jf[r][c2];
+#pragma unroll
+        for (int r = kk + 1; r < 24; ++r) w += jf[r][kk] * jf[r][c2];
         w *= tau[kk];
         jf[kk][c2] -= w;
-        for (int r = kk + 1; r < mr; ++r) jf[r][c2] -= w * jf[r][kk];
+#pragma unroll
+        for (int r = kk + 1; r < 24; ++r) jf[r][c2] -= w * jf[r][kk];
       }
     }
-    for (int i = 0; i < mr; ++i)
-      for (int j = 0; j < mr; ++j) Q[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int kk = 2; kk >= 0; --kk) {  // Q = H0 H1 H2 applied to I
-      if (tau[kk] == 0.0) continue;
-      for (int j = kk; j < mr; ++j) {
-        double w = Q[kk][j];
-        for (int r = kk + 1; r < mr; ++r) w += jf[r][kk] * Q[r][j];
-        w *= tau[kk];
-        Q[kk][j] -= w;
-        for (int r = kk + 1; r < mr; ++r) Q[r][j] -= w * jf[r][kk];
-      }
-    }
-    for (int c = 0; c < m; ++c) {      // res = A^T res_pf, A = Q[:, 3:]
-      double s = 0;
-      for (int r = 0; r < mr; ++r) s += Q[r][3 + c] * rp[r];
-      a.res[c] = s;
-    }
+#pragma unroll
+    for (int r = 0; r < 24; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) V[r][c] = jf[r][c];
+    for (int kk = 0; kk < 3; ++kk) taus[kk] = tau[kk];
   }
   __syncthreads();
+  for (int kk = 2; kk >= 0; --kk) {  // Q = H0 H1 H2 applied to I, one thread per column
+    const double tk = taus[kk];
+    if (tk != 0.0 && tid >= kk && tid < mr) {
+      const int j = tid;
+      double w = Q[kk][j];
+      for (int r = kk + 1; r < mr; ++r) w += V[r][kk] * Q[r][j];
+      w *= tk;
+      Q[kk][j] -= w;
+      for (int r = kk + 1; r < mr; ++r) Q[r][j] -= w * V[r][kk];
+    }
+    __syncthreads();
+  }
+  if (tid < m) {                     // res = A^T res_pf, A = Q[:, 3:]
+    double s = 0;
+    for (int r = 0; r < mr; ++r) s += Q[r][3 + tid] * rp[r];
+    a.res[tid] = s;
+  }
   for (int i = 0; i < a.k1; ++i) {     // H_i = A[3i:3i+3, :]^T * up_jac_i
     const double *uj = a.up[i];
     for (int col = tid; col < a.n[i]; col += 256) {
@@ -299,4 +316,141 @@ __global__ void xk_small_gamma(const double *S /*m x m col-major*/, const double
     g += y[i] * y[i];
   }
   *gamma = bad ? INFINITY : g;
+}
+
+// ----------------------------------------------------------------------------
+// Device-resident CI round (the received SimpleState payloads never leave HBM): the same
+// MSCKF-MSCKF CI block as above, with every per-agent stage batched over the agents.
+// ----------------------------------------------------------------------------
+// Concatenated pose / observation lists for the joint triangulation (matched agents first, self
+// last, msckf_update.cpp:113-149): agent i contributes the last L_i poses of its window.
+struct XkCiGatherArgs {
+  int k1;
+  const double *q[XK_CI_MAXK + 1], *p[XK_CI_MAXK + 1], *obs[XK_CI_MAXK + 1];
+  int np[XK_CI_MAXK + 1], L[XK_CI_MAXK + 1];
+  double *dq, *dp, *dobs;
+};
+__global__ __launch_bounds__(64) void xk_ci_gather(XkCiGatherArgs a) {
+  int at = 0;
+  for (int i = 0; i < a.k1; ++i) {
+    const int L = a.L[i], p0 = a.np[i] - L;
+    for (int t = threadIdx.x; t < L; t += 64) {
+      for (int c = 0; c < 4; ++c) a.dq[4 * (size_t)(at + t) + c] = a.q[i][4 * (size_t)(p0 + t) + c];
+      for (int c = 0; c < 3; ++c) a.dp[3 * (size_t)(at + t) + c] = a.p[i][3 * (size_t)(p0 + t) + c];
+      for (int c = 0; c < 2; ++c) a.dobs[2 * (size_t)(at + t) + c] = a.obs[i][2 * (size_t)t + c];
+    }
+    at += L;
+  }
+}
+
+// S_i = H_i P_i H_i^T for every agent at once: block (i, cb) owns 32 columns of W = H_i P_i and their
+// contribution W[:, cols] H_i[:, cols]^T to S_i (partials are summed in a fixed order by xk_ci_combine).
+// H_i is m x n_i (column-major, ld = m, m = 3k <= 21), P_i the agent's n_i x n_i covariance (symmetric:
+// row j is read as column j, coalesced).  Thread (c, g) accumulates rows 3g..3g+2 of column c.
+#define XK_CI_CHUNK 32
+#define XK_CI_MAXCHUNK 16   // n <= 512
+struct XkCiHphArgs {
+  int m;
+  const double *H[XK_CI_MAXK + 1], *P[XK_CI_MAXK + 1];
+  int n[XK_CI_MAXK + 1];
+  double *S;   // out: [k1][XK_CI_MAXCHUNK][24 * 24] column-major m x m partials
+};
+__global__ __launch_bounds__(256) void xk_ci_hph(XkCiHphArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double hsm[];
+  const int i = blockIdx.x, cb = blockIdx.y, m = a.m, n = a.n[i], tid = threadIdx.x;
+  double *Hs = hsm;                       // m x n, ld = m
+  double *Ws = hsm + (size_t)m * n;       // 24 x 32 chunk of W, ld = 25
+  double *out = a.S + ((size_t)i * XK_CI_MAXCHUNK + cb) * 576;
+  const int c0 = cb * XK_CI_CHUNK;
+  if (c0 >= n) {                          // (grid.y is sized for the widest agent)
+    for (int e = tid; e < m * m; e += 256) out[e] = 0.0;
+    return;
+  }
+  const double *H = a.H[i], *P = a.P[i];
+  for (int e = tid; e < m * n; e += 256) Hs[e] = H[e];
+  __syncthreads();
+  const int cl = tid & 31, g = tid >> 5, c = c0 + cl;   // 8 row groups of 3
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  if (c < n && 3 * g < m) {
+    for (int j0 = 0; j0 < n; j0 += 16) {   // 16 covariance entries in flight per thread
+      double pj[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) pj[u] = (j0 + u < n) ? P[(size_t)c + (size_t)(j0 + u) * n] : 0.0;   // = P(j, c)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int j = (j0 + u < n) ? j0 + u : 0;
+        const double *hj = Hs + (size_t)j * m + 3 * g;
+        a0 = fma(hj[0], pj[u], a0);
+        a1 = fma(hj[1], pj[u], a1);
+        a2 = fma(hj[2], pj[u], a2);
+      }
+    }
+  }
+  Ws[(3 * g) * 33 + cl] = a0; Ws[(3 * g + 1) * 33 + cl] = a1; Ws[(3 * g + 2) * 33 + cl] = a2;
+  __syncthreads();
+  // partial S = W[:, chunk] H[:, chunk]^T
+  const int nc = min(XK_CI_CHUNK, n - c0);
+  for (int e = tid; e < m * m; e += 256) {
+    const int r = e % m, s2 = e / m;
+    double acc = 0.0;
+    for (int cc = 0; cc < nc; ++cc) acc = fma(Ws[r * 33 + cc], Hs[s2 + (size_t)(c0 + cc) * m], acc);
+    out[e] = acc;
+  }
+}
+
+// S_gate = sum_i S_i + sigma^2 I (msckf_update.cpp:217-237), S_ci = S_0 / w0 + sum_{i>0} S_i / w + sigma^2 I
+// (ci.cpp:78-85 + msckf_update.cpp:255), gamma = res^T S_gate^-1 res (:243-244).
+struct XkCiCombineArgs {
+  int k1, m;
+  const double *S;      // [k1][XK_CI_MAXCHUNK][576] partials from xk_ci_hph
+  int nchunk;
+  double w0, w, var_img;
+  const double *res;    // m
+  double *S_gate, *S_ci;  // m x m column-major
+  double *gamma;
+};
+__global__ __launch_bounds__(64) void xk_ci_combine(XkCiCombineArgs a) {
+  const int m = a.m;
+  for (int e = threadIdx.x; e < m * m; e += 64) {
+    double g = 0.0, c = 0.0;
+    for (int i = 0; i < a.k1; ++i) {
+      double v = 0.0;
+      for (int cb = 0; cb < a.nchunk; ++cb) v += a.S[((size_t)i * XK_CI_MAXCHUNK + cb) * 576 + e];
+      g += v;
+      c += v * (i == 0 ? 1.0 / a.w0 : 1.0 / a.w);
+    }
+    if (e % m == e / m) { g += a.var_img; c += a.var_img; }
+    a.S_gate[e] = g;
+    a.S_ci[e] = c;
+  }
+  __syncthreads();
+  // gamma = res^T S_gate^-1 res: right-looking Cholesky in LDS, lane i owns row i; then a column-oriented
+  // forward substitution (one wave: the barriers are wave barriers)
+  __shared__ double A[24][25], y[24];
+  const int t = threadIdx.x;
+  for (int e = t; e < m * m; e += 64) A[e % m][e / m] = a.S_gate[e];
+  if (t < m) y[t] = a.res[t];
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < m; ++k) {
+    const double p = A[k][k];
+    if (!(p > 0)) bad = true;
+    const double inv = 1.0 / sqrt(p);
+    double lik = 0.0;
+    if (t > k && t < m) { lik = A[t][k] * inv; A[t][k] = lik; }
+    __syncthreads();
+    if (t > k && t < m)
+      for (int j = k + 1; j <= t; ++j) A[t][j] -= lik * A[j][k];
+    if (t == k) A[k][k] = p * inv;   // sqrt(p)
+    __syncthreads();
+  }
+  double g = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const double yi = y[i] / A[i][i];   // uniform
+    g += yi * yi;
+    __syncthreads();
+    if (t > i && t < m) y[t] -= A[t][i] * yi;
+    __syncthreads();
+  }
+  if (t == 0) *a.gamma = bad ? INFINITY : g;
 }

@@ -57,7 +57,16 @@ struct XkFeatArgs {
   // also emit the 3 column-space rows  A_up^T [jac | Hf | res]  (up_out: [3*n | 9 | 3] doubles, col-major)
   const double *gpf_in;
   double *up_out;
+  // batch mode (CI round): block b works on its OWN window / prior / track, described by batch[b]
+  const struct XkFeatBatch *batch;
   long long *dbg;   // probe builds only: phase stamps of block 0
+};
+
+// One agent's view of a shared track: window, prior covariance, observations (all device pointers).
+struct XkFeatBatch {
+  const double *q, *p, *obs, *P;
+  int n_poses, n_poses_max, n, L;
+  double *up_out;
 };
 
 __device__ __forceinline__ void xk_quat_to_rot(const double *q, double *r /*row-major 3x3*/) {
@@ -290,8 +299,14 @@ static inline size_t xk_feature_lds_bytes(int n_poses) {
   return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 134);
 }
 
-__global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a) {
+__global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  XkFeatArgs a = a_in;
+  if (a_in.batch) {
+    const XkFeatBatch bb = a_in.batch[blockIdx.x];
+    a.q = bb.q; a.p = bb.p; a.obs = bb.obs; a.P = bb.P;
+    a.n_poses = bb.n_poses; a.n_poses_max = bb.n_poses_max; a.n = bb.n; a.na = bb.n - XK_CORE; a.up_out = bb.up_out;
+  }
   XK_WG_BEGIN();
   const int tid = threadIdx.x, k = blockIdx.x;
   const int np = a.n_poses, Lmax = np;
@@ -306,7 +321,8 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   double *scal = Mm + (size_t)(2 * Lmax + 1) * ldm;  // 32 scalars (16..24: R factor of Hf)
   // scal: 0..2 tau, 3 g01, 4 g02, 5 g12, 6..8 gpf, 9 valid, 10 bad, 11 inlier, 12 gamma
 
-  const int off = a.trk_off[k], L = a.trk_off[k + 1] - off, m2 = 2 * L, d = m2 - 3, p0 = np - L;
+  const int off = a_in.batch ? 0 : a.trk_off[k], L = a_in.batch ? a_in.batch[k].L : a.trk_off[k + 1] - off;
+  const int m2 = 2 * L, d = m2 - 3, p0 = np - L;
 
   for (int i = tid; i < np; i += XK_FEAT_THREADS) {
     xk_quat_to_rot(a.q + 4 * i, rot + 9 * i);

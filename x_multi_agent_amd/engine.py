@@ -26,6 +26,7 @@ SYMBOLS = [
     "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
+    "xk_ci_round_device",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
 ]
 
@@ -322,6 +323,23 @@ class Engine:
         if hc.value:
             out["ci"] = dict(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj), H=np.ascontiguousarray(H), res=res)
         return out
+
+    def ci_round_device(self, payloads_ptr, payload_stride, world, self_rank, tracks_ptr, n_tracks, track_len,
+                        n_poses_valid, self_track, sigma_img, ci_msckf_w, want_corrections=False):
+        """CI round against gathered payloads that already sit in device memory (RCCL receive buffer).
+        payloads_ptr / tracks_ptr are device addresses (e.g. torch tensor.data_ptr()).  Returns
+        (n_fused, corrections or None); the resident covariance becomes the last fused posterior."""
+        tl, tlp = _i(np.asarray(track_len, dtype=np.int32).ravel())
+        nv, nvp = _i(np.asarray(n_poses_valid, dtype=np.int32).ravel())
+        st, stp = _i(np.asarray(self_track, dtype=np.int32).ravel())
+        nf = C.c_int()
+        corr = np.zeros((max(n_tracks, 1), self.n)) if want_corrections else None
+        self._chk(self.L.xk_ci_round_device(
+            self.h, C.cast(C.c_void_p(payloads_ptr), c_dp), C.c_long(payload_stride), C.c_int(world), C.c_int(self_rank),
+            C.cast(C.c_void_p(tracks_ptr), c_dp), C.c_int(n_tracks), tlp, nvp, stp, C.c_double(sigma_img),
+            C.c_double(ci_msckf_w), C.byref(nf), corr.ctypes.data_as(c_dp) if want_corrections else None),
+            "xk_ci_round_device")
+        return nf.value, (corr[:nf.value] if want_corrections else None)
 
     # ---- measurement -------------------------------------------------
     def bench_staged(self, sigma_img, warmup, steps):

@@ -162,3 +162,16 @@ def ci_round(eng, sc, others, n_tracks, ci_msckf_w):
             last, _corr = eng.apply_ci(c["P_j"], c["H"], c["res"], c["S"])
             fused += 1
     return fused, last
+
+
+def ci_round_device(eng, sc, rank, world, payloads, tracks, n_tracks, ci_msckf_w, want_corrections=False):
+    """The same CI round with everything the other agents sent left in device memory.
+    payloads: torch CUDA tensor [world, payload_doubles] (the all-gather output); tracks: torch CUDA tensor
+    [world, n_tracks * (1 + 2N)] (pack_tracks of every agent).  The engine must have agent `rank`'s problem staged
+    (its shared tracks are its first n_tracks staged tracks).  Only the few header / length words come to the host."""
+    N = sc["n_poses_max"]
+    tl = tracks.view(world, n_tracks, 1 + 2 * N)[:, :, 0].to("cpu").numpy().astype(np.int32)
+    nv = payloads[:, 5].to("cpu").numpy().astype(np.int32)
+    nv[rank] = len(sc["G_p_C"])
+    return eng.ci_round_device(payloads.data_ptr(), payloads.shape[1], world, rank, tracks.data_ptr(), n_tracks, tl, nv,
+                               np.arange(n_tracks, dtype=np.int32), sc["sigma_img"], ci_msckf_w, want_corrections)
