@@ -183,6 +183,15 @@ int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const double *C_q_
                       double *ci_gamma, double *H, int ldh, double *res, double *S, int lds, double *P_j,
                       int ldpj);
 
+/* ---- StateManager::manage on the resident covariance (state_manager.cpp:31-149) ----
+ * Every covariance operation of manage() -- persistent-feature removal (:52-112), anchor re-parametrisation
+ * (reparametrizeFeatures, :351-482), window slide (slideWindow, :484-537) and pose augmentation
+ * (augmentCovariance, :273-349) -- is  P <- J P J^T  with a J that is an identity / permutation / zero except
+ * for a few 3-row blocks.  The reference forms J densely and does two n^3 products per operation; here J is
+ * handed over in CSR (n rows, row_ptr[n+1], 0-based col_idx, val) and applied to the handle's RESIDENT
+ * covariance in O(nnz(J)^2 / n + n^2).  host/src/state_manager.cpp builds the J's exactly as the reference. */
+int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz);
+
 /* Device-resident CI round (MsckfUpdate::preProcessOneTrack CI block, msckf_update.cpp:96-279, followed by
  * Updater::applyCI per fused entry, updater.cpp:90-93,144-161) against the snapshots of the other agents as they
  * sit in the RCCL receive buffer -- no host staging of the n x n covariances.

@@ -565,3 +565,151 @@ def msckf_ci_track(trk, C_q_G, G_p_C, P, n_poses_max, sigma_img, matches, ci_msc
             Pj[c:c + 3, c:c + 3] *= w_res
         out["ci"] = dict(S=S, P_j=Pj, H=h_j, res=rp, w_result=w_res)
     return out
+
+
+# ----------------------------------------------------------------------------
+# StateManager::manage (src/x/vio/state_manager.cpp:31-149): the step that runs immediately before the
+# visual update every frame -- persistent-feature removal, anchor re-parametrisation + window slide when
+# the window is full, pose augmentation.  Restated AS WRITTEN: dense n x n Jacobians and products.
+#   sm    dict(n_poses, n_features, n_poses_max, n_features_max, anchor_idxs[list], filled_before[bool])
+#   state dict(p[3], q[4 xyzw], q_ic[4 xyzw], p_ic[3], q_array[4N], p_array[3N], f_array[3M], cov[n,n])
+# Both are copied; returns (sm', state').
+# ----------------------------------------------------------------------------
+def _rot(q_xyzw):
+    return quat_to_rot(np.asarray(q_xyzw, float))
+
+
+def _unit(q):
+    q = np.asarray(q, float)
+    return q / np.sqrt(np.dot(q, q))
+
+
+quat_mul_xyzw = quat_mul
+
+
+def sm_augment_covariance(sm, state, pos, cov):
+    """StateManager::augmentCovariance, state_manager.cpp:273-349."""
+    N, M = sm["n_poses_max"], sm["n_features_max"]
+    n = 15 + 6 * N + 3 * M
+    J = np.eye(n) if sm["filled_before"] else np.zeros((n, n))           # :276-284
+    k = 15 + (pos + 1) * 3
+    J[:k, :k] = np.eye(k)                                                 # :288-291
+    a0 = 15 + 3 * N
+    J[a0:a0 + 3 * (pos + 1), a0:a0 + 3 * (pos + 1)] = np.eye(3 * (pos + 1))   # :294-297
+    f0 = 15 + 6 * N
+    nf = sm["n_features"]
+    J[f0:f0 + 3 * nf, f0:f0 + 3 * nf] = np.eye(3 * nf)                    # :300-303
+    J[15 + 3 * pos:15 + 3 * pos + 3, 0:3] = np.eye(3)                     # :307-308
+    J[15 + 3 * pos:15 + 3 * pos + 3, 6:9] = -_rot(state["q"]) @ skew(state["p_ic"])   # :312-315
+    qic = np.asarray(state["q_ic"], float)
+    qic_conj = np.array([-qic[0], -qic[1], -qic[2], qic[3]])
+    J[a0 + 3 * pos:a0 + 3 * pos + 3, 6:9] = _rot(qic_conj)               # :318-322
+    Pc = cov.copy()
+    for s0 in (15 + 3 * pos, a0 + 3 * pos):                               # :326-339
+        Pc[s0:s0 + 3, :] = 0.0
+        Pc[:, s0:s0 + 3] = 0.0
+    if pos + 1 == N:                                                      # :342-343
+        sm["filled_before"] = True
+    return J @ Pc @ J.T                                                   # :346-347
+
+
+def sm_reparametrize_features(sm, atts, poss, feats, cov):
+    """StateManager::reparametrizeFeatures, state_manager.cpp:351-482 (modifies feats, sm['anchor_idxs'])."""
+    N, M = sm["n_poses_max"], sm["n_features_max"]
+    n = 15 + 6 * N + 3 * M
+    R_old = _rot(atts[0:4])
+    p_old = poss[0:3].copy()
+    idx1 = N - 1
+    R_new = _rot(atts[4 * idx1:4 * idx1 + 4])
+    p_new = poss[3 * idx1:3 * idx1 + 3].copy()
+    J = np.eye(n)
+    for j in [i for i in range(sm["n_features"]) if sm["anchor_idxs"][i] == 0]:
+        al, be, rho = feats[3 * j:3 * j + 3]
+        v = np.array([al, be, 1.0])
+        new_params = R_new.T @ (-p_new + p_old + (1.0 / rho) * R_old @ v)       # Eq. 38, :402-406
+        rho_n = 1.0 / new_params[2]
+        al_n, be_n = new_params[0] * rho_n, new_params[1] * rho_n
+        feats[3 * j:3 * j + 3] = [al_n, be_n, rho_n]
+        sm["anchor_idxs"][j] = idx1
+        J_att_old = -(1.0 / rho) * R_new.T @ R_old @ skew(v)                     # :424-427
+        J_att_new = skew(new_params)                                            # :430-436
+        J_pos_old = R_new.T                                                     # :439-440
+        J_pos_new = -R_new.T                                                    # :443-444
+        mat = np.eye(3)
+        mat[0, 2], mat[1, 2], mat[2, 2] = -al / rho, -be / rho, -1.0 / rho
+        J_feat_old = (1.0 / rho) * R_new.T @ R_old @ mat                        # :447-453
+        A = np.zeros((3, n))
+        A[:, 15 + 3 * idx1:15 + 3 * idx1 + 3] = J_pos_new                       # :458-460
+        A[:, 15 + 3 * idx1 + 3 * N:15 + 3 * idx1 + 3 * N + 3] = J_att_new       # :462-463
+        A[:, 15:18] = J_pos_old                                                 # :465-466
+        A[:, 15 + 3 * N:15 + 3 * N + 3] = J_att_old                             # :468-469
+        A[:, 15 + 6 * N + 3 * j:15 + 6 * N + 3 * j + 3] = J_feat_old            # :471-473
+        mat = np.eye(3)
+        mat[0, 2], mat[1, 2], mat[2, 2] = -al_n, -be_n, -rho_n
+        n1 = 15 + 6 * N + 3 * j
+        J[n1:n1 + 3, :] = rho_n * mat @ A                                       # :476-482
+    return J @ cov @ J.T
+
+
+def sm_slide_window(sm, atts, poss, cov):
+    """StateManager::slideWindow, state_manager.cpp:484-537 (modifies atts, poss, sm)."""
+    N, M = sm["n_poses_max"], sm["n_features_max"]
+    atts[:4 * (N - 1)] = atts[4:].copy()
+    poss[:3 * (N - 1)] = poss[3:].copy()
+    atts[4 * (N - 1):] = 0.0
+    poss[3 * (N - 1):] = 0.0
+    n = cov.shape[0]
+    left = np.zeros((n, n))
+    left[:15, :15] = np.eye(15)
+    if M:
+        f0 = 15 + 6 * N
+        left[f0:f0 + 3 * M, f0:f0 + 3 * M] = np.eye(3 * M)
+    right = left.copy()
+    w = 3 * (N - 1)
+    left[15:15 + w, 18:18 + w] = np.eye(w)
+    left[15 + 3 * N:15 + 3 * N + w, 18 + 3 * N:18 + 3 * N + w] = np.eye(w)
+    right[18:18 + w, 15:15 + w] = np.eye(w)
+    right[18 + 3 * N:18 + 3 * N + w, 15 + 3 * N:15 + 3 * N + w] = np.eye(w)
+    out = left @ cov @ right
+    for i in range(sm["n_features"]):
+        sm["anchor_idxs"][i] -= 1
+    sm["n_poses"] -= 1
+    return out
+
+
+def state_manage(sm, state, del_feat_idx=()):
+    """StateManager::manage, state_manager.cpp:31-149."""
+    sm = dict(sm, anchor_idxs=list(sm["anchor_idxs"]))
+    st = {k: (np.array(v, dtype=float, copy=True) if not np.isscalar(v) else v) for k, v in state.items()}
+    N, M = sm["n_poses_max"], sm["n_features_max"]
+    att, pos, feats, cov = st["q_array"], st["p_array"], st["f_array"], st["cov"]
+    cae = quat_mul_xyzw(_unit(st["q"]), _unit(st["q_ic"]))               # State::computeCameraOrientation, state.cpp:184-187
+    cpe = st["p"] + _rot(st["q"]) @ st["p_ic"]                           # computeCameraPosition, :189-191
+    n = cov.shape[0]
+    for idx in sorted(del_feat_idx, reverse=True):                        # :52-112
+        n1 = sm["n_features"] - idx - 1
+        feats[3 * idx:3 * idx + 3 * n1] = feats[3 * (idx + 1):3 * (idx + 1) + 3 * n1].copy()
+        feats[3 * (sm["n_features"] - 1):3 * sm["n_features"]] = 0.0
+        del sm["anchor_idxs"][idx]
+        sm["anchor_idxs"].append(-1)
+        idx0 = 15 + 6 * N + 3 * idx
+        idx1 = idx0 + 3
+        dim0 = 3 * (M - idx - 1)
+        cols_after = cov[:, idx1:idx1 + dim0].copy()
+        cols_after[idx0:idx0 + dim0, :] = cols_after[idx1:idx1 + dim0, :].copy()
+        rows_after = cov[idx1:idx1 + dim0, :idx0].copy()
+        cov[:, idx0:idx0 + dim0] = cols_after
+        cov[idx0:idx0 + dim0, :idx0] = rows_after
+        cov[:, n - 3:] = 0.0
+        cov[n - 3:, :] = 0.0
+        sm["n_features"] -= 1
+    if sm["n_poses"] == N:                                                # :119-125
+        cov = sm_reparametrize_features(sm, att, pos, feats, cov)
+        cov = sm_slide_window(sm, att, pos, cov)
+    p_i = sm["n_poses"]
+    att[4 * p_i:4 * p_i + 4] = cae                                        # :133
+    pos[3 * p_i:3 * p_i + 3] = cpe                                        # :134
+    cov = sm_augment_covariance(sm, st, p_i, cov)                        # :137
+    sm["n_poses"] += 1
+    st.update(q_array=att, p_array=pos, f_array=feats, cov=cov)
+    return sm, st

@@ -92,6 +92,23 @@ def ci_cases():
     print("ci_two_agents", [bool(d[f"ms{j}_inlier"]) for j in range(4)], [bool(d[f"mc{j}_has_ci"]) for j in range(4)])
 
 
+def manage_cases():
+    """StateManager::manage sequences (SURVEY 8(f) rank 1): expected state/covariance after every call."""
+    for name, kw in synth.MANAGE_SEQUENCES.items():
+        seq = synth.make_manage_sequence(**kw)
+        sm, st = seq["init"]["sm"], dict(seq["init"])
+        st.pop("sm")
+        d = {}
+        for i, step in enumerate(seq["steps"]):
+            st.update(p=step["p"], q=step["q"], q_ic=step["q_ic"], p_ic=step["p_ic"])
+            sm, st = ref_np.state_manage(sm, st, step["del"])
+            d[f"s{i}_cov"] = st["cov"]
+            d[f"s{i}_q_array"], d[f"s{i}_p_array"], d[f"s{i}_f_array"] = st["q_array"], st["p_array"], st["f_array"]
+            d[f"s{i}_sm"] = np.array([sm["n_poses"], sm["n_features"], int(sm["filled_before"])] + list(sm["anchor_idxs"]), float)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, "steps", len(seq["steps"]), "final n_poses", sm["n_poses"], "n_features", sm["n_features"], sm["anchor_idxs"])
+
+
 if __name__ == "__main__":
     visual_case("cfg1_n10_k50", synth.make_config(1))
     visual_case("slam_n8_k30_m6", synth.make_scenario(8, 30, 6, seed=77))
@@ -101,3 +118,4 @@ if __name__ == "__main__":
     visual_case("stress_prior_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress", prior_scale=0.01))
     visual_case("all_outliers_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress"))
     ci_cases()
+    manage_cases()

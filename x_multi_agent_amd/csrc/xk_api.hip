@@ -51,6 +51,9 @@ struct xk_handle {
   XkFeatBatch *d_batch;    // per-agent descriptors of the batched feature launch, [8 tracks][8 agents]
   XkFeatBatch *h_batch;    // pinned staging of the same
   int *h_trk_off;          // host copy of the staged track offsets
+  int *d_csr_i;            // sparse congruence operand: row pointers then column indices
+  double *d_csr_v;         //   and values
+  size_t csr_cap;          //   capacity in non-zeros
   // host pinned staging
   double *h_pin;
   size_t h_pin_doubles;
@@ -160,6 +163,9 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_ci, (size_t)4 * nn + 64 * (size_t)h->n + 1024));
   h->h_pin_doubles = nn + 8 * (size_t)h->n + 4 * (size_t)k_max + 4 * (size_t)n_feat_max + 1024;
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin, sizeof(double) * h->h_pin_doubles));
+  h->csr_cap = 24 * (size_t)h->n;
+  HIPCHK(h, dalloc(&h->d_csr_i, (size_t)h->n + 1 + h->csr_cap));
+  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap));
   h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 64)));
@@ -181,6 +187,8 @@ extern "C" int xk_destroy(xk_handle *h) {
                   h->d_ci};
   for (void *p : ptrs)
     if (p) hipFree(p);
+  if (h->d_csr_i) hipFree(h->d_csr_i);
+  if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_ciws) hipFree(h->d_ciws);
   if (h->d_batch) hipFree(h->d_batch);
   if (h->h_batch) hipHostFree(h->h_batch);
@@ -1014,6 +1022,34 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
   HIPCHK(h, hipMemcpy2DAsync(P_j, sizeof(double) * ldpj, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   *has_ci = 1;
+  return XK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// StateManager::manage on the resident covariance
+// ---------------------------------------------------------------------------
+extern "C" int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz) {
+  if (!h || !row_ptr || nnz < 0 || (nnz > 0 && (!col_idx || !val))) return XK_EINVAL;
+  const int n = h->n;
+  if (row_ptr[0] != 0 || row_ptr[n] != nnz) return fail(h, XK_EINVAL, "CSR row pointers inconsistent with nnz");
+  if ((size_t)nnz > h->csr_cap) return fail(h, XK_ECAPACITY, "sparse operand has more than 24 n non-zeros");
+  for (int i = 0; i < n; ++i)
+    if (row_ptr[i + 1] < row_ptr[i]) return fail(h, XK_EINVAL, "CSR row pointers not monotone");
+  for (int k = 0; k < nnz; ++k)
+    if (col_idx[k] < 0 || col_idx[k] >= n) return fail(h, XK_EINVAL, "CSR column index outside the state");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->d_csr_i, row_ptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice, h->stream));
+  if (nnz) {
+    HIPCHK(h, hipMemcpyAsync(h->d_csr_i + n + 1, col_idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_csr_v, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+  }
+  XkCongArgs a{h->d_P, h->d_Pout, n, h->d_csr_i, h->d_csr_i + n + 1, h->d_csr_v};
+  hipLaunchKernelGGL(xk_congruence, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "congruence launch", e);
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller's CSR buffers are free again
+  std::swap(h->d_P, h->d_Pout);
+  h->have_rows = h->have_R = false;
   return XK_OK;
 }
 

@@ -309,6 +309,32 @@ __global__ void xk_corr(XkCorrArgs a) {
   a.corr[i] = ((s0 + s1) + (s2 + s3)) - (a.ct ? a.ct[i] : 0.0);
 }
 
+// P' = J P J^T for a sparse J in CSR (StateManager::manage, state_manager.cpp:31-149: feature removal,
+// window slide, anchor re-parametrisation and pose augmentation are all congruences with a J that is a
+// permutation / identity except for a handful of 3-row blocks with <= 15 non-zeros).  One thread per output
+// entry; same association as the reference's (J * cov) * J^T.  P column-major, ld = n.
+struct XkCongArgs {
+  const double *Pin;
+  double *Pout;
+  int n;
+  const int *rp, *ci;   // row pointers [n+1], column indices
+  const double *v;      // values
+};
+__global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)a.n * a.n) return;
+  const int r = (int)(idx % a.n), c = (int)(idx / a.n);
+  const int r0 = a.rp[r], r1 = a.rp[r + 1], c0 = a.rp[c], c1 = a.rp[c + 1];
+  double acc = 0.0;
+  for (int ib = c0; ib < c1; ++ib) {
+    const double *pb = a.Pin + (size_t)a.ci[ib] * a.n;
+    double t = 0.0;
+    for (int ia = r0; ia < r1; ++ia) t = fma(a.v[ia], pb[a.ci[ia]], t);   // (J P)[r][b]
+    acc = fma(t, a.v[ib], acc);
+  }
+  a.Pout[idx] = acc;
+}
+
 // strided copy / scale helpers
 struct XkCopyArgs {
   const double *src;

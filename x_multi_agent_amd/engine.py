@@ -26,7 +26,7 @@ SYMBOLS = [
     "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
-    "xk_ci_round_device",
+    "xk_ci_round_device", "xk_cov_congruence",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
 ]
 
@@ -323,6 +323,21 @@ class Engine:
         if hc.value:
             out["ci"] = dict(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj), H=np.ascontiguousarray(H), res=res)
         return out
+
+    def cov_congruence(self, J):
+        """Resident P <- J P J^T; J dense (n x n, mostly zeros) or a (row_ptr, col_idx, val) CSR triple."""
+        if isinstance(J, tuple):
+            rp, ci, v = J
+        else:
+            J = np.asarray(J, dtype=np.float64)
+            nz = [np.nonzero(row)[0] for row in J]
+            rp = np.concatenate([[0], np.cumsum([len(z) for z in nz])])
+            ci = np.concatenate(nz) if len(nz) else np.zeros(0, int)
+            v = np.concatenate([J[i, z] for i, z in enumerate(nz)]) if len(nz) else np.zeros(0)
+        rp_, rpp = _i(rp)
+        ci_, cip = _i(ci if len(ci) else [0])
+        v_, vp = _d(v if len(v) else [0.0])
+        self._chk(self.L.xk_cov_congruence(self.h, rpp, cip, vp, C.c_int(int(rp_[-1]))), "xk_cov_congruence")
 
     def ci_round_device(self, payloads_ptr, payload_stride, world, self_rank, tracks_ptr, n_tracks, track_len,
                         n_poses_valid, self_track, sigma_img, ci_msckf_w, want_corrections=False):

@@ -265,3 +265,48 @@ CONFIGS = {
 def make_config(cfg, agent_id=0, **kw):
     N, K, M = CONFIGS[cfg]
     return make_scenario(N, K, M, seed=seed_for(cfg, agent_id), **kw)
+
+
+def make_manage_sequence(n_poses_max, n_feat_max, n_steps, seed, start_poses=0, start_features=0, removals=None):
+    """Inputs of a run of StateManager::manage calls (state_manager.cpp:31-149): an IMU/camera rig moving along
+    the usual circle, a covariance that starts as a dense SPD matrix, `start_features` persistent features
+    anchored in the first poses of a partly filled window, and per-step lists of features to delete.
+    Returns dict(N, M, init=dict(cov, q_array, p_array, f_array, sm=dict(...)), steps=[dict(p, q, q_ic, p_ic, del)])."""
+    N, M = n_poses_max, n_feat_max
+    n = 15 + 6 * N + 3 * M
+    rng = SplitMix(seed)
+    removals = removals or {}
+    A = rng.normal(n * n).reshape(n, n)
+    cov = (A @ A.T) / n * 1e-2 + np.diag(1e-3 + 1e-2 * rng.uniform(n))
+    Rs, ps = true_poses(start_poses + n_steps + 1)
+    q_ic = _rot_to_quat_xyzw(_small_rot(np.array([0.03, -0.02, 0.05])) @ np.array([[0.0, 0, 1], [-1, 0, 0], [0, -1, 0]]))
+    p_ic = np.array([0.05, -0.02, 0.01])
+    R_ic = _quat_to_rot(q_ic)
+    q_array, p_array, f_array = np.zeros(4 * N), np.zeros(3 * N), np.zeros(3 * M)
+    for i in range(start_poses):            # window slots already occupied: camera poses of the first frames
+        q_array[4 * i:4 * i + 4] = _rot_to_quat_xyzw(Rs[i])
+        p_array[3 * i:3 * i + 3] = ps[i]
+    anchors = [-1] * M
+    for j in range(start_features):
+        anchors[j] = j % max(start_poses, 1) if j % 2 == 0 else 0
+        f_array[3 * j:3 * j + 3] = [0.1 * (rng.uniform(1)[0] - 0.5), 0.1 * (rng.uniform(1)[0] - 0.5), 1.0 / (3.0 + 4.0 * rng.uniform(1)[0])]
+    init = dict(cov=cov, q_array=q_array, p_array=p_array, f_array=f_array,
+                sm=dict(n_poses=start_poses, n_features=start_features, n_poses_max=N, n_features_max=M,
+                        anchor_idxs=anchors, filled_before=False))
+    steps = []
+    for s in range(n_steps):
+        Rc, pc = Rs[start_poses + s], ps[start_poses + s]      # camera pose; IMU pose follows from the extrinsics
+        R_i = Rc @ R_ic.T
+        steps.append(dict(p=pc - R_i @ p_ic, q=_rot_to_quat_xyzw(R_i), q_ic=q_ic, p_ic=p_ic, **{"del": list(removals.get(s, []))}))
+    return dict(N=N, M=M, init=init, steps=steps)
+
+
+MANAGE_SEQUENCES = {
+    # window fills from empty (zero-Jacobian rows of the never-filled slots), then slides
+    "manage_empty_n4_m0": dict(n_poses_max=4, n_feat_max=0, n_steps=7, seed=0x5EED3001),
+    # running filter: partly filled window, features anchored in the oldest poses, removals along the way
+    "manage_feats_n5_m4": dict(n_poses_max=5, n_feat_max=4, n_steps=8, seed=0x5EED3002, start_poses=3, start_features=4,
+                               removals={1: [1], 4: [0, 2]}),
+    # headline-sized state
+    "manage_n30_m0": dict(n_poses_max=30, n_feat_max=0, n_steps=3, seed=0x5EED3003, start_poses=29),
+}
