@@ -192,6 +192,13 @@ int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const double *C_q_
  * covariance in O(nnz(J)^2 / n + n^2).  host/src/state_manager.cpp builds the J's exactly as the reference. */
 int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz);
 
+/* Propagator::propagateCovarianceMatrices (src/x/ekf/propagator.cpp:166-205) on the resident covariance, one
+ * IMU step (and, called in a loop, Ekf::repropagateFromStateAtIdx, ekf.cpp:227-252):
+ *   P_ii <- F_d P_ii F_d^T + Q_d,  P_iv <- F_d P_iv,  P_vi <- P_vi F_d^T,  P_vv unchanged.
+ * f_d, q_d: the 15 x 15 discrete transition and process-noise matrices (column-major, ld >= 15) that
+ * Propagator::discreteStateTransition / discreteProcessNoiseCov (:110-164, :207-840) compute on the host. */
+int xk_cov_propagate(xk_handle *h, const double *f_d, int ldf, const double *q_d, int ldq);
+
 /* Device-resident CI round (MsckfUpdate::preProcessOneTrack CI block, msckf_update.cpp:96-279, followed by
  * Updater::applyCI per fused entry, updater.cpp:90-93,144-161) against the snapshots of the other agents as they
  * sit in the RCCL receive buffer -- no host staging of the n x n covariances.

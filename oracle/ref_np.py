@@ -713,3 +713,15 @@ def state_manage(sm, state, del_feat_idx=()):
     sm["n_poses"] += 1
     st.update(q_array=att, p_array=pos, f_array=feats, cov=cov)
     return sm, st
+
+
+def propagate_covariance_matrices(cov_0, f_d, q_d):
+    """Propagator::propagateCovarianceMatrices, propagator.cpp:166-205 (block form, vi computed on its own)."""
+    cov_0 = np.asarray(cov_0, float)
+    k = 15
+    cov_1 = np.empty_like(cov_0)
+    cov_1[:k, :k] = f_d @ cov_0[:k, :k] @ f_d.T + q_d      # :194
+    cov_1[:k, k:] = f_d @ cov_0[:k, k:]                    # :195
+    cov_1[k:, :k] = cov_0[k:, :k] @ f_d.T                  # :203
+    cov_1[k:, k:] = cov_0[k:, k:]                          # :204
+    return cov_1

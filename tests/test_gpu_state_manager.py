@@ -76,3 +76,28 @@ def test_cpp_state_manager_sequences(tmp_path, name, resident):
         assert rel(q_arr, g[f"s{i}_q_array"]) <= 1e-14 and rel(p_arr, g[f"s{i}_p_array"]) <= 1e-14
         if M:
             assert rel(f_arr, g[f"s{i}_f_array"]) <= 1e-12
+
+
+@pytest.mark.parametrize("N,M", [(4, 0), (10, 3), (30, 0)])
+def test_covariance_propagation_and_repropagation_loop(xk, N, M):
+    """xk_cov_propagate == Propagator::propagateCovarianceMatrices, also over the ~7 IMU steps between frames."""
+    from oracle import ref_np
+    rng = np.random.default_rng(100 + N)
+    n = 15 + 6 * N + 3 * M
+    A = rng.normal(size=(n, n))
+    P = A @ A.T / n
+    P[3, 20] += 1e-9          # the reference keeps P_vi and P_iv separate: an asymmetry must survive as such
+    eng = xk.Engine(N, M, 4)
+    eng.upload_P(P)
+    ref = P.copy()
+    for step in range(7):
+        F = np.eye(15) + 0.01 * rng.normal(size=(15, 15))
+        B = rng.normal(size=(15, 15))
+        Q = 1e-6 * (B @ B.T) + 1e-12 * rng.normal(size=(15, 15))    # "non-symmetric numerical differences in q_d"
+        eng.cov_propagate(F, Q)
+        ref = ref_np.propagate_covariance_matrices(ref, F, Q)
+    got = eng.download_P()
+    eng.close()
+    assert rel(got, ref) <= 1e-13
+    assert np.array_equal(got[15:, 15:], P[15:, 15:])           # the non-core block is carried bit for bit
+    assert got[3, 20] != got[20, 3]

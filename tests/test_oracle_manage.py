@@ -91,3 +91,20 @@ def test_feature_removal_is_a_shift_and_reanchoring_preserves_the_landmark():
             assert np.allclose(new_pt, landmark(st_before, sm_b, j), rtol=1e-12, atol=1e-12)
         else:
             assert sm_c["anchor_idxs"][j] == sm_b["anchor_idxs"][j] - 1
+
+
+def test_propagation_blocks_equal_the_full_congruence():
+    rng = np.random.default_rng(3)
+    n = 15 + 6 * 5
+    A = rng.normal(size=(n, n))
+    P = A @ A.T
+    F = np.eye(15) + 0.05 * rng.normal(size=(15, 15))
+    B = rng.normal(size=(15, 15))
+    Q = B @ B.T
+    J = np.eye(n)
+    J[:15, :15] = F
+    full = J @ P @ J.T
+    full[:15, :15] += Q
+    got = ref_np.propagate_covariance_matrices(P, F, Q)
+    assert np.allclose(got, full, rtol=1e-13, atol=1e-13 * np.abs(full).max())
+    assert np.array_equal(got[15:, 15:], P[15:, 15:])

@@ -165,7 +165,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin, sizeof(double) * h->h_pin_doubles));
   h->csr_cap = 24 * (size_t)h->n;
   HIPCHK(h, dalloc(&h->d_csr_i, (size_t)h->n + 1 + h->csr_cap));
-  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap));
+  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE));
   h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 64)));
@@ -1028,6 +1028,29 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
 // ---------------------------------------------------------------------------
 // StateManager::manage on the resident covariance
 // ---------------------------------------------------------------------------
+static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz, const double *q15) {
+  const int n = h->n;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->d_csr_i, row_ptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice, h->stream));
+  if (nnz) {
+    HIPCHK(h, hipMemcpyAsync(h->d_csr_i + n + 1, col_idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_csr_v, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+  }
+  double *dq = nullptr;
+  if (q15) {   // behind the values
+    dq = h->d_csr_v + h->csr_cap;
+    HIPCHK(h, hipMemcpyAsync(dq, q15, sizeof(double) * XK_CORE * XK_CORE, hipMemcpyHostToDevice, h->stream));
+  }
+  XkCongArgs a{h->d_P, h->d_Pout, n, h->d_csr_i, h->d_csr_i + n + 1, h->d_csr_v, dq, XK_CORE};
+  hipLaunchKernelGGL(xk_congruence, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "congruence launch", e);
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller's buffers are free again
+  std::swap(h->d_P, h->d_Pout);
+  h->have_rows = h->have_R = false;
+  return XK_OK;
+}
+
 extern "C" int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz) {
   if (!h || !row_ptr || nnz < 0 || (nnz > 0 && (!col_idx || !val))) return XK_EINVAL;
   const int n = h->n;
@@ -1037,20 +1060,31 @@ extern "C" int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *co
     if (row_ptr[i + 1] < row_ptr[i]) return fail(h, XK_EINVAL, "CSR row pointers not monotone");
   for (int k = 0; k < nnz; ++k)
     if (col_idx[k] < 0 || col_idx[k] >= n) return fail(h, XK_EINVAL, "CSR column index outside the state");
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->d_csr_i, row_ptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice, h->stream));
-  if (nnz) {
-    HIPCHK(h, hipMemcpyAsync(h->d_csr_i + n + 1, col_idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_csr_v, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+  return congruence(h, row_ptr, col_idx, val, nnz, nullptr);
+}
+
+// Propagator::propagateCovarianceMatrices (propagator.cpp:166-205) on the resident covariance:
+//   P_ii <- F P_ii F^T + Q,  P_iv <- F P_iv,  P_vi <- P_vi F^T (computed on its own, as the reference insists),  P_vv kept
+extern "C" int xk_cov_propagate(xk_handle *h, const double *f_d, int ldf, const double *q_d, int ldq) {
+  if (!h || !f_d || !q_d || ldf < XK_CORE || ldq < XK_CORE) return XK_EINVAL;
+  const int n = h->n;
+  std::vector<int> rp(n + 1), ci;
+  std::vector<double> v, q(XK_CORE * XK_CORE);
+  ci.reserve(XK_CORE * XK_CORE + n);
+  v.reserve(XK_CORE * XK_CORE + n);
+  for (int r = 0; r < n; ++r) {
+    rp[r] = (int)ci.size();
+    if (r < XK_CORE) {
+      for (int c = 0; c < XK_CORE; ++c) { ci.push_back(c); v.push_back(f_d[r + (size_t)c * ldf]); }
+    } else {
+      ci.push_back(r);
+      v.push_back(1.0);
+    }
   }
-  XkCongArgs a{h->d_P, h->d_Pout, n, h->d_csr_i, h->d_csr_i + n + 1, h->d_csr_v};
-  hipLaunchKernelGGL(xk_congruence, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(h, XK_EDEVICE, "congruence launch", e);
-  HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller's CSR buffers are free again
-  std::swap(h->d_P, h->d_Pout);
-  h->have_rows = h->have_R = false;
-  return XK_OK;
+  rp[n] = (int)ci.size();
+  for (int c = 0; c < XK_CORE; ++c)
+    for (int r = 0; r < XK_CORE; ++r) q[r + XK_CORE * c] = q_d[r + (size_t)c * ldq];
+  return congruence(h, rp.data(), ci.data(), v.data(), (int)ci.size(), q.data());
 }
 
 // ---------------------------------------------------------------------------

@@ -313,12 +313,16 @@ __global__ void xk_corr(XkCorrArgs a) {
 // window slide, anchor re-parametrisation and pose augmentation are all congruences with a J that is a
 // permutation / identity except for a handful of 3-row blocks with <= 15 non-zeros).  One thread per output
 // entry; same association as the reference's (J * cov) * J^T.  P column-major, ld = n.
+// Covariance propagation (Propagator::propagateCovarianceMatrices, propagator.cpp:166-205) is the same
+// operation with J = blkdiag(F_d, I) plus the process noise Q_d on the core block.
 struct XkCongArgs {
   const double *Pin;
   double *Pout;
   int n;
   const int *rp, *ci;   // row pointers [n+1], column indices
   const double *v;      // values
+  const double *Q;      // optional: qdim x qdim (column-major) added to the leading block (process noise)
+  int qdim;
 };
 __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
     for (int ia = r0; ia < r1; ++ia) t = fma(a.v[ia], pb[a.ci[ia]], t);   // (J P)[r][b]
     acc = fma(t, a.v[ib], acc);
   }
+  if (a.Q && r < a.qdim && c < a.qdim) acc += a.Q[r + (size_t)c * a.qdim];
   a.Pout[idx] = acc;
 }
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
-    "xk_ci_round_device", "xk_cov_congruence",
+    "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
 ]
 
@@ -338,6 +338,12 @@ class Engine:
         ci_, cip = _i(ci if len(ci) else [0])
         v_, vp = _d(v if len(v) else [0.0])
         self._chk(self.L.xk_cov_congruence(self.h, rpp, cip, vp, C.c_int(int(rp_[-1]))), "xk_cov_congruence")
+
+    def cov_propagate(self, f_d, q_d):
+        """Resident P <- blkdiag(F_d, I) P blkdiag(F_d, I)^T + blkdiag(Q_d, 0) (propagateCovarianceMatrices)."""
+        f, fp = _f(f_d)
+        q, qp = _f(q_d)
+        self._chk(self.L.xk_cov_propagate(self.h, fp, C.c_int(15), qp, C.c_int(15)), "xk_cov_propagate")
 
     def ci_round_device(self, payloads_ptr, payload_stride, world, self_rank, tracks_ptr, n_tracks, track_len,
                         n_poses_valid, self_track, sigma_img, ci_msckf_w, want_corrections=False):
