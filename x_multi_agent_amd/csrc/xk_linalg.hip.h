@@ -426,12 +426,15 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
       xk_d2 tt = {b[r], b[r + 1]};
       useg[r >> 1] = tt;
     }
+    // rows 0..KK of the part-0 lane (R entries and the pivot) do not count: one multiply by a 0/1 lane mask
+    // instead of a 64-bit select (two v_cndmask) per such row
+    const double below = (part != 0) ? 1.0 : 0.0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
-      const double v = ((part != 0) || (r > KK)) ? b[r] : 0.0;
-      if ((r & 3) == 0) s0 = fma(v, v, s0); else if ((r & 3) == 1) s1 = fma(v, v, s1);
-      else if ((r & 3) == 2) s2 = fma(v, v, s2); else s3 = fma(v, v, s3);
+      const double v = b[r], vm = (r > KK) ? v : v * below;
+      if ((r & 3) == 0) s0 = fma(vm, v, s0); else if ((r & 3) == 1) s1 = fma(vm, v, s1);
+      else if ((r & 3) == 2) s2 = fma(vm, v, s2); else s3 = fma(vm, v, s3);
     }
     const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
     if (part == 0) {
