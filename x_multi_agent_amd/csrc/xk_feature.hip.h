@@ -323,6 +323,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
 
   const int off = a_in.batch ? 0 : a.trk_off[k], L = a_in.batch ? a_in.batch[k].L : a.trk_off[k + 1] - off;
   const int m2 = 2 * L, d = m2 - 3, p0 = np - L;
+  const double chi_gate = a.chi95[d];   // fetched now: its HBM latency would otherwise sit between the gate and the tile write
 
   for (int i = tid; i < np; i += XK_FEAT_THREADS) {
     xk_quat_to_rot(a.q + 4 * i, rot + 9 * i);
@@ -722,14 +723,18 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
     const bool valid = scal[9] != 0.0 && gx == gx;
     const bool bad = scal[10] != 0.0;
     const double gam = (valid && !bad) ? g : (valid ? INFINITY : nan(""));
-    const bool inl = valid && !bad && (g < a.chi95[d]);  // :459-463
+    const bool inl = valid && !bad && (g < chi_gate);  // :459-463
     scal[11] = inl ? 1.0 : 0.0;
-    a.gamma[k] = gam;
-    a.inlier[k] = inl ? 1 : 0;
-    a.tile_rows[k] = inl ? d : 0;
+    scal[13] = gam;
   }
   XK_STAMP(6);
   __syncthreads();
+  if (tid == 64) {   // after the barrier (it would wait for these stores), overlapped with the tile write
+    const bool inl = scal[11] != 0.0;
+    a.gamma[k] = scal[13];
+    a.inlier[k] = inl ? 1 : 0;
+    a.tile_rows[k] = inl ? d : 0;
+  }
   if (a.up_out) {
     // rows 0..2 of Q^T [J | Hf | res]   (msckf_update.cpp:439-443)
     double *uj = a.up_out, *uh = a.up_out + 3 * (size_t)a.n, *ur = uh + 9;
