@@ -547,11 +547,90 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
   }
 }
 
-// (2) A-way strip merge, A = RPL strips (16 lanes per column, RPL = 20 or 40 rows per lane).
+// (2) A-way strip merge, A = RPL strips of 16 rows.  Lane layout, transposed with respect to the tile
+// kernel: 16 lanes per column, lane p holds ROW p of EVERY strip (register s = strip s).  The pivot strip
+// is then register 0 of the 16 lanes: pivot row kk sits in lane kk, so
+//   * only register 0 needs a lane mask in the norm (rows above the pivot = lanes < kk),
+//   * the lane that owns the pivot runs the scalar chain on its own register -- no broadcast --
+//     and patches ONE reflector entry afterwards (the tile layout rewrites kk/2 + 1 vector entries),
+//   * the merged 16 x 16 block / the next rows of R are one register across 16 lanes, and a strip is
+//     addressed by one uniform stride.
+// (~25 fewer instructions on the owner's path of a step; measured step time is unchanged -- the owner is
+//  not what the other waves wait for -- so this layout is kept for its simpler addressing.)
+template <int KK, int RPL>
+__device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool live, int part, double *ubuf, double *sc) {
+  constexpr int NP = 16, RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
+  double *scp = sc + pb * 4;
+  if (rel == KK) {
+    // raw column out first (the LDS write latency hides behind the reduction and the scalar chain); rows of
+    // the pivot strip above the pivot are not part of the reflector
+    const double below = (part > KK) ? 1.0 : 0.0, at_or_below = (part >= KK) ? 1.0 : 0.0;
+    {
+      xk_d2 t0 = {b[0] * at_or_below, b[1]};
+      useg[0] = t0;
+    }
+#pragma unroll
+    for (int r = 2; r < RPL; r += 2) {
+      xk_d2 tt = {b[r], b[r + 1]};
+      useg[r >> 1] = tt;
+    }
+    double s0 = (b[0] * below) * b[0], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int r = 1; r < RPL; ++r) {
+      if ((r & 3) == 0) s0 = fma(b[r], b[r], s0); else if ((r & 3) == 1) s1 = fma(b[r], b[r], s1);
+      else if ((r & 3) == 2) s2 = fma(b[r], b[r], s2); else s3 = fma(b[r], b[r], s3);
+    }
+    const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
+    if (part == KK) {
+      const double c0v = b[0];
+      double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+      if (tail > 2.2250738585072014e-308) {
+        const double n2 = fma(c0v, c0v, tail);
+        double y = __builtin_amdgcn_rsq(n2);             // ~ 1/|beta|
+        y = y * fma(-0.5 * n2 * y, y, 1.5);
+        y = y * fma(-0.5 * n2 * y, y, 1.5);
+        const double ab = n2 * y;                        // |beta|
+        beta = (c0v >= 0) ? -ab : ab;
+        vp = c0v - beta;
+        y2 = y * y;
+        tden = fma(fabs(c0v), y, 1.0);
+      }
+      ubuf[(pb * NP + part) * RPLP] = vp;                // the pivot entry of the reflector
+      xk_d2 s01 = {y2, tden};
+      *reinterpret_cast<xk_d2 *>(scp) = s01;
+      b[0] = beta;
+    }
+  }
+  __syncthreads();
+  const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
+  xk_d2 u[RPL / 2];
+#pragma unroll
+  for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+  if (rel > KK && live && s01[0] != 0.0) {
+    double rt = __builtin_amdgcn_rcp(s01[1]);
+    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+      else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+    }
+    const double w = -(s01[0] * rt) * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+    }
+  }
+}
+
 template <int RPL>
 __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArgs a) {
-  constexpr int NP = 16, RPLP = RPL + 2, ARITY = NP * RPL / 16;
-  static_assert(RPL >= 16 && RPL % 4 == 0, "the part-0 lane must hold the 16 pivot rows");
+  constexpr int NP = 16, RPLP = RPL + 2, ARITY = RPL;
+  static_assert(RPL % 2 == 0, "reflector segments are read two doubles at a time");
   __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
 #ifdef XK_CAQR_PROBE
@@ -562,36 +641,26 @@ __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
   const int col = panel ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
   const bool mine = col < a.C1 && (panel || cidx - 16 < a.chalf);
   const int base = blockIdx.x * ARITY * a.stride;
-  // Row groups of this lane: FG whole strips (strip g*16 + part -> registers 16g..16g+15) and TR rows of
-  // one of the TR tail strips (16/TR lanes share a tail strip).  A group is addressed by one base pointer
-  // and a uniform row stride: the tiles for trailing columns, the 16 x 16 panel blocks of the level below
-  // for panel columns.
-  constexpr int FG = RPL / 16, TR = RPL - 16 * FG, NG = FG + 1, PER = 16 / TR;
-  static_assert(TR > 0 && 16 % TR == 0, "lane layout");
-  const size_t rs = panel ? 16 : (size_t)a.C1P;
-  double *gp[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int s = (g < FG) ? g * 16 + part : 16 * FG + part / PER;
-    const int r0 = (g < FG) ? 0 : TR * (part % PER);
-    const int pos = base + s * a.stride;
-    gp[g] = (pos >= a.ntiles) ? nullptr
-            : panel ? const_cast<double *>(a.pin) + ((size_t)(blockIdx.x * ARITY + s) * 16 + r0) * 16 + cidx
-                    : a.A + ((size_t)pos * a.TS + r0) * a.C1P + col;
-  }
+  // strip s of this group = rows 0..15 of tile base + s*stride (trailing columns) or block
+  // blockIdx.x*ARITY + s of the level below (panel columns); this lane's row of it is `part`
+  const size_t lane_off = panel ? (size_t)part * 16 + cidx : (size_t)part * a.C1P + col;
+  const size_t strip_step = panel ? 256 : (size_t)a.stride * a.TS * a.C1P;
+  double *g0 = panel ? const_cast<double *>(a.pin) + (size_t)blockIdx.x * ARITY * 256 + lane_off
+                     : a.A + (size_t)base * a.TS * a.C1P + lane_off;
+  const int nstrips = min(ARITY, (a.ntiles - base + a.stride - 1) / a.stride);   // strips that exist
   double b[RPL];
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) {
-    const int g = (r < 16 * FG) ? r / 16 : FG, rr = (r < 16 * FG) ? r % 16 : r - 16 * FG;
-    b[r] = (mine && gp[g]) ? gp[g][rr * rs] : 0.0;
-  }
+  for (int r = 0; r < RPL; ++r) b[r] = (mine && r < nstrips) ? g0[(size_t)r * strip_step] : 0.0;
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
 #ifdef XK_CAQR_PROBE
   double sink = 0; for (int r = 0; r < RPL; ++r) sink += b[r];
   asm volatile("" :: "v"(sink));
   const long long t1 = clock64(), w1 = wall_clock64();
 #endif
-  xk_caqr_steps<NP, RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
+#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL>(b, cidx, mine, part, ubuf, sc);
+  XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
+  XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
+#undef XK_STEP
 #ifdef XK_CAQR_PROBE
   const long long w2 = wall_clock64();
   if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
@@ -601,27 +670,20 @@ __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
 #endif
   if (!mine) return;
   if (panel) {
-    // the merged panel block: rows 0..15 of the stack, held by the part-0 lanes; split 0 publishes it
-    if (part == 0 && blockIdx.y == 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const double v = (r > cidx) ? 0.0 : b[r];   // eliminated entries are not zeroed in registers
-        if (a.final_level) { if (a.c0 + r < a.C1) a.Rout[(size_t)(a.c0 + r) * a.C1P + col] = v; }
-        else a.pout[((size_t)blockIdx.x * 16 + r) * 16 + cidx] = v;
-      }
+    // the merged panel block = register 0 across the 16 lanes; split 0 publishes it
+    if (blockIdx.y == 0) {
+      const double v = (part > cidx) ? 0.0 : b[0];   // eliminated entries are not zeroed in registers
+      if (a.final_level) { if (a.c0 + part < a.C1) a.Rout[(size_t)(a.c0 + part) * a.C1P + col] = v; }
+      else a.pout[(size_t)blockIdx.x * 256 + part * 16 + cidx] = v;
     }
   } else {
-#pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-      const int g = (r < 16 * FG) ? r / 16 : FG, rr = (r < 16 * FG) ? r % 16 : r - 16 * FG;
-      if (!gp[g]) continue;
-      double v = b[r];
-      if (a.final_level && part == 0 && r < 16) {   // stacked rows 0..15 of the root group = rows c0.. of R
-        if (a.c0 + r < a.C1) a.Rout[(size_t)(a.c0 + r) * a.C1P + col] = v;
-        v = 0.0;
-      }
-      gp[g][rr * rs] = v;
+    if (a.final_level) {                              // row `part` of the root strip = row c0 + part of R
+      if (a.c0 + part < a.C1) a.Rout[(size_t)(a.c0 + part) * a.C1P + col] = b[0];
+      b[0] = 0.0;
     }
+#pragma unroll
+    for (int r = 0; r < RPL; ++r)
+      if (r < nstrips) g0[(size_t)r * strip_step] = b[r];
   }
 #ifdef XK_CAQR_PROBE
   if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
