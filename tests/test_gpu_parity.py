@@ -64,6 +64,11 @@ CASES_VS_ORACLE = {
     "caqr_401_tiles": lambda: synth.make_scenario(8, 401, 0, seed=909),
     "caqr_450_tiles_40way": lambda: synth.make_scenario(10, 450, 0, seed=910),
     "caqr_mostly_rejected": lambda: synth.make_scenario(12, 120, 0, seed=911, outlier_frac=0.7),
+    # SLAM rows only / SLAM-dominated stacks, and the two tile heights either side of the 64-row boundary
+    "slam_only_m5": lambda: synth.make_scenario(8, 0, 5, seed=1201),
+    "slam_heavy_m40": lambda: synth.make_scenario(6, 2, 40, seed=1203),
+    "tile64_last_n33": lambda: synth.make_scenario(33, 30, 0, seed=1204),
+    "tile128_first_n34": lambda: synth.make_scenario(34, 30, 0, seed=1205),
 }
 
 
