@@ -2,6 +2,8 @@
 //   Ekf::processUpdateMeasurement -> Updater::update -> VioUpdater::constructUpdate -> applyUpdate
 // Input/outputs are flat little-endian double files written/read by tests/test_gpu_host_cpp.py.
 //   in : N M K n_poses sigma_img | q[4N] p[3N] | L_k[K] | obs[2*sum L] | feat[3M] anchors[M] zlast[2M] tsz[M] | P[n*n]
+//        optionally followed by  K2 M_used | L2_k[K2] | obs2[2*sum L2]:  K2 MSCKF-SLAM tracks (features initialised in
+//        postUpdate) and the number of feature slots in use (M is then the capacity)
 //   out: P_post[n*n] | p_array[3N] q_array[4N] f_array[3M] | inlier_msckf[K]
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +61,19 @@ int main(int argc, char **argv) {
   }
   at += M;
   for (size_t i = 0; i < (size_t)n * n; ++i) s.cov_.data()[i] = in[at + i];
+  at += (size_t)n * n;
+  if (at < in.size()) {
+    const int K2 = (int)in[at++], M_used = (int)in[at++];
+    std::vector<int> L2(K2);
+    for (int k = 0; k < K2; ++k) L2[k] = (int)in[at++];
+    for (int k = 0; k < K2; ++k) {
+      Track t;
+      for (int i = 0; i < L2[k]; ++i) { t.emplace_back(in[at], in[at + 1]); at += 2; }
+      meas.new_msckf_slam_tracks.push_back(t);
+    }
+    meas.slam_tracks.resize(M_used);
+    anchors.resize(M_used);
+  }
 
   VioUpdater updater(0, N, M, K > 0 ? K : 1, sigma_img);
   updater.setWindow(n_poses, anchors);

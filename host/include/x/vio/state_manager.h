@@ -24,6 +24,13 @@ class StateManager {
   // the covariance).  resident = true: the handle's covariance is the live one and state.cov_ is not touched.
   void manage(State &state, std::vector<unsigned int> del_feat_idx, bool resident = false);   // :31-149
 
+  // After the update (VioUpdater::postUpdate, vio_updater.cpp:425-446): turn this frame's MSCKF-SLAM tracks into
+  // persistent features (state_manager.cpp:151-174) / add standard SLAM features with a prior on rho (:176-197).
+  // The covariance blocks are written on the device (xk_init_*_features); state.cov_ follows unless resident.
+  void initMsckfSlamFeatures(State &state, int n_new, const Matrix &correction, double sigma_img, bool resident = false);
+  void initStandardSlamFeatures(State &state, const Matrix &new_features, double sigma_img, double sigma_rho_0,
+                                bool resident = false);
+
   int getNPoses() const { return n_poses_; }
   int getNFeatures() const { return n_features_; }
   const std::vector<int> &getAnchorIdxs() const { return anchor_idxs_; }
@@ -47,6 +54,7 @@ class StateManager {
   void reparametrizeFeatures(const Matrix &atts_old, const Matrix &poss_old, Matrix &features);   // :351-482
   void slideWindow(Matrix &atts, Matrix &poss, int n);                   // :484-537
   void augmentCovariance(const State &state, int pos, int n);            // :273-349
+  void addFeatureStates(State &state, const double *new_features, int n_new_states);   // :199-226 (state part)
 
   int n_poses_max_, n_features_max_;
   int n_poses_ = 0, n_features_ = 0;

@@ -1,7 +1,8 @@
 // x/vio/vio_updater.h -- mirror of the concrete updater x::VioUpdater (include/x/vio/vio_updater.h:35,
 // src/x/vio/vio_updater.cpp) restricted to the hot path: measurements arrive as ready-made track lists
 // (the tracker / track manager / state manager front end is out of scope), constructUpdate runs the
-// MSCKF + SLAM builders and the QR compression on the GPU, postUpdate is a no-op.
+// MSCKF + MSCKF-SLAM + SLAM builders and the QR compression on the GPU, postUpdate initialises the new
+// persistent features.
 #pragma once
 #include <memory>
 #include <vector>
@@ -23,6 +24,7 @@ struct VioMeasurement {
   double timestamp = 0.0;
   TrackList msckf_tracks;          // full or short tracks ending at the current frame
   TrackList slam_tracks;           // one per persistent feature, newest observation last
+  TrackList new_msckf_slam_tracks; // tracks whose landmark becomes a persistent feature this frame (vio_updater.cpp:176)
   std::vector<SlamMatchInput> slam_matches;
 };
 
@@ -36,9 +38,11 @@ class VioUpdater : public Updater {
   void setMeasurement(const VioMeasurement &m) { measurement_ = m; }
   // window occupancy and SLAM anchors, kept by StateManager in the reference (state_manager.h)
   void setWindow(int n_poses, const std::vector<int> &anchor_idxs) { n_poses_ = n_poses; anchor_idxs_ = anchor_idxs; }
+  const std::vector<int> &getAnchorIdxs() const { return anchor_idxs_; }
   double getTime() const override { return measurement_.timestamp; }
   const std::vector<int> &getMsckfInlierFlags() const { return inlier_msckf_; }
   const std::vector<int> &getSlamInlierFlags() const { return inlier_slam_; }
+  xk_handle *engine() const { return xk_; }   // for the StateManager mirror, which works on the same resident covariance
 
  protected:
   void preProcess(const State &) override {}
@@ -52,7 +56,7 @@ class VioUpdater : public Updater {
   void constructShortMsckfUpdate(const State &state, Matrix &h, Matrix &res, Matrix &r) override {
     constructUpdate(state, h, res, r);                                                    // vio_updater.cpp:218-264
   }
-  void postUpdate(State &, const Matrix &) override {}
+  void postUpdate(State &state, const Matrix &correction) override;                       // vio_updater.cpp:425-446
 
  private:
   void windowLists(const State &state, std::vector<double> &q, std::vector<double> &p) const;  // state_manager.cpp:539-584

@@ -233,4 +233,37 @@ void StateManager::augmentCovariance(const State &state, int pos, int n) {
   if (pos + 1 == n_poses_max_) stateHasBeenFilledBefore_ = true;                               // :342-343
   apply(J);                                                                                    // :346-347
 }
+// state_manager.cpp:199-226 without the covariance blocks (the device wrote those)
+void StateManager::addFeatureStates(State &state, const double *new_features, int n_new_states) {
+  Matrix features = state.getFeatureArray();
+  for (int k = 0; k < n_new_states; ++k) features(3 * n_features_ + k) = new_features[k];   // :206-207
+  state.setFeatureArray(features);
+  const int n_new = n_new_states / 3;
+  for (int i = 0; i < n_new; ++i) anchor_idxs_[n_features_ + i] = n_poses_ - 1;               // :219-221
+  n_features_ += n_new;                                                                     // :223
+}
+
+void StateManager::initMsckfSlamFeatures(State &state, int n_new, const Matrix &correction, double sigma_img, bool resident) {
+  if (n_new == 0) return;
+  const int n = state.nErrorStates();
+  if (!resident) check(xk_, xk_upload_P(xk_, state.getCovariance().data(), n, n), "xk_upload_P");   // :156
+  std::vector<double> f(3 * (size_t)n_new);
+  const int rc = xk_init_msckf_slam_features(xk_, n_features_, correction.data(), sigma_img, f.data());   // :158-171
+  if (rc == XK_ESINGULAR) throw std::runtime_error(xk_last_error(xk_));   // H2 singular: camera hovering (:158-160)
+  check(xk_, rc, "xk_init_msckf_slam_features");
+  if (!resident) check(xk_, xk_download_P(xk_, state.getCovarianceRef().data(), n, n), "xk_download_P");
+  addFeatureStates(state, f.data(), 3 * n_new);                                                       // :173
+}
+
+void StateManager::initStandardSlamFeatures(State &state, const Matrix &new_features, double sigma_img, double sigma_rho_0,
+                                            bool resident) {
+  const int n_new_states = (int)new_features.size();                                                  // :180
+  if (n_new_states == 0) return;
+  const int n = state.nErrorStates();
+  if (!resident) check(xk_, xk_upload_P(xk_, state.getCovariance().data(), n, n), "xk_upload_P");
+  check(xk_, xk_init_standard_slam_features(xk_, n_features_, n_new_states / 3, sigma_img, sigma_rho_0),
+        "xk_init_standard_slam_features");                                                           // :183-193
+  if (!resident) check(xk_, xk_download_P(xk_, state.getCovarianceRef().data(), n, n), "xk_download_P");
+  addFeatureStates(state, new_features.data(), n_new_states);                                         // :196
+}
 }  // namespace x

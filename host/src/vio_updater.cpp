@@ -1,6 +1,8 @@
 // Mirror of the hot-path half of src/x/vio/vio_updater.cpp.
 #include "x/vio/vio_updater.h"
 
+#include "x/vio/state_manager.h"
+
 #include <stdexcept>
 #include <string>
 
@@ -56,6 +58,26 @@ void VioUpdater::constructUpdate(const State &state, Matrix &h, Matrix &res, Mat
   }
   check(xk_, xk_stage_slam(xk_, state.getFeatureArray().data(), anchor_idxs_.data(), tsz.data(), z.data(), M),
         "xk_stage_slam");
+  {   // MSCKF-SLAM tracks (vio_updater.cpp:311-321): their rows sit between the MSCKF and the SLAM rows (:413-419)
+    const TrackList &mt = measurement_.new_msckf_slam_tracks;
+    std::vector<int> moff(mt.size() + 1, 0);
+    std::vector<double> mobs;
+    for (size_t k = 0; k < mt.size(); ++k) {
+      moff[k + 1] = moff[k] + (int)mt[k].size();
+      for (const Feature &f : mt[k]) { mobs.push_back(f.getX()); mobs.push_back(f.getY()); }
+    }
+    check(xk_, xk_stage_msckf_slam(xk_, moff.data(), mobs.data(), (int)mt.size()), "xk_stage_msckf_slam");
+  }
+  {   // MSCKF-SLAM tracks (vio_updater.cpp:311-321): their rows sit between the MSCKF and the SLAM rows (:413-419)
+    const TrackList &mt = measurement_.new_msckf_slam_tracks;
+    std::vector<int> moff(mt.size() + 1, 0);
+    std::vector<double> mobs;
+    for (size_t k = 0; k < mt.size(); ++k) {
+      moff[k + 1] = moff[k] + (int)mt[k].size();
+      for (const Feature &f : mt[k]) { mobs.push_back(f.getX()); mobs.push_back(f.getY()); }
+    }
+    check(xk_, xk_stage_msckf_slam(xk_, moff.data(), mobs.data(), (int)mt.size()), "xk_stage_msckf_slam");
+  }
   check(xk_, xk_upload_P(xk_, state.getCovariance().data(), n, n), "xk_upload_P");   // Matrix P = state.getCovariance()
   inlier_msckf_.assign(tr.size(), 0);
   inlier_slam_.assign(M, 0);
@@ -97,4 +119,18 @@ void VioUpdater::constructSlamCIUpdate(const State &state, std::vector<std::shar
     if (inl) { H_list.push_back(H); S_list.push_back(S); res_list.push_back(res); P_list.push_back(Pj); }
   }
   measurement_.slam_matches.clear();                                    // tracker_.cleanSlamMatches()
+}
+
+// MSCKF-SLAM feature initialisation after the update (vio_updater.cpp:425-435); the standard-SLAM branch
+// (:437-446) needs the tracker's new_slam_std_trks_ and is reachable through StateManager directly.
+void VioUpdater::postUpdate(State &state, const Matrix &correction) {
+  const int n_new = (int)measurement_.new_msckf_slam_tracks.size();
+  if (n_new == 0) return;
+  const int n_existing = (int)measurement_.slam_tracks.size();
+  StateManager sm(n_poses_max_, n_feat_max_, xk_);
+  std::vector<int> anchors = anchor_idxs_;
+  anchors.resize(n_feat_max_, -1);
+  sm.restore(n_poses_, n_existing, anchors, true);
+  sm.initMsckfSlamFeatures(state, n_new, correction, sigma_img_);
+  anchor_idxs_ = sm.getAnchorIdxs();
 }

@@ -183,6 +183,29 @@ int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const double *C_q_
                       double *ci_gamma, double *H, int ldh, double *res, double *S, int lds, double *P_j,
                       int ldpj);
 
+/* ---- MSCKF-SLAM update and persistent-feature initialisation ----
+ * Tracks whose landmark becomes a persistent (SLAM) feature this frame (VioUpdater::constructUpdate,
+ * vio_updater.cpp:311-321 -> MsckfSlamUpdate, msckf_slam_update.cpp:25-267).  Staged like the MSCKF tracks
+ * (CSR of normalised observations, a length-L track sees the last L poses); xk_msckf_build then also builds
+ * their null-space rows (stacked between the MSCKF and the SLAM rows, vio_updater.cpp:413-419) and keeps the
+ * column-space rows H1, H2, r1 and the triangulated inverse-depth features on the device. */
+int xk_stage_msckf_slam(xk_handle *h, const int *trk_off, const double *obs_xy, int K2);
+/* After xk_msckf_build: per-track gate result and the MsckfSlamMatrices (types.h) -- H1 (3K2 x n, ldh1),
+ * H2 (3K2 x 3K2 block diagonal, ldh2), r1 (3K2), features (3K2); any pointer may be NULL.  H1/H2/r1 are defined
+ * up to an orthogonal 3x3 factor per track (basis of the column space); H2^-1 H1, H2^-1 r1, H2^-1 H2^-T are not. */
+int xk_msckf_slam_results(xk_handle *h, int *inlier, double *gamma, double *H1, int ldh1, double *H2, int ldh2,
+                          double *r1, double *features);
+/* StateManager::initMsckfSlamFeatures + addFeatureStates (state_manager.cpp:151-174,199-226) after the update:
+ * new_features (out, 3K2) = features - H2^-1 H1 correction + H2^-1 r1, and the covariance blocks of feature
+ * slots n_features .. n_features + K2 - 1 of the RESIDENT (posterior) covariance are set to -H2^-1 H1 P (cross)
+ * and H2^-1 H1 P (H2^-1 H1)^T + sigma_img^2 H2^-1 H2^-T.  XK_ESINGULAR if an H2 block is singular. */
+int xk_init_msckf_slam_features(xk_handle *h, int n_features, const double *correction, double sigma_img,
+                                double *new_features);
+/* StateManager::initStandardSlamFeatures + addFeatureStates (state_manager.cpp:176-226): k uncorrelated new
+ * features in slots n_features.., variances sigma_img^2, sigma_img^2, sigma_rho_0^2 (feature values:
+ * SlamUpdate::computeInverseDepthsNew, slam_update.cpp:216-242, stay on the host). */
+int xk_init_standard_slam_features(xk_handle *h, int n_features, int k, double sigma_img, double sigma_rho_0);
+
 /* ---- StateManager::manage on the resident covariance (state_manager.cpp:31-149) ----
  * Every covariance operation of manage() -- persistent-feature removal (:52-112), anchor re-parametrisation
  * (reparametrizeFeatures, :351-482), window slide (slideWindow, :484-537) and pose augmentation

@@ -390,14 +390,23 @@ def state_correct(state, corr):
     return s
 
 
-def visual_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img, slam=None):
-    """constructUpdate + applyUpdate for MSCKF (+ optional SLAM) rows,
+def visual_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img, slam=None, msckf_slam_tracks=None):
+    """constructUpdate + applyUpdate for MSCKF (+ optional MSCKF-SLAM and SLAM) rows,
     vio_updater.cpp:267-423 + updater.cpp:99-110 with iekf_iter = 1.
 
     slam: None or dict(track_sizes, z_last, feat, anchor_idxs).
+    msckf_slam_tracks: None or list of observation arrays (tracks whose feature becomes persistent);
+    their rows are stacked between the MSCKF and the SLAM rows (:413-419).
     Returns dict(P, correction, inlier, gamma, h, res, did_qr, ...)."""
     jac, res, cov, info = msckf_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img)
     out = dict(msckf=info)
+    if msckf_slam_tracks:
+        jm, rm, cm, minfo, init_mats = msckf_slam_update(msckf_slam_tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img)
+        jac = np.vstack([jac, jm])
+        res = np.concatenate([res, rm])
+        cov = np.concatenate([cov, cm])
+        out["msckf_slam"] = minfo
+        out["init_mats"] = init_mats
     if slam is not None:
         js, rs, cs, sinfo = slam_update(slam["track_sizes"], slam["z_last"], C_q_G, G_p_C,
                                         slam["feat"], slam["anchor_idxs"], P, n_poses_max,
@@ -725,3 +734,132 @@ def propagate_covariance_matrices(cov_0, f_d, q_d):
     cov_1[k:, :k] = cov_0[k:, :k] @ f_d.T                  # :203
     cov_1[k:, k:] = cov_0[k:, k:]                          # :204
     return cov_1
+
+
+# ----------------------------------------------------------------------------
+# MSCKF-SLAM update + persistent-feature initialisation
+#   MsckfSlamUpdate            src/x/vio/msckf_slam_update.cpp:25-267
+#   initMsckfSlamFeatures      src/x/vio/state_manager.cpp:151-174
+#   initStandardSlamFeatures   src/x/vio/state_manager.cpp:176-197
+#   addFeatureStates           src/x/vio/state_manager.cpp:199-226
+#   computeInverseDepthsNew    src/x/vio/slam_update.cpp:216-242
+# ----------------------------------------------------------------------------
+def msckf_slam_process_one_track(obs, C_q_G, G_p_C, P, n_poses_max, var_img):
+    """MsckfSlamUpdate::processOneTrack, msckf_slam_update.cpp:64-267: the feature is parametrised by inverse
+    depth in the LAST pose of the window (its future anchor), so every earlier observation also has Jacobian
+    blocks on that pose; no observability constraint is applied.  Returns dict(inlier, gamma, jac0, res0, H1,
+    H2, r1, feature, gn_iters)."""
+    L = len(obs)
+    n = P.shape[1]
+    npz = len(C_q_G)
+    q_l, p_l = C_q_G[npz - L:], G_p_C[npz - L:]
+    ivd, it = triangulate_gn(q_l, p_l, obs)                                   # :82
+    al, be, rho = ivd
+    R_n = quat_to_rot(C_q_G[-1])                                              # anchor = last pose, :88-94
+    p_n = np.asarray(G_p_C[-1], float)
+    gpf = (1.0 / rho) * R_n @ np.array([al, be, 1.0]) + p_n                   # :97-99
+    h = np.zeros((2 * L, n))
+    hf = np.zeros((2 * L, 3))
+    res = np.zeros(2 * L)
+    N3 = 3 * n_poses_max
+    for i in range(L):
+        pos = npz - L + i                                                     # :105
+        R_i = quat_to_rot(C_q_G[pos])
+        p_i = np.asarray(G_p_C[pos], float)
+        c = R_i.T @ (gpf - p_i)                                               # :111-113
+        res[2 * i:2 * i + 2] = np.asarray(obs[i], float) - np.array([c[0] / c[2], c[1] / c[2]])   # :116-127
+        if i == L - 1:                                                        # :133-142
+            hf[2 * i:2 * i + 2] = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+            continue
+        Ji = np.array([[1.0 / c[2], 0.0, -c[0] / c[2] ** 2], [0.0, 1.0 / c[2], -c[1] / c[2] ** 2]])   # :145-153
+        J_att = Ji @ skew(c)                                                  # :156-160
+        J_pos = -Ji @ R_i.T                                                   # :163-164
+        J_anchor_att = -(1.0 / rho) * Ji @ R_i.T @ R_n @ skew([al, be, 1.0])  # :167-170
+        J_anchor_pos = -J_pos                                                 # :173
+        mat = np.eye(3)
+        mat[0, 2], mat[1, 2], mat[2, 2] = -al / rho, -be / rho, -1.0 / rho
+        hf[2 * i:2 * i + 2] = (1.0 / rho) * Ji @ R_i.T @ R_n @ mat            # :176-183
+        h[2 * i:2 * i + 2, 15 + 3 * pos:15 + 3 * pos + 3] = J_pos             # :189-190
+        h[2 * i:2 * i + 2, 15 + 3 * pos + N3:15 + 3 * pos + N3 + 3] = J_att   # :192-193
+        a = npz - 1
+        h[2 * i:2 * i + 2, 15 + 3 * a:15 + 3 * a + 3] = J_anchor_pos          # :195-196
+        h[2 * i:2 * i + 2, 15 + 3 * a + N3:15 + 3 * a + N3 + 3] = J_anchor_att   # :198-199
+    a_up, a_null = left_nullspace(hf)                                         # :206-207
+    res0, h0 = a_null.T @ res, a_null.T @ h                                   # :210-211
+    H1, H2, r1 = a_up.T @ h, a_up.T @ hf, a_up.T @ res                        # :224-233
+    d = 2 * L - 3
+    S = h0 @ P @ h0.T + var_img * np.eye(d)                                   # :243
+    gamma = float(res0 @ np.linalg.inv(S) @ res0)
+    return dict(inlier=gamma < chi2inv(0.95, d), gamma=gamma, jac0=h0, res0=res0, H1=H1, H2=H2, r1=r1,
+                feature=np.asarray(ivd, float), gn_iters=it)
+
+
+def msckf_slam_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img):
+    """MsckfSlamUpdate ctor, msckf_slam_update.cpp:25-62.  Returns (jac, res, cov_diag, info, init_mats);
+    init_mats (H1, H2 block diagonal, r1, features) is filled for EVERY track, gated out or not."""
+    k = len(tracks)
+    n = P.shape[1]
+    rows0 = 2 * sum(len(t) for t in tracks) - 3 * k
+    jac, cov_diag, res = np.zeros((rows0, n)), np.ones(rows0), np.zeros(rows0)
+    H1, H2, r1, feats = np.zeros((3 * k, n)), np.zeros((3 * k, 3 * k)), np.zeros(3 * k), np.zeros(3 * k)
+    var_img = sigma_img * sigma_img
+    inlier, gamma = np.zeros(k, np.int32), np.zeros(k)
+    row_h = 0
+    for j, trk in enumerate(tracks):
+        o = msckf_slam_process_one_track(trk, C_q_G, G_p_C, P, n_poses_max, var_img)
+        H1[3 * j:3 * j + 3], H2[3 * j:3 * j + 3, 3 * j:3 * j + 3], r1[3 * j:3 * j + 3] = o["H1"], o["H2"], o["r1"]
+        feats[3 * j:3 * j + 3] = o["feature"]
+        gamma[j] = o["gamma"]
+        if o["inlier"]:
+            d = 2 * len(trk) - 3
+            jac[row_h:row_h + d], res[row_h:row_h + d], cov_diag[row_h:row_h + d] = o["jac0"], o["res0"], var_img
+            row_h += d
+            inlier[j] = 1
+    return jac, res, cov_diag, dict(inlier=inlier, gamma=gamma, rows_used=row_h), dict(H1=H1, H2=H2, r1=r1, features=feats)
+
+
+def sm_add_feature_states(sm, state, new_features, cov_new, cross):
+    """StateManager::addFeatureStates, state_manager.cpp:199-226 (modifies sm and state)."""
+    N = sm["n_poses_max"]
+    k3 = len(new_features)
+    nf = sm["n_features"]
+    state["f_array"][3 * nf:3 * nf + k3] = new_features
+    P = state["cov"]
+    ns = 15 + 6 * N + 3 * nf
+    P[ns:ns + k3, :] = cross
+    P[:, ns:ns + k3] = cross.T
+    P[ns:ns + k3, ns:ns + k3] = cov_new
+    for i in range(k3 // 3):
+        sm["anchor_idxs"][nf + i] = sm["n_poses"] - 1
+    sm["n_features"] = nf + k3 // 3
+
+
+def sm_init_msckf_slam_features(sm, state, init_mats, correction, sigma_img):
+    """StateManager::initMsckfSlamFeatures, state_manager.cpp:151-174."""
+    sm = dict(sm, anchor_idxs=list(sm["anchor_idxs"]))
+    st = {k: (np.array(v, dtype=float, copy=True) if not np.isscalar(v) else v) for k, v in state.items()}
+    P = st["cov"]
+    H2_inv = np.linalg.inv(init_mats["H2"])
+    G = H2_inv @ init_mats["H1"]
+    new_features = init_mats["features"] - G @ correction + H2_inv @ init_mats["r1"]
+    var_img = sigma_img * sigma_img
+    P_cross = -G @ P
+    P_diag = G @ P @ G.T + var_img * H2_inv @ H2_inv.T
+    sm_add_feature_states(sm, st, new_features, P_diag, P_cross)
+    return sm, st
+
+
+def sm_init_standard_slam_features(sm, state, last_obs, rho_0, sigma_img, sigma_rho_0):
+    """computeInverseDepthsNew (slam_update.cpp:216-242) + initStandardSlamFeatures (state_manager.cpp:176-197)."""
+    sm = dict(sm, anchor_idxs=list(sm["anchor_idxs"]))
+    st = {k: (np.array(v, dtype=float, copy=True) if not np.isscalar(v) else v) for k, v in state.items()}
+    k = len(last_obs)
+    ivds = np.zeros(3 * k)
+    for j, z in enumerate(last_obs):
+        ivds[3 * j:3 * j + 3] = [z[0], z[1], rho_0]
+    n = st["cov"].shape[0]
+    P_diag = sigma_img ** 2 * np.eye(3 * k)
+    for j in range(k):
+        P_diag[3 * j + 2, 3 * j + 2] = sigma_rho_0 ** 2
+    sm_add_feature_states(sm, st, ivds, P_diag, np.zeros((3 * k, n)))
+    return sm, st

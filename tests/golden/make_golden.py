@@ -109,6 +109,36 @@ def manage_cases():
         print(name, "steps", len(seq["steps"]), "final n_poses", sm["n_poses"], "n_features", sm["n_features"], sm["anchor_idxs"])
 
 
+def msckf_slam_case():
+    """MSCKF + MSCKF-SLAM + SLAM rows in one update, then the new features are initialised."""
+    N, M = 8, 6
+    sc = synth.make_scenario(N, 14, 3, seed=0x5EED4001)
+    tr = synth.tracks_as_list(sc)
+    n = 15 + 6 * N + 3 * M
+    P = np.zeros((n, n))
+    n0 = sc["P"].shape[0]                      # the scenario's prior covers the 3 existing features
+    P[:n0, :n0] = sc["P"]
+    feat = np.zeros(3 * M); feat[:9] = sc["slam_feat"]
+    slam = dict(track_sizes=sc["slam_track_sizes"], z_last=sc["slam_z_last"], feat=feat, anchor_idxs=sc["slam_anchor_idxs"])
+    out = ref_np.visual_update(tr[:10], sc["C_q_G"], sc["G_p_C"], P, N, sc["sigma_img"], slam=slam, msckf_slam_tracks=tr[10:13])
+    im = out["init_mats"]
+    H2i = np.linalg.inv(im["H2"])
+    sm = dict(n_poses=N, n_features=3, n_poses_max=N, n_features_max=M, anchor_idxs=list(sc["slam_anchor_idxs"]) + [-1] * 3,
+              filled_before=True)
+    st = dict(p=np.zeros(3), q=np.array([0, 0, 0, 1.0]), q_ic=np.array([0, 0, 0, 1.0]), p_ic=np.zeros(3),
+              q_array=np.zeros(4 * N), p_array=np.zeros(3 * N), f_array=feat.copy(), cov=out["P"])
+    sm1, st1 = ref_np.sm_init_msckf_slam_features(sm, st, im, out["correction"], sc["sigma_img"])
+    sm2, st2 = ref_np.sm_init_standard_slam_features(sm, st, [t[-1] for t in tr[10:12]], 0.2, sc["sigma_img"], 0.4)
+    d = {k: sc[k] for k in INPUT_KEYS if k in sc}
+    d.update(n_poses_max=N, n_feat_max=M, sigma_img=sc["sigma_img"], P_full=P, feat_full=feat,
+             exp_inlier=out["msckf"]["inlier"], exp_inlier_ms=out["msckf_slam"]["inlier"], exp_gamma_ms=out["msckf_slam"]["gamma"],
+             exp_inlier_slam=out["slam"]["inlier"], exp_G=H2i @ im["H1"], exp_g=H2i @ im["r1"], exp_HH=H2i @ H2i.T,
+             exp_features=im["features"], exp_correction=out["correction"], exp_P=out["P"],
+             exp_new_features=st1["f_array"], exp_P_init=st1["cov"], exp_P_std=st2["cov"])
+    np.savez_compressed(os.path.join(HERE, "msckf_slam_n8.npz"), **d)
+    print("msckf_slam_n8", out["msckf_slam"], "new features", np.round(st1["f_array"][9:], 4))
+
+
 if __name__ == "__main__":
     visual_case("cfg1_n10_k50", synth.make_config(1))
     visual_case("slam_n8_k30_m6", synth.make_scenario(8, 30, 6, seed=77))
@@ -119,3 +149,4 @@ if __name__ == "__main__":
     visual_case("all_outliers_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress"))
     ci_cases()
     manage_cases()
+    msckf_slam_case()

@@ -13,6 +13,7 @@
 
 #include "xk_chi2_table.h"
 #include "xk_feature.hip.h"
+#include "xk_slaminit.hip.h"
 #include "xk_linalg.hip.h"
 #include "xk_ci.hip.h"
 
@@ -51,6 +52,11 @@ struct xk_handle {
   XkFeatBatch *d_batch;    // per-agent descriptors of the batched feature launch, [8 tracks][8 agents]
   XkFeatBatch *h_batch;    // pinned staging of the same
   int *h_trk_off;          // host copy of the staged track offsets
+  // MSCKF-SLAM tracks (features being initialised this frame)
+  int K2;
+  bool ms_built;           // their column-space rows on the device belong to the staged tracks
+  int *d_trk2_off, *h_trk2_off, *d_inl2, *d_gn2;
+  double *d_obs2, *d_gpf2, *d_W2, *d_gam2, *d_H1, *d_H2, *d_r1, *d_feat2;
   int *d_csr_i;            // sparse congruence operand: row pointers then column indices
   double *d_csr_v;         //   and values
   size_t csr_cap;          //   capacity in non-zeros
@@ -116,7 +122,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   const int dmax = 2 * n_poses_max - 3;
   h->DB = dmax <= 64 ? 64 : 128;   // rows per tile slot (one track per tile; SLAM rows are packed DB per tile)
   const int slam_tiles = (2 * n_feat_max + h->DB - 1) / h->DB;
-  h->ntiles_max = k_max + slam_tiles;
+  h->ntiles_max = k_max + n_feat_max + slam_tiles;   // MSCKF tracks, MSCKF-SLAM tracks, packed SLAM rows
   h->CM = round_up(h->n + 1, 16);
   h->LDA = h->CM + round_up(h->n + 1, 16);
   HIPCHK(h, hipSetDevice(device));
@@ -163,9 +169,25 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_ci, (size_t)4 * nn + 64 * (size_t)h->n + 1024));
   h->h_pin_doubles = nn + 8 * (size_t)h->n + 4 * (size_t)k_max + 4 * (size_t)n_feat_max + 1024;
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin, sizeof(double) * h->h_pin_doubles));
-  h->csr_cap = 24 * (size_t)h->n;
+  h->csr_cap = 24 * (size_t)h->n + 3 * (size_t)n_feat_max * h->n;
+  {
+    const size_t m = (size_t)std::max(n_feat_max, 1);
+    HIPCHK(h, dalloc(&h->d_trk2_off, m + 1));
+    HIPCHK(h, dalloc(&h->d_inl2, m));
+    HIPCHK(h, dalloc(&h->d_gn2, m));
+    HIPCHK(h, dalloc(&h->d_obs2, 2 * m * n_poses_max));
+    HIPCHK(h, dalloc(&h->d_gpf2, 3 * m));
+    HIPCHK(h, dalloc(&h->d_W2, m * h->DB * h->na));
+    HIPCHK(h, dalloc(&h->d_gam2, m));
+    HIPCHK(h, dalloc(&h->d_H1, 3 * m * h->n));
+    HIPCHK(h, dalloc(&h->d_H2, 9 * m));
+    HIPCHK(h, dalloc(&h->d_r1, 3 * m));
+    HIPCHK(h, dalloc(&h->d_feat2, 3 * m));
+    h->h_trk2_off = (int *)calloc(m + 1, sizeof(int));
+    if (!h->h_trk2_off) return fail(h, XK_ENOMEM, "host track offsets");
+  }
   HIPCHK(h, dalloc(&h->d_csr_i, (size_t)h->n + 1 + h->csr_cap));
-  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE));
+  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max));
   h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 64)));
@@ -187,6 +209,10 @@ extern "C" int xk_destroy(xk_handle *h) {
                   h->d_ci};
   for (void *p : ptrs)
     if (p) hipFree(p);
+  for (void *p2 : {(void *)h->d_trk2_off, (void *)h->d_inl2, (void *)h->d_gn2, (void *)h->d_obs2, (void *)h->d_gpf2, (void *)h->d_W2,
+                   (void *)h->d_gam2, (void *)h->d_H1, (void *)h->d_H2, (void *)h->d_r1, (void *)h->d_feat2})
+    if (p2) hipFree(p2);
+  free(h->h_trk2_off);
   if (h->d_csr_i) hipFree(h->d_csr_i);
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_ciws) hipFree(h->d_ciws);
@@ -214,6 +240,7 @@ extern "C" int xk_stage_window(xk_handle *h, const double *C_q_G, const double *
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->n_poses = n_poses;
   h->have_rows = h->have_R = false;
+  h->ms_built = false;
   return XK_OK;
 }
 
@@ -259,6 +286,147 @@ extern "C" int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor
   return XK_OK;
 }
 
+// MSCKF-SLAM tracks: the tracks whose feature becomes a persistent (SLAM) feature this frame
+// (VioUpdater::constructUpdate, vio_updater.cpp:311-321).
+extern "C" int xk_stage_msckf_slam(xk_handle *h, const int *trk_off, const double *obs_xy, int K2) {
+  if (!h || K2 < 0 || (K2 > 0 && (!trk_off || !obs_xy))) return XK_EINVAL;
+  if (K2 > h->Mmax) return fail(h, XK_ECAPACITY, "more MSCKF-SLAM tracks than feature slots");
+  int lmax = 0;
+  if (K2 > 0) {
+    if (trk_off[0] != 0) return fail(h, XK_EINVAL, "trk_off[0] != 0");
+    for (int k = 0; k < K2; ++k) {
+      const int L = trk_off[k + 1] - trk_off[k];
+      if (L < 2 || L > h->N) return fail(h, XK_EINVAL, "track length outside [2, n_poses_max]");
+      lmax = std::max(lmax, L);
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d_trk2_off, trk_off, sizeof(int) * (K2 + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_obs2, obs_xy, sizeof(double) * 2 * trk_off[K2], hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(h->h_trk2_off, trk_off, sizeof(int) * (K2 + 1));
+  }
+  h->K2 = K2;
+  h->ms_built = false;
+  h->h_pin_i[1] = lmax;
+  h->have_rows = h->have_R = false;
+  return XK_OK;
+}
+
+extern "C" int xk_msckf_slam_results(xk_handle *h, int *inlier, double *gamma, double *H1, int ldh1, double *H2, int ldh2,
+                                     double *r1, double *features) {
+  if (!h) return XK_EINVAL;
+  const int k = h->K2, n = h->n;
+  if (k == 0) return XK_OK;
+  if (!h->ms_built) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged MSCKF-SLAM tracks");
+  if ((H1 && ldh1 < 3 * k) || (H2 && ldh2 < 3 * k)) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> h1((size_t)3 * k * n), h2((size_t)9 * k);
+  if (inlier) HIPCHK(h, hipMemcpyAsync(inlier, h->d_inl2, sizeof(int) * k, hipMemcpyDeviceToHost, h->stream));
+  if (gamma) HIPCHK(h, hipMemcpyAsync(gamma, h->d_gam2, sizeof(double) * k, hipMemcpyDeviceToHost, h->stream));
+  if (r1) HIPCHK(h, hipMemcpyAsync(r1, h->d_r1, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, h->stream));
+  if (features) HIPCHK(h, hipMemcpyAsync(features, h->d_feat2, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h1.data(), h->d_H1, sizeof(double) * h1.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h2.data(), h->d_H2, sizeof(double) * h2.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (H1)     // device: [track][3][n] row-major -> (3k x n) column-major
+    for (int j = 0; j < k; ++j)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < n; ++c) H1[(size_t)(3 * j + r) + (size_t)c * ldh1] = h1[((size_t)j * 3 + r) * n + c];
+  if (H2) {   // block diagonal (msckf_slam_update.cpp:231)
+    for (int c = 0; c < 3 * k; ++c)
+      for (int r = 0; r < 3 * k; ++r) H2[r + (size_t)c * ldh2] = 0.0;
+    for (int j = 0; j < k; ++j)
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) H2[(size_t)(3 * j + r) + (size_t)(3 * j + c) * ldh2] = h2[9 * (size_t)j + r + 3 * c];
+  }
+  return XK_OK;
+}
+
+static bool inv3(const double *a /*col-major*/, double *o) {
+  const double c00 = a[4] * a[8] - a[7] * a[5], c01 = a[7] * a[2] - a[1] * a[8], c02 = a[1] * a[5] - a[4] * a[2];
+  const double det = a[0] * c00 + a[3] * c01 + a[6] * c02;
+  if (!(fabs(det) > 0.0)) return false;
+  const double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (a[6] * a[5] - a[3] * a[8]) * id; o[4] = (a[0] * a[8] - a[6] * a[2]) * id; o[5] = (a[3] * a[2] - a[0] * a[5]) * id;
+  o[6] = (a[3] * a[7] - a[6] * a[4]) * id; o[7] = (a[6] * a[1] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[3] * a[1]) * id;
+  return true;
+}
+
+static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz, const double *q,
+                      int qdim, int qoff);
+
+// StateManager::initMsckfSlamFeatures + addFeatureStates (state_manager.cpp:151-174,199-226) on the resident
+// covariance: with G = H2^-1 H1 the new feature states are  f - G corr + H2^-1 r1,  their covariance blocks
+// -G P (cross) and G P G^T + sigma^2 H2^-1 H2^-T (diagonal) -- one congruence with J = [I; -G] on the rows of
+// the new features plus the noise block.
+extern "C" int xk_init_msckf_slam_features(xk_handle *h, int n_features, const double *correction, double sigma_img,
+                                           double *new_features) {
+  if (!h || !correction || !new_features || n_features < 0 || !(sigma_img > 0.0)) return XK_EINVAL;
+  const int k = h->K2, n = h->n;
+  if (k == 0) return XK_OK;
+  if (!h->ms_built) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged MSCKF-SLAM tracks");
+  if (n_features + k > h->Mmax) return fail(h, XK_ECAPACITY, "not enough free feature slots");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> h1((size_t)3 * k * n), h2((size_t)9 * k), r1((size_t)3 * k), f((size_t)3 * k);
+  HIPCHK(h, hipMemcpyAsync(h1.data(), h->d_H1, sizeof(double) * h1.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h2.data(), h->d_H2, sizeof(double) * h2.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(r1.data(), h->d_r1, sizeof(double) * r1.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(f.data(), h->d_feat2, sizeof(double) * f.size(), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const int ns = XK_CORE + 6 * h->N + 3 * n_features;     // first row of the new features
+  const double var_img = sigma_img * sigma_img;
+  std::vector<double> G((size_t)3 * k * n, 0.0), Q((size_t)9 * k * k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    double hi[9];
+    if (!inv3(&h2[9 * (size_t)j], hi)) return fail(h, XK_ESINGULAR, "H2 is singular (camera hovering)");   // state_manager.cpp:158-160
+    for (int r = 0; r < 3; ++r) {
+      double *g = &G[((size_t)3 * j + r) * n];
+      for (int c = 0; c < n; ++c)
+        g[c] = hi[r] * h1[((size_t)j * 3) * n + c] + hi[r + 3] * h1[((size_t)j * 3 + 1) * n + c] + hi[r + 6] * h1[((size_t)j * 3 + 2) * n + c];
+      double fr = f[3 * j + r] + hi[r] * r1[3 * j] + hi[r + 3] * r1[3 * j + 1] + hi[r + 6] * r1[3 * j + 2];
+      for (int c = 0; c < n; ++c) fr -= g[c] * correction[c];
+      new_features[3 * j + r] = fr;
+      for (int c2 = 0; c2 < 3; ++c2)      // sigma^2 H2^-1 H2^-T, block (j, j)
+        Q[(size_t)(3 * j + r) + (size_t)(3 * j + c2) * 3 * k] = var_img * (hi[r] * hi[c2] + hi[r + 3] * hi[c2 + 3] + hi[r + 6] * hi[c2 + 6]);
+    }
+  }
+  std::vector<int> rp(n + 1), ci;
+  std::vector<double> v;
+  for (int r = 0; r < n; ++r) {
+    rp[r] = (int)ci.size();
+    if (r >= ns && r < ns + 3 * k) {
+      const double *g = &G[(size_t)(r - ns) * n];
+      for (int c = 0; c < n; ++c)
+        if (g[c] != 0.0) { ci.push_back(c); v.push_back(-g[c]); }
+    } else {
+      ci.push_back(r);
+      v.push_back(1.0);
+    }
+  }
+  rp[n] = (int)ci.size();
+  if (ci.size() > h->csr_cap) return fail(h, XK_ECAPACITY, "sparse operand too large");
+  return congruence(h, rp.data(), ci.data(), v.data(), (int)ci.size(), Q.data(), 3 * k, ns);
+}
+
+// StateManager::initStandardSlamFeatures + addFeatureStates (state_manager.cpp:176-226): k new features with no
+// correlation to the rest, variances sigma_img^2, sigma_img^2, sigma_rho_0^2.
+extern "C" int xk_init_standard_slam_features(xk_handle *h, int n_features, int k, double sigma_img, double sigma_rho_0) {
+  if (!h || n_features < 0 || k < 0) return XK_EINVAL;
+  if (k == 0) return XK_OK;
+  if (n_features + k > h->Mmax) return fail(h, XK_ECAPACITY, "not enough free feature slots");
+  const int n = h->n, ns = XK_CORE + 6 * h->N + 3 * n_features;
+  std::vector<int> rp(n + 1), ci;
+  std::vector<double> v, Q((size_t)9 * k * k, 0.0);
+  for (int r = 0; r < n; ++r) {
+    rp[r] = (int)ci.size();
+    if (r < ns || r >= ns + 3 * k) { ci.push_back(r); v.push_back(1.0); }
+  }
+  rp[n] = (int)ci.size();
+  for (int j = 0; j < 3 * k; ++j) Q[(size_t)j + (size_t)j * 3 * k] = (j % 3 == 2) ? sigma_rho_0 * sigma_rho_0 : sigma_img * sigma_img;
+  return congruence(h, rp.data(), ci.data(), v.data(), (int)ci.size(), Q.data(), 3 * k, ns);
+}
+
 extern "C" int xk_upload_P(xk_handle *h, const double *P, int ldp, int n) {
   if (!h || !P || n != h->n || ldp < n) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
@@ -297,19 +465,39 @@ static int launch_build(xk_handle *h, double sigma_img) {
     const size_t lds = xk_feature_lds_bytes(h->n_poses);
     hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
   }
+  if (h->K2 > 0) {   // tracks that become persistent features this frame: tiles K .. K + K2 - 1
+    if (h->h_pin_i[1] > h->n_poses) return fail(h, XK_EINVAL, "MSCKF-SLAM track longer than the staged window");
+    XkTriMultiArgs ta{h->d_q, h->d_p, h->d_obs2, 0, h->d_gpf2, h->d_gn2, h->d_trk2_off, h->n_poses};
+    hipLaunchKernelGGL(xk_triangulate_multi, dim3(h->K2), dim3(64), 0, h->stream, ta);
+    XkSlamInitArgs a;
+    a.q = h->d_q; a.p = h->d_p; a.n_poses = h->n_poses; a.n_poses_max = h->N;
+    a.trk_off = h->d_trk2_off; a.obs = h->d_obs2; a.gpf = h->d_gpf2;
+    a.P = h->d_P; a.n = h->n; a.na = h->na; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
+    a.A = h->d_A + (size_t)h->K * h->DB * h->C1P; a.DB = h->DB; a.C1P = h->C1P; a.W = h->d_W2;
+    a.tile_rows = h->d_tile_rows + h->K; a.inlier = h->d_inl2; a.gamma = h->d_gam2;
+    a.H1 = h->d_H1; a.H2 = h->d_H2; a.r1 = h->d_r1; a.features = h->d_feat2;
+    const size_t lds = xk_slaminit_lds_bytes(h->n_poses);
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipFuncSetAttribute((const void *)xk_msckf_slam_init, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(xk_msckf_slam_init, dim3(h->K2), dim3(XK_FEAT_THREADS), lds, h->stream, a);
+    h->ms_built = true;
+  }
   if (h->M > 0) {
     XkSlamArgs s;
     s.q = h->d_q; s.p = h->d_p; s.n_poses = h->n_poses; s.n_poses_max = h->N;
     s.feat = h->d_feat; s.anchor_idxs = h->d_anchor; s.track_sizes = h->d_tsz; s.z_last = h->d_zlast; s.M = h->M;
     s.P = h->d_P; s.n = h->n; s.var_img = sigma_img * sigma_img; s.chi90 = h->d_chi90; s.chi_len = XK_CHI2_LEN;
-    s.A = h->d_A + (size_t)h->K * h->DB * h->C1P; s.DB = h->DB; s.C1P = h->C1P; s.na = h->na;
+    s.A = h->d_A + (size_t)(h->K + h->K2) * h->DB * h->C1P; s.DB = h->DB; s.C1P = h->C1P; s.na = h->na;
     s.inlier = h->d_inl_s; s.gamma = h->d_gam_s;
     hipLaunchKernelGGL(xk_slam_rows, dim3(h->M), dim3(64), 0, h->stream, s);
     // rows per SLAM tile (gated-out features leave zero rows, as in the reference)
     std::vector<int> tr(slam_tiles);
     for (int t = 0; t < slam_tiles; ++t) tr[t] = std::min(h->DB, 2 * h->M - t * h->DB);
     for (int t = 0; t < slam_tiles; ++t) h->h_pin_i[8 + t] = tr[t];
-    if (hipMemcpyAsync(h->d_tile_rows + h->K, h->h_pin_i + 8, sizeof(int) * slam_tiles, hipMemcpyHostToDevice,
+    if (hipMemcpyAsync(h->d_tile_rows + h->K + h->K2, h->h_pin_i + 8, sizeof(int) * slam_tiles, hipMemcpyHostToDevice,
                        h->stream) != hipSuccess)
       return fail(h, XK_EDEVICE, "tile_rows upload");
   }
@@ -335,7 +523,7 @@ static int env_int(const char *name, int dflt) {
 static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
-  const int ntiles = h->K + slam_tiles;
+  const int ntiles = h->K + h->K2 + slam_tiles;
   // (d_R was zeroed at creation; the merges rewrite the whole upper trapezoid every update and nothing else)
   XkCaqrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles; a.TS = h->DB;
@@ -595,6 +783,7 @@ extern "C" int xk_visual_update(xk_handle *h, const double *C_q_G, const double 
   if ((rc = xk_stage_window(h, C_q_G, G_p_C, n_poses)) != XK_OK) return rc;
   if ((rc = xk_stage_tracks(h, trk_off, obs_xy, K)) != XK_OK) return rc;
   if ((rc = xk_stage_slam(h, feat, anchor_idxs, track_sizes, z_last, M)) != XK_OK) return rc;
+  if ((rc = xk_stage_msckf_slam(h, nullptr, nullptr, 0)) != XK_OK) return rc;   // this entry point has no MSCKF-SLAM tracks
   if ((rc = xk_upload_P(h, P, ldp, n)) != XK_OK) return rc;
   if ((rc = xk_visual_update_staged(h, sigma_img, correction, inlier_msckf, gamma_msckf, inlier_slam,
                                     gamma_slam)) != XK_OK)
@@ -717,7 +906,7 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
   // stacked rows actually folded (inlier rows)
   {
     const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
-    std::vector<int> tr(h->K + slam_tiles);
+    std::vector<int> tr(h->K + h->K2 + slam_tiles);
     HIPCHK(h, hipMemcpy(tr.data(), h->d_tile_rows, sizeof(int) * tr.size(), hipMemcpyDeviceToHost));
     int rows = 0;
     for (int v : tr) rows += v;
@@ -922,7 +1111,7 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
   HIPCHK(h, hipMemcpyAsync(dq + 4 * at, C_q_G + 4 * (size_t)(n_poses - L), sizeof(double) * 4 * L, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(dp + 3 * at, G_p_C + 3 * (size_t)(n_poses - L), sizeof(double) * 3 * L, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(dobs + 2 * at, obs, sizeof(double) * 2 * L, hipMemcpyHostToDevice, h->stream));
-  XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint};
+  XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint, nullptr, 0};
   hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, h->stream, ta);
   // per-agent column-space rows (self first = row block 0, then the matched agents, :168-204)
   const int offs[2] = {0, 0};
@@ -1028,7 +1217,8 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
 // ---------------------------------------------------------------------------
 // StateManager::manage on the resident covariance
 // ---------------------------------------------------------------------------
-static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz, const double *q15) {
+static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, const double *val, int nnz, const double *q,
+                      int qdim, int qoff) {
   const int n = h->n;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(h->d_csr_i, row_ptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice, h->stream));
@@ -1037,11 +1227,11 @@ static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, cons
     HIPCHK(h, hipMemcpyAsync(h->d_csr_v, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
   }
   double *dq = nullptr;
-  if (q15) {   // behind the values
+  if (q) {   // additive block, stored behind the values
     dq = h->d_csr_v + h->csr_cap;
-    HIPCHK(h, hipMemcpyAsync(dq, q15, sizeof(double) * XK_CORE * XK_CORE, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dq, q, sizeof(double) * (size_t)qdim * qdim, hipMemcpyHostToDevice, h->stream));
   }
-  XkCongArgs a{h->d_P, h->d_Pout, n, h->d_csr_i, h->d_csr_i + n + 1, h->d_csr_v, dq, XK_CORE};
+  XkCongArgs a{h->d_P, h->d_Pout, n, h->d_csr_i, h->d_csr_i + n + 1, h->d_csr_v, dq, qdim, qoff};
   hipLaunchKernelGGL(xk_congruence, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "congruence launch", e);
@@ -1060,7 +1250,7 @@ extern "C" int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *co
     if (row_ptr[i + 1] < row_ptr[i]) return fail(h, XK_EINVAL, "CSR row pointers not monotone");
   for (int k = 0; k < nnz; ++k)
     if (col_idx[k] < 0 || col_idx[k] >= n) return fail(h, XK_EINVAL, "CSR column index outside the state");
-  return congruence(h, row_ptr, col_idx, val, nnz, nullptr);
+  return congruence(h, row_ptr, col_idx, val, nnz, nullptr, 0, 0);
 }
 
 // Propagator::propagateCovarianceMatrices (propagator.cpp:166-205) on the resident covariance:
@@ -1084,7 +1274,7 @@ extern "C" int xk_cov_propagate(xk_handle *h, const double *f_d, int ldf, const 
   rp[n] = (int)ci.size();
   for (int c = 0; c < XK_CORE; ++c)
     for (int r = 0; r < XK_CORE; ++r) q[r + XK_CORE * c] = q_d[r + (size_t)c * ldq];
-  return congruence(h, rp.data(), ci.data(), v.data(), (int)ci.size(), q.data());
+  return congruence(h, rp.data(), ci.data(), v.data(), (int)ci.size(), q.data(), XK_CORE, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1153,7 +1343,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       ga.q[i] = aq[src]; ga.p[i] = ap[src]; ga.obs[i] = aobs[src]; ga.np[i] = anp[src]; ga.L[i] = aL[src];
     }
     hipLaunchKernelGGL(xk_ci_gather, dim3(1), dim3(64), 0, h->stream, ga);
-    XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint + 16};
+    XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint + 16, nullptr, 0};
     hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, h->stream, ta);
     // per-agent column-space rows, one workgroup per agent (:168-204)
     XkFeatBatch *hb = h->h_batch + 8 * j, *db = h->d_batch + 8 * j;

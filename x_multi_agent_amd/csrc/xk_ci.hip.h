@@ -139,9 +139,23 @@ struct XkTriMultiArgs {
   int Ltot;
   double *gpf;                // [3]
   int *iters;
+  // batch mode (one block per track of ONE agent, Triangulation::triangulateGN on the last L poses of the
+  // window): trk_off [K+1] non-null, q / p = the n_poses window lists, obs = the concatenated tracks
+  const int *trk_off;
+  int n_poses;
 };
 
-__global__ __launch_bounds__(64) void xk_triangulate_multi(XkTriMultiArgs a) {
+__global__ __launch_bounds__(64) void xk_triangulate_multi(XkTriMultiArgs a_in) {
+  XkTriMultiArgs a = a_in;
+  if (a_in.trk_off) {
+    const int b = blockIdx.x, o = a_in.trk_off[b];
+    a.Ltot = a_in.trk_off[b + 1] - o;
+    a.q = a_in.q + 4 * (size_t)(a_in.n_poses - a.Ltot);
+    a.p = a_in.p + 3 * (size_t)(a_in.n_poses - a.Ltot);
+    a.obs = a_in.obs + 2 * (size_t)o;
+    a.gpf = a_in.gpf + 3 * (size_t)b;
+    a.iters = a_in.iters + b;
+  }
   const int lane = threadIdx.x, L = a.Ltot;
   double Ra[9], R1[9];
   xk_quat_to_rot(a.q + 4 * (size_t)(L - 1), Ra);

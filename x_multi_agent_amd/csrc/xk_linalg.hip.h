@@ -321,8 +321,8 @@ struct XkCongArgs {
   int n;
   const int *rp, *ci;   // row pointers [n+1], column indices
   const double *v;      // values
-  const double *Q;      // optional: qdim x qdim (column-major) added to the leading block (process noise)
-  int qdim;
+  const double *Q;      // optional: qdim x qdim block (column-major) added at rows/cols [qoff, qoff + qdim)
+  int qdim, qoff;
 };
 __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
     for (int ia = r0; ia < r1; ++ia) t = fma(a.v[ia], pb[a.ci[ia]], t);   // (J P)[r][b]
     acc = fma(t, a.v[ib], acc);
   }
-  if (a.Q && r < a.qdim && c < a.qdim) acc += a.Q[r + (size_t)c * a.qdim];
+  if (a.Q && r >= a.qoff && r < a.qoff + a.qdim && c >= a.qoff && c < a.qoff + a.qdim)
+    acc += a.Q[(r - a.qoff) + (size_t)(c - a.qoff) * a.qdim];
   a.Pout[idx] = acc;
 }
 

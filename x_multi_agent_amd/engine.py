@@ -27,6 +27,7 @@ SYMBOLS = [
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
     "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
+    "xk_stage_msckf_slam", "xk_msckf_slam_results", "xk_init_msckf_slam_features", "xk_init_standard_slam_features",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
 ]
 
@@ -323,6 +324,44 @@ class Engine:
         if hc.value:
             out["ci"] = dict(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj), H=np.ascontiguousarray(H), res=res)
         return out
+
+    # ---- MSCKF-SLAM tracks / persistent-feature initialisation --------
+    def stage_msckf_slam(self, tracks):
+        """tracks: list of (L x 2) observation arrays (possibly empty)."""
+        k = len(tracks)
+        self.K2 = k
+        if k == 0:
+            self._chk(self.L.xk_stage_msckf_slam(self.h, None, None, C.c_int(0)), "xk_stage_msckf_slam")
+            return
+        off, offp = _i(np.concatenate([[0], np.cumsum([len(t) for t in tracks])]))
+        obs, obsp = _d(np.concatenate([np.asarray(t, float).reshape(-1, 2) for t in tracks]))
+        self._chk(self.L.xk_stage_msckf_slam(self.h, offp, obsp, C.c_int(k)), "xk_stage_msckf_slam")
+
+    def msckf_slam_results(self):
+        k = getattr(self, "K2", 0)
+        m = max(3 * k, 1)
+        inl = np.zeros(max(k, 1), np.int32)
+        gam = np.zeros(max(k, 1))
+        H1 = np.zeros((m, self.n), order="F")
+        H2 = np.zeros((m, m), order="F")
+        r1, f = np.zeros(m), np.zeros(m)
+        self._chk(self.L.xk_msckf_slam_results(self.h, inl.ctypes.data_as(c_ip), gam.ctypes.data_as(c_dp),
+                                               H1.ctypes.data_as(c_dp), C.c_int(m), H2.ctypes.data_as(c_dp), C.c_int(m),
+                                               r1.ctypes.data_as(c_dp), f.ctypes.data_as(c_dp)), "xk_msckf_slam_results")
+        return dict(inlier=inl[:k], gamma=gam[:k], H1=np.ascontiguousarray(H1[:3 * k]), H2=np.ascontiguousarray(H2[:3 * k, :3 * k]),
+                    r1=r1[:3 * k], features=f[:3 * k])
+
+    def init_msckf_slam_features(self, n_features, correction, sigma_img):
+        k = getattr(self, "K2", 0)
+        corr, corrp = _d(correction)
+        out = np.zeros(max(3 * k, 1))
+        self._chk(self.L.xk_init_msckf_slam_features(self.h, C.c_int(n_features), corrp, C.c_double(sigma_img),
+                                                     out.ctypes.data_as(c_dp)), "xk_init_msckf_slam_features")
+        return out[:3 * k]
+
+    def init_standard_slam_features(self, n_features, k, sigma_img, sigma_rho_0):
+        self._chk(self.L.xk_init_standard_slam_features(self.h, C.c_int(n_features), C.c_int(k), C.c_double(sigma_img),
+                                                        C.c_double(sigma_rho_0)), "xk_init_standard_slam_features")
 
     def cov_congruence(self, J):
         """Resident P <- J P J^T; J dense (n x n, mostly zeros) or a (row_ptr, col_idx, val) CSR triple."""
