@@ -154,3 +154,20 @@ def test_capacity_and_argument_errors(xk):
     with pytest.raises(xk.XkError):
         eng.visual_update(sc)
     eng.close()
+
+
+def test_repeated_updates_are_bit_identical(xk):
+    """The compression runs redundant / unsynchronised workgroups (column splits of the merges, the replicated
+    block factorisations of the Cholesky): any race between them would make the posterior vary between runs."""
+    sc = synth.make_config(4)
+    eng = _engine(xk, sc)
+    eng.stage(sc)
+    first = None
+    for _ in range(12):
+        eng.upload_P(sc["P"])
+        r = eng.visual_update_staged(sc["sigma_img"])
+        P = eng.download_P()
+        if first is None:
+            first = (P.copy(), r["correction"].copy())
+        assert np.array_equal(P, first[0]) and np.array_equal(r["correction"], first[1])
+    eng.close()

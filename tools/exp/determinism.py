@@ -1,0 +1,21 @@
+"""Same staged inputs, many updates: the posterior must be bit-identical every time (a data race between the
+unsynchronised column splits / redundant factorizations would show up here)."""
+import sys; sys.path.insert(0, '.')
+import numpy as np
+from x_multi_agent_amd import engine, synth
+for cfg, reps in ((4, 300), (2, 100), (3, 30)):
+    N, K, M = synth.CONFIGS[cfg]
+    sc = synth.make_config(cfg)
+    eng = engine.Engine(N, M, K)
+    eng.stage(sc)
+    first, diff = None, 0
+    for i in range(reps):
+        eng.upload_P(sc["P"])
+        r = eng.visual_update_staged(sc["sigma_img"])
+        P = eng.download_P()
+        if first is None:
+            first = (P.copy(), r["correction"].copy())
+        elif not (np.array_equal(P, first[0]) and np.array_equal(r["correction"], first[1])):
+            diff += 1
+    eng.close()
+    print(f"config {cfg}: {reps} repeated updates, {diff} differ from the first")

@@ -1,0 +1,46 @@
+"""Randomised parity sweep of the visual update (GPU, through the C ABI) against the C oracle over window sizes,
+track counts / lengths, SLAM features, partial windows, rejection rates and prior scales.
+    python tools/exp/stress_parity.py [n_cases] [seed]"""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from x_multi_agent_amd import engine, synth
+from oracle import c_oracle
+from helpers import rel
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+worst, bad, t0 = 0.0, [], time.time()
+for it in range(n_cases):
+    N = int(rng.choice([2, 3, 5, 8, 12, 16, 24, 30, 33, 34, 40, 50, 64]))
+    K = int(rng.choice([0, 1, 2, 7, 19, 20, 21, 39, 41, 60, 120, 250]))
+    M = int(rng.choice([0, 0, 0, 1, 4, 11]))
+    if K == 0 and M == 0:
+        K = 3
+    if 15 + 6 * N + 3 * M + 1 > 512:
+        M = 0
+    kw = dict(seed=int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.choice([0.0, 0.05, 0.3, 0.8])),
+              prior_scale=float(rng.choice([0.1, 1.0, 30.0])))
+    if N > 3 and rng.random() < 0.4:
+        kw["track_len"] = (2, N)
+    if N > 4 and rng.random() < 0.3:
+        kw["n_poses"] = int(rng.integers(max(2, N // 2), N))
+        if "track_len" in kw:
+            kw["track_len"] = (2, kw["n_poses"])
+    try:
+        sc = synth.make_scenario(N, K, M, **kw)
+    except Exception as e:      # generator constraints (e.g. track longer than the partial window)
+        continue
+    ref = c_oracle.visual_update(sc)
+    eng = engine.Engine(N, M, max(K, 1))
+    got = eng.visual_update(sc)
+    again = eng.visual_update(sc)      # same handle, second call: stale device state must not leak
+    eng.close()
+    ok = (np.array_equal(got["inlier"], ref["inlier"]) and np.array_equal(got["inlier_slam"], ref["inlier_slam"]))
+    rp = rel(got["P"], ref["P"]); rc = rel(got["correction"], ref["correction"]) if np.linalg.norm(ref["correction"]) > 0 else 0.0
+    rr = rel(again["P"], got["P"])
+    worst = max(worst, rp)
+    if not ok or rp > 1e-8 or rc > 1e-6 or rr != 0.0:
+        bad.append((N, K, M, kw, ok, rp, rc, rr))
+        print("MISMATCH", bad[-1], flush=True)
+print(f"{n_cases} cases in {time.time() - t0:.0f} s: worst rel dP {worst:.2e}; mismatches {len(bad)}")
+sys.exit(1 if bad else 0)
