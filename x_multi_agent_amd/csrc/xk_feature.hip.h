@@ -7,7 +7,7 @@
 //   chi-square gate                         msckf_update.cpp:452-463
 // Output per inlier track: the d = 2L-3 projected rows [H0 | res0] over the
 // ACTIVE columns (state columns 15.., the 15 core columns are identically
-// zero, msckf_update.cpp:412-416) as one row-major tile for the TSQR.
+// zero, msckf_update.cpp:412-416) as one row-major tile for the QR compression.
 //
 // What is exploited that the reference does not: J is block-sparse (one 2x3
 // position block and one 2x3 attitude block per observation), so
