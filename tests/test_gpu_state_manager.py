@@ -101,3 +101,40 @@ def test_covariance_propagation_and_repropagation_loop(xk, N, M):
     assert rel(got, ref) <= 1e-13
     assert np.array_equal(got[15:, 15:], P[15:, 15:])           # the non-core block is carried bit for bit
     assert got[3, 20] != got[20, 3]
+
+
+def test_error_paths_of_the_state_side_entry_points(xk):
+    """Same status codes as the rest of the ABI: EINVAL (1) for malformed input, ECAPACITY (6) for too much of it."""
+    import ctypes as C
+    N, M = 6, 2
+    n = 15 + 6 * N + 3 * M
+    eng = xk.Engine(N, M, 4)
+    L, h = eng.L, eng.h
+    F = np.asfortranarray(np.eye(15)); Q = np.asfortranarray(np.zeros((15, 15)))
+    dp = C.POINTER(C.c_double)
+    assert L.xk_cov_propagate(h, F.ctypes.data_as(dp), C.c_int(14), Q.ctypes.data_as(dp), C.c_int(15)) == 1
+    assert L.xk_cov_propagate(h, None, C.c_int(15), Q.ctypes.data_as(dp), C.c_int(15)) == 1
+    # more MSCKF-SLAM tracks than feature slots
+    tracks = [np.zeros((3, 2))] * (M + 1)
+    with pytest.raises(xk.XkError) as e:
+        eng.stage_msckf_slam(tracks)
+    assert e.value.status == 6
+    # feature initialisation before any build on the staged tracks
+    sc = synth.make_scenario(N, 4, 0, seed=31)
+    tr = synth.tracks_as_list(sc)
+    eng.stage_msckf_slam(tr[:1])
+    with pytest.raises(xk.XkError) as e:
+        eng.init_msckf_slam_features(0, np.zeros(n), 0.002)
+    assert e.value.status == 1
+    # no free slot left
+    with pytest.raises(xk.XkError) as e:
+        eng.init_standard_slam_features(M, 1, 0.002, 0.5)
+    assert e.value.status == 6
+    # CI round with a payload layout that is not this handle's
+    import torch
+    buf = torch.zeros(2, 100, dtype=torch.float64, device="cuda")
+    trk = torch.zeros(2, 1 + 2 * N, dtype=torch.float64, device="cuda")
+    with pytest.raises(xk.XkError) as e:
+        eng.ci_round_device(buf.data_ptr(), 100, 2, 0, trk.data_ptr(), 1, [[3], [3]], [N, N], [0], 0.002, 0.1)
+    assert e.value.status == 1
+    eng.close()
