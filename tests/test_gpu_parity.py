@@ -63,6 +63,7 @@ CASES_VS_ORACLE = {
     "caqr_21_tiles": lambda: synth.make_scenario(8, 21, 0, seed=908),
     "caqr_401_tiles": lambda: synth.make_scenario(8, 401, 0, seed=909),
     "caqr_450_tiles_40way": lambda: synth.make_scenario(10, 450, 0, seed=910),
+    "caqr_1700_tiles_three_levels": lambda: synth.make_scenario(3, 1700, 0, seed=71),
     "caqr_mostly_rejected": lambda: synth.make_scenario(12, 120, 0, seed=911, outlier_frac=0.7),
     # SLAM rows only / SLAM-dominated stacks, and the two tile heights either side of the 64-row boundary
     "slam_only_m5": lambda: synth.make_scenario(8, 0, 5, seed=1201),
