@@ -528,6 +528,10 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   XkCaqrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles; a.TS = h->DB;
   a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
+  {   // tallest tile: 2 L_max - 3 rows for the track tiles, full slots for packed SLAM rows
+    const int lmax = std::max(h->K > 0 ? h->h_pin_i[0] : 0, h->K2 > 0 ? h->h_pin_i[1] : 0);
+    a.rows_max = (h->M > 0) ? h->DB : std::min(h->DB, std::max(16, 2 * lmax - 3));
+  }
   // first-level arity: 40 strips per workgroup once 20 x 20 no longer covers the stack in two levels
   static const int arity1_env = env_int("XK_CAQR_ARITY1", 0);
   const int arity1 = arity1_env ? arity1_env : (ntiles > 400 ? 40 : 20);

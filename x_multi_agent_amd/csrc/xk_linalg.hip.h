@@ -389,6 +389,7 @@ struct XkCaqrArgs {
   double *A;              // tiles [ntiles][tile_rows_max][C1P] row-major (in place)
   const int *tile_rows;   // valid rows per tile before panel 0 (0 = rejected track)
   int ntiles, TS;         // TS = rows per tile slot (64 or 128)
+  int rows_max;           // tallest tile of this update (<= TS): rows past it are all-zero by construction
   int C1P, C1, c0;        // panel = columns [c0, min(c0+16, C1))
   int stride;             // merge: group g merges tiles g*A*stride + u*stride, u = 0..A-1
   int final_level;        // merge: root strip -> Rout
@@ -516,8 +517,9 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
   const long long t0 = clock64();
 #endif
   // the loads do not wait for the row count: rows past it are masked after they arrive
+  const int rlim = a.rows_max - part * RPL;   // rows of the slot past the tallest staged tile are never touched
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) b[r] = mine ? rowp[(size_t)r * a.C1P] : 0.0;
+  for (int r = 0; r < RPL; ++r) b[r] = (mine && r < rlim) ? rowp[(size_t)r * a.C1P] : 0.0;
   if (a.c0 == 0) {
     const int nvalid = a.tile_rows[t] - part * RPL;
 #pragma unroll
@@ -544,7 +546,8 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) rowp[(size_t)r * a.C1P] = b[r];
+    for (int r = 0; r < RPL; ++r)
+      if (r < rlim) rowp[(size_t)r * a.C1P] = b[r];
   }
 }
 
