@@ -190,7 +190,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max));
   h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
-  HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 64)));
+  HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 512)));
   HIPCHK(h, hipMemset(h->d_status, 0, sizeof(int) * 4));
   HIPCHK(h, hipMemset(h->d_tile_rows, 0, sizeof(int) * (size_t)h->ntiles_max));
   h->sigma_img = 0.0;
