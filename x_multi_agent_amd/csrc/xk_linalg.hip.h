@@ -468,10 +468,11 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
   }
   __syncthreads();
   const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-  xk_d2 u[RPL / 2];
-#pragma unroll
-  for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
   if (rel > KK && live && s01[0] != 0.0) {
+    // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
+    xk_d2 u[RPL / 2];
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
     double rt = __builtin_amdgcn_rcp(s01[1]);
     rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
     rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
@@ -609,10 +610,11 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
   }
   __syncthreads();
   const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-  xk_d2 u[RPL / 2];
-#pragma unroll
-  for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
   if (rel > KK && live && s01[0] != 0.0) {
+    // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
+    xk_d2 u[RPL / 2];
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
     double rt = __builtin_amdgcn_rcp(s01[1]);
     rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
     rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
