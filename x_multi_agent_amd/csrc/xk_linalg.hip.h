@@ -413,7 +413,9 @@ struct XkCaqrArgs {
 //     (zeros above the pivot, v_pivot at it) so that no consumer has to;
 //   * the eliminated entries are never zeroed in registers: rows below the pivot of a finished
 //     column are dead, the write-back masks the few that are not;
-//   * the division by t = 1 + |c0| y is left to the consumers, overlapped with their LDS reads.
+//   * the owner also publishes -tt itself: a SIMD executes one wave64 VALU instruction per 4 clocks in
+//     TOTAL (clock_probe), so six redundant reciprocal instructions on every lane of 6-12 waves cost
+//     more than six more instructions on the owner's chain.
 // (Several columns per lane -- fewer LDS reads, independent FMA chains -- is slower at every width
 //  tried: it lengthens exactly these per-wave instruction streams.)
 template <int KK, int NP, int RPL>
@@ -453,6 +455,12 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
         y2 = y * y;
         tden = fma(fabs(c0v), y, 1.0);
       }
+      // -tt = -y^2 / (1 + |c0| y), once for the whole workgroup: the VALU is shared by all waves of a SIMD
+      // (one wave64 instruction per 4 clocks in total), so per-lane redundant scalar work is not free
+      double rt = __builtin_amdgcn_rcp(tden);
+      rt = fma(rt, fma(-tden, rt, 1.0), rt);
+      rt = fma(rt, fma(-tden, rt, 1.0), rt);
+      const double mtt = -(y2 * rt);
       // entries 0..KK of the reflector: rows above the pivot do not take part, the pivot entry is vp
 #pragma unroll
       for (int q = 0; q <= KK / 2; ++q) {
@@ -461,28 +469,24 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
         pp[1] = (2 * q + 1 < KK) ? 0.0 : (2 * q + 1 == KK) ? vp : b[2 * q + 1];
         useg[q] = pp;
       }
-      xk_d2 s01 = {y2, tden};
-      *reinterpret_cast<xk_d2 *>(scp) = s01;
+      scp[0] = mtt;
       b[KK] = beta;
     }
   }
   __syncthreads();
-  const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-  if (rel > KK && live && s01[0] != 0.0) {
+  const double mtt = scp[0];
+  if (rel > KK && live && mtt != 0.0) {
     // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
     xk_d2 u[RPL / 2];
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-    double rt = __builtin_amdgcn_rcp(s01[1]);
-    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) {
       if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
       else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
     }
-    const double w = -(s01[0] * rt) * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+    const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) {
       b[2 * r] = fma(w, u[r][0], b[2 * r]);
@@ -602,29 +606,31 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
         y2 = y * y;
         tden = fma(fabs(c0v), y, 1.0);
       }
+      // -tt = -y^2 / (1 + |c0| y), once for the whole workgroup: the VALU is shared by all waves of a SIMD
+      // (one wave64 instruction per 4 clocks in total), so per-lane redundant scalar work is not free
+      double rt = __builtin_amdgcn_rcp(tden);
+      rt = fma(rt, fma(-tden, rt, 1.0), rt);
+      rt = fma(rt, fma(-tden, rt, 1.0), rt);
+      const double mtt = -(y2 * rt);
       ubuf[(pb * NP + part) * RPLP] = vp;                // the pivot entry of the reflector
-      xk_d2 s01 = {y2, tden};
-      *reinterpret_cast<xk_d2 *>(scp) = s01;
+      scp[0] = mtt;
       b[0] = beta;
     }
   }
   __syncthreads();
-  const xk_d2 s01 = *reinterpret_cast<const xk_d2 *>(scp);
-  if (rel > KK && live && s01[0] != 0.0) {
+  const double mtt = scp[0];
+  if (rel > KK && live && mtt != 0.0) {
     // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
     xk_d2 u[RPL / 2];
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-    double rt = __builtin_amdgcn_rcp(s01[1]);
-    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
-    rt = fma(rt, fma(-s01[1], rt, 1.0), rt);
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) {
       if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
       else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
     }
-    const double w = -(s01[0] * rt) * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+    const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
 #pragma unroll
     for (int r = 0; r < RPL / 2; ++r) {
       b[2 * r] = fma(w, u[r][0], b[2 * r]);
