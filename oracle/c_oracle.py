@@ -16,12 +16,12 @@ c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
 
 
-def build(march="x86-64-v3", out=None, force=False):
+def build(march="x86-64-v3", out=None, force=False, extra_flags=()):
     out = out or os.path.join(_HERE, "libxk_oracle.so")
     src = os.path.join(_HERE, "xk_oracle.c")
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         subprocess.check_call(["gcc", "-O3", f"-march={march}", "-std=gnu11", "-fPIC", "-Wall",
-                               "-Wno-unused-function", "-shared", "-o", out, src, "-lm"])
+                               "-Wno-unused-function", *extra_flags, "-shared", "-o", out, src, "-lm"])
     return out
 
 
