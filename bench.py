@@ -158,6 +158,7 @@ def main():
     xdev = f"cuda:{dev}" if backend == "nccl" else "cpu"
 
     N, K, M = synth.CONFIGS[args.config]
+    ci_every = 6 if args.config == 5 else CI_EVERY    # config 5: 5 Hz requests at a 30 Hz update rate
     sc = fleet.shared_scenario(synth, args.config, rank)
     eng = engine.Engine(N, M, K, device=dev)
     eng.stage(sc)
@@ -181,6 +182,18 @@ def main():
             return
         eng.pack_payload_into(rank, float(step), dyn16, pay_dev.data_ptr())   # packed on the device ...
         ex.send.copy_(pay_dev)                                                # ... into the RCCL send buffer
+        if args.config == 5:
+            # request/response mode (VIO::processOtherRequests, vio.cpp:462-496): one responder per requester and tick
+            reqs = fleet.ring_requests(world, step // ci_every)
+            gp, gt = ex.request_response(reqs), tex.request_response(reqs)
+            (rsp, rp), = gp.items()
+            allp, allt = torch.stack([ex.send, rp]), torch.stack([tex.send, gt[rsp]])
+            if allp.device.type != "cuda":
+                allp, allt = allp.cuda(dev), allt.cuda(dev)
+            fused, _ = fleet.ci_round_device(eng, sc, 0, 2, allp, allt, CI_TRACKS, CI_MSCKF_W)
+            ci_stats["rounds"] += 1
+            ci_stats["fused"] += fused
+            return
         allp, allt = ex.all_gather(), tex.all_gather()
         if allp.device.type != "cuda":           # gloo functional mode: the exchange ran on host tensors
             allp, allt = allp.cuda(dev), allt.cuda(dev)
@@ -202,10 +215,10 @@ def main():
     t0 = time.perf_counter()
     done = 0
     while done < args.steps:
-        chunk = min(CI_EVERY, args.steps - done)
+        chunk = min(ci_every, args.steps - done)
         eng.run_steps(sigma, chunk)          # `chunk` sequential updates, device-resident
         done += chunk
-        if done % CI_EVERY == 0:
+        if done % ci_every == 0:
             exchange(done)
     sync()
     dt = time.perf_counter() - t0
@@ -254,9 +267,10 @@ def main():
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: one agent per GPU, window N={N}, "
                                       f"K={K} MSCKF tracks (L=N), M={M} SLAM features, n={15 + 6 * N + 3 * M}; "
-                                      f"CI payload all-gather every {CI_EVERY} updates",
+                                      + (f"CI payload request/response (ring) every {ci_every} updates" if args.config == 5
+                                         else f"CI payload all-gather every {ci_every} updates"),
                           "n_poses_max": N, "k_msckf": K, "m_slam": M, "agents": world,
-                          "ci_every": CI_EVERY, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
+                          "ci_every": ci_every, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
                           "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"]},
                "roofline": roof, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
