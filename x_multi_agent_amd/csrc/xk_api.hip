@@ -536,41 +536,99 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   static const int arity1_env = env_int("XK_CAQR_ARITY1", 0);
   const int arity1 = arity1_env ? arity1_env : (ntiles > 400 ? 40 : 20);
   static const int chalf = env_int("XK_CAQR_CHALF", 8);
+  static const int overlap_env = env_int("XK_CAQR_OVERLAP", 1);
   // per-tile kernel: 4 lanes per column, at most 192 (64-row tiles) / 128 (128-row tiles) columns per workgroup
   const int tile_cols = (h->DB == 64) ? 192 : 128;
+  const int groups1 = (ntiles + arity1 - 1) / arity1;
+  // overlapped schedule (xk_caqr_fused): exactly two merge levels, the second one a single 20-way group
+  const bool overlap = overlap_env && (arity1 == 20 || arity1 == 40) && groups1 >= 2 && groups1 <= 20;
+  a.hole_stride = 0; a.lead_off = 0; a.lead_all = 0; a.pend = 0;
   int launches = 0;
-  for (int c0 = 0; c0 < h->C1; c0 += 16) {
+  auto tile_geom = [&](int c0, int &tsplit, int &tchalf, int &tthreads) {
     const int trail = std::max(0, h->C1 - c0 - 16);
-    a.c0 = c0; a.stride = 1; a.final_level = 0; a.pin = nullptr; a.pout = h->d_panel[0];
-    const int tsplit = std::max(1, (trail + (tile_cols - 16) - 1) / (tile_cols - 16));
-    a.chalf = (trail + tsplit - 1) / tsplit;
-    const dim3 tgrid(ntiles, tsplit), tblock(round_up(4 * (16 + a.chalf), 64));
+    tsplit = std::max(1, (trail + (tile_cols - 16) - 1) / (tile_cols - 16));
+    tchalf = (trail + tsplit - 1) / tsplit;
+    tthreads = round_up(4 * (16 + tchalf), 64);
+  };
+  auto launch_tile = [&](XkCaqrArgs &t) {
+    int tsplit, tthreads;
+    tile_geom(t.c0, tsplit, t.chalf, tthreads);
+    const dim3 tgrid(ntiles, tsplit), tblock(tthreads);
     if (h->DB == 64) {
-      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, false>), tgrid, tblock, 0, h->stream, a);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, true>), tgrid, tblock, 0, h->stream, a);
+      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, false>), tgrid, tblock, 0, h->stream, t);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, true>), tgrid, tblock, 0, h->stream, t);
     } else {
-      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, false>), tgrid, tblock, 0, h->stream, a);
-      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, true>), tgrid, tblock, 0, h->stream, a);
+      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, false>), tgrid, tblock, 0, h->stream, t);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, true>), tgrid, tblock, 0, h->stream, t);
     }
-    if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
-    if (c0 > 0) ++launches;                                        // (the first tile launch is timed as its own stage)
-    a.chalf = chalf;
-    const int csplit = std::max(1, (trail + a.chalf - 1) / a.chalf);
-    int stride = 1, level = 0;
-    do {
-      const int left = (ntiles + stride - 1) / stride;             // strips still alive at this level
-      const int arity = (stride == 1) ? arity1 : (left > 20 ? 40 : 20);
-      a.stride = stride;
-      a.final_level = (left <= arity) ? 1 : 0;
-      const int groups = (left + arity - 1) / arity;
-      a.pin = h->d_panel[level & 1];
-      a.pout = h->d_panel[(level + 1) & 1];
-      ++level;
-      if (arity == 40) launch_merge<40>(h, a, groups, csplit);
-      else launch_merge<20>(h, a, groups, csplit);
+  };
+  if (overlap) {
+    a.rows_max = std::max(a.rows_max, 32);        // a leader's pivot strip alternates between rows 0..15 and 16..31
+    for (int c0 = 0, k = 0; c0 < h->C1; c0 += 16, ++k) {
+      const int trail = std::max(0, h->C1 - c0 - 16);
+      const int csplit = std::max(1, (trail + chalf - 1) / chalf);
+      static const int lchalf = 4 * std::max(1, env_int("XK_CAQR_LCHALF", 8) / 4);   // whole waves: 16 lanes per column
+      const int lsplit = std::max(1, (trail + lchalf - 1) / lchalf);
+      const int lead_off = (k & 1) ? 16 : 0;
+      if (k == 0) {
+        XkCaqrArgs t = a;
+        t.c0 = 0; t.stride = 1; t.final_level = 0; t.pin = nullptr; t.pout = h->d_panel[0];
+        launch_tile(t);
+        if (mid) hipEventRecord(mid, h->stream);
+      }
+      XkCaqrArgs m = a;                            // first level: leaders' pivot strips at lead_off, + the pending strips
+      m.c0 = c0; m.stride = 1; m.final_level = 0; m.pin = h->d_panel[0]; m.pout = h->d_panel[1]; m.chalf = chalf;
+      m.lead_off = lead_off; m.lead_all = 0; m.pend = (k > 0) ? 1 : 0;
+      if (arity1 == 40) launch_merge<42>(h, m, groups1, csplit);
+      else launch_merge<22>(h, m, groups1, csplit);
       ++launches;
-      stride *= arity;
-    } while (stride < ntiles);
+      XkCaqrArgs l = a;                            // last level: the leaders' pivot strips -> 16 rows of R
+      l.c0 = c0; l.stride = arity1; l.final_level = 1; l.pin = h->d_panel[1]; l.pout = h->d_panel[0]; l.chalf = lchalf;
+      l.lead_off = lead_off; l.lead_all = 1; l.pend = 0;
+      if (c0 + 16 < h->C1) {
+        XkCaqrArgs t = a;                          // ... next to the tile step of the next panel
+        t.c0 = c0 + 16; t.stride = 1; t.final_level = 0; t.pin = nullptr; t.pout = h->d_panel[0];
+        t.hole_stride = arity1; t.lead_off = 16 - lead_off;
+        int tsplit, tthreads;
+        tile_geom(t.c0, tsplit, t.chalf, tthreads);
+                const dim3 grid(lsplit + ntiles * tsplit), block(std::max(tthreads, round_up(16 * (16 + lchalf), 64)));
+        if (h->DB == 64) {
+          if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<16, false>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<16, true>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
+        } else {
+          if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<32, false>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<32, true>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
+        }
+      } else {
+        launch_merge<20>(h, l, 1, lsplit);
+      }
+      ++launches;
+    }
+  } else {
+    for (int c0 = 0; c0 < h->C1; c0 += 16) {
+      const int trail = std::max(0, h->C1 - c0 - 16);
+      a.c0 = c0; a.stride = 1; a.final_level = 0; a.pin = nullptr; a.pout = h->d_panel[0];
+      launch_tile(a);
+      if (c0 == 0 && mid) hipEventRecord(mid, h->stream);
+      if (c0 > 0) ++launches;                                        // (the first tile launch is timed as its own stage)
+      a.chalf = chalf;
+      const int csplit = std::max(1, (trail + a.chalf - 1) / a.chalf);
+      int stride = 1, level = 0;
+      do {
+        const int left = (ntiles + stride - 1) / stride;             // strips still alive at this level
+        const int arity = (stride == 1) ? arity1 : (left > 20 ? 40 : 20);
+        a.stride = stride;
+        a.final_level = (left <= arity) ? 1 : 0;
+        const int groups = (left + arity - 1) / arity;
+        a.pin = h->d_panel[level & 1];
+        a.pout = h->d_panel[(level + 1) & 1];
+        ++level;
+        if (arity == 40) launch_merge<40>(h, a, groups, csplit);
+        else launch_merge<20>(h, a, groups, csplit);
+        ++launches;
+        stride *= arity;
+      } while (stride < ntiles);
+    }
   }
   h->nleaf = ntiles;
   h->nlevels = launches;

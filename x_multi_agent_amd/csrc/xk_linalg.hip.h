@@ -397,6 +397,11 @@ struct XkCaqrArgs {
   int chalf;              // trailing columns per workgroup (gridDim.y workgroups cover the range)
   const double *pin;      // merge: 16 x 16 panel blocks of the level below [block][16][16]
   double *pout;           // panel block of this tile / merge group for the level above
+  // overlapped schedule (see xk_caqr_fused): tiles t % hole_stride == 0 are the strips of the LAST merge level
+  int hole_stride;        // tile kernel: 0 = no tile has a hole (panel 0, or the plain schedule)
+  int lead_off;           // first physical row (0 or 16) of such a tile's pivot strip in this panel
+  int lead_all;           // merge: every strip is such a tile (last level) / only strip 0 (first level)
+  int pend;               // merge (first level): the group leader's hole rows join as strip number ARITY
   long long *dbg;         // optional: clock stamps of workgroup 0 (probe builds only)
 };
 
@@ -505,24 +510,29 @@ __device__ __forceinline__ void xk_caqr_steps(double (&b)[RPL], int rel, bool li
 
 // (1) per-tile panel step: 4 lanes per column, RPL = 16 (64-row tiles) or 32 (128-row tiles) rows per lane.
 // (RPL = 16 must stay at <= 80 VGPRs so that two 12-wave workgroups share a CU.)
-// CSPLIT: the trailing columns are spread over gridDim.y workgroups (systems wider than one workgroup).
+// CSPLIT: the trailing columns are spread over `ysplit` workgroups (systems wider than one workgroup).
+// Tiles with a hole (overlapped schedule): 16 of the first 32 physical rows are still being merged by the last
+// level of the previous panel; the part-0 lanes take the other 16 as the pivot strip and the hole is skipped.
 template <int RPL, bool CSPLIT>
-__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_tile(XkCaqrArgs a) {
-  constexpr int NP = 4, RPLP = RPL + 2;
-  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
-  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+__device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, int ysplit, double *ubuf, double *sc) {
+  constexpr int NP = 4;
   const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
   const bool panel = cidx < 16;
-  const int col = (!CSPLIT || panel) ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
+  const int col = (!CSPLIT || panel) ? a.c0 + cidx : a.c0 + 16 + ysplit * a.chalf + (cidx - 16);
   const bool mine = col < a.C1 && (!CSPLIT || panel || cidx - 16 < a.chalf);
-  const int t = blockIdx.x;
-  double *rowp = a.A + ((size_t)t * a.TS + part * RPL) * a.C1P + col;
+  const bool holed = a.hole_stride > 0 && (t % a.hole_stride) == 0;
+  int prow = part * RPL;
+  // the loads do not wait for the row count: rows past it are masked after they arrive
+  int rlim = a.rows_max - part * RPL;         // rows of the slot past the tallest staged tile are never touched
+  if (holed) {
+    if (part == 0) { prow = a.lead_off; rlim = 16; }
+    else if (RPL == 16 && part == 1) rlim = 0;
+  }
+  double *rowp = a.A + ((size_t)t * a.TS + prow) * a.C1P + col;
   double b[RPL];
 #ifdef XK_CAQR_PROBE
   const long long t0 = clock64();
 #endif
-  // the loads do not wait for the row count: rows past it are masked after they arrive
-  const int rlim = a.rows_max - part * RPL;   // rows of the slot past the tallest staged tile are never touched
 #pragma unroll
   for (int r = 0; r < RPL; ++r) b[r] = (mine && r < rlim) ? rowp[(size_t)r * a.C1P] : 0.0;
   if (a.c0 == 0) {
@@ -539,13 +549,13 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
   xk_caqr_steps<NP, RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
 #ifdef XK_CAQR_PROBE
   const long long t2 = clock64();
-  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[2] = wall_clock64() - w1; a.dbg[3] = nsteps; }
+  if (a.dbg && t == 0 && ysplit == 0 && threadIdx.x == 0) { a.dbg[0] = t1 - t0; a.dbg[1] = t2 - t1; a.dbg[2] = wall_clock64() - w1; a.dbg[3] = nsteps; }
 #endif
   if (!mine) return;
   if (panel) {
     // the strip's panel block (upper triangle, zeros below: eliminated entries are not zeroed in registers)
     // is the next level's input; rows 16.. of a finished column are dead
-    if (part == 0 && (!CSPLIT || blockIdx.y == 0)) {
+    if (part == 0 && (!CSPLIT || ysplit == 0)) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) a.pout[((size_t)t * 16 + r) * 16 + cidx] = (r > cidx) ? 0.0 : b[r];
     }
@@ -554,6 +564,14 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
     for (int r = 0; r < RPL; ++r)
       if (r < rlim) rowp[(size_t)r * a.C1P] = b[r];
   }
+}
+
+template <int RPL, bool CSPLIT>
+__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_tile(XkCaqrArgs a) {
+  constexpr int NP = 4, RPLP = RPL + 2;
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  xk_caqr_tile_body<RPL, CSPLIT>(a, blockIdx.x, blockIdx.y, ubuf, sc);
 }
 
 // (2) A-way strip merge, A = RPL strips of 16 rows.  Lane layout, transposed with respect to the tile
@@ -566,7 +584,9 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
 //     addressed by one uniform stride.
 // (~25 fewer instructions on the owner's path of a step; measured step time is unchanged -- the owner is
 //  not what the other waves wait for -- so this layout is kept for its simpler addressing.)
-template <int KK, int RPL>
+// REREAD: the reflector is fetched twice (dot product, then update) instead of being held in RPL more
+// registers -- for the copy of this code that shares a kernel, and an 80-VGPR budget, with the tile step.
+template <int KK, int RPL, bool REREAD>
 __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool live, int part, double *ubuf, double *sc) {
   constexpr int NP = 16, RPLP = RPL + 2;
   constexpr int pb = KK & 1;
@@ -621,61 +641,89 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
   const double mtt = scp[0];
   if (rel > KK && live && mtt != 0.0) {
     // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
-    xk_d2 u[RPL / 2];
+    if (REREAD) {
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-    for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+      for (int r = 0; r < RPL / 2; ++r) {
+        const xk_d2 u = useg[r];
+        if (r & 1) { d2 = fma(u[0], b[2 * r], d2); d3 = fma(u[1], b[2 * r + 1], d3); }
+        else { d0 = fma(u[0], b[2 * r], d0); d1 = fma(u[1], b[2 * r + 1], d1); }
+      }
+      const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+      asm volatile("" ::: "memory");                      // the second fetch is not merged with the first
 #pragma unroll
-    for (int r = 0; r < RPL / 2; ++r) {
-      if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
-      else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
-    }
-    const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+      for (int r = 0; r < RPL / 2; ++r) {
+        const xk_d2 u = useg[r];
+        b[2 * r] = fma(w, u[0], b[2 * r]);
+        b[2 * r + 1] = fma(w, u[1], b[2 * r + 1]);
+      }
+    } else {
+      xk_d2 u[RPL / 2];
 #pragma unroll
-    for (int r = 0; r < RPL / 2; ++r) {
-      b[2 * r] = fma(w, u[r][0], b[2 * r]);
-      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) {
+        if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+        else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+      }
+      const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) {
+        b[2 * r] = fma(w, u[r][0], b[2 * r]);
+        b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+      }
     }
   }
 }
 
-template <int RPL>
-__global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArgs a) {
-  constexpr int NP = 16, RPLP = RPL + 2, ARITY = RPL;
+// Merge body.  RPL = ARITY (20, 40) or ARITY + 2 (22, 42: register ARITY is the pending strip of the
+// overlapped schedule).  `group` / `split` = which strips / which trailing columns this workgroup owns.
+template <int RPL, bool REREAD>
+__device__ __forceinline__ void xk_caqr_merge_body(const XkCaqrArgs &a, int group, int split, double *ubuf, double *sc) {
+  constexpr int NP = 16, ARITY = (RPL % 20 == 0) ? RPL : RPL - 2;
+  constexpr bool PEND = ARITY != RPL;
   static_assert(RPL % 2 == 0, "reflector segments are read two doubles at a time");
-  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
-  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
 #ifdef XK_CAQR_PROBE
   const long long w0 = wall_clock64();
 #endif
   const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
   const bool panel = cidx < 16;
-  const int col = panel ? a.c0 + cidx : a.c0 + 16 + (int)blockIdx.y * a.chalf + (cidx - 16);
+  const int col = panel ? a.c0 + cidx : a.c0 + 16 + split * a.chalf + (cidx - 16);
   const bool mine = col < a.C1 && (panel || cidx - 16 < a.chalf);
-  const int base = blockIdx.x * ARITY * a.stride;
-  // strip s of this group = rows 0..15 of tile base + s*stride (trailing columns) or block
-  // blockIdx.x*ARITY + s of the level below (panel columns); this lane's row of it is `part`
+  const int base = group * ARITY * a.stride;
+  // strip s of this group = the pivot strip of tile base + s*stride (trailing columns) or block
+  // group*ARITY + s of the level below (panel columns); this lane's row of it is `part`.  The pivot strip
+  // is rows 0..15 of the tile, except rows lead_off.. for the tiles the last level works on.
   const size_t lane_off = panel ? (size_t)part * 16 + cidx : (size_t)part * a.C1P + col;
   const size_t strip_step = panel ? 256 : (size_t)a.stride * a.TS * a.C1P;
-  double *g0 = panel ? const_cast<double *>(a.pin) + (size_t)blockIdx.x * ARITY * 256 + lane_off
-                     : a.A + (size_t)base * a.TS * a.C1P + lane_off;
+  const size_t lead = panel ? 0 : (size_t)a.lead_off * a.C1P;
+  double *g0 = panel ? const_cast<double *>(a.pin) + (size_t)group * ARITY * 256 + lane_off
+                     : a.A + (size_t)base * a.TS * a.C1P + lane_off + (a.lead_all ? lead : 0);
+  double *g00 = g0 + (a.lead_all ? 0 : lead);                                      // strip 0
+  double *gp = a.A + ((size_t)base * a.TS + (16 - a.lead_off) + part) * a.C1P + col;   // pending strip (hole rows)
   const int nstrips = min(ARITY, (a.ntiles - base + a.stride - 1) / a.stride);   // strips that exist
   double b[RPL];
+  b[0] = mine ? g00[0] : 0.0;
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) b[r] = (mine && r < nstrips) ? g0[(size_t)r * strip_step] : 0.0;
+  for (int r = 1; r < ARITY; ++r) b[r] = (mine && r < nstrips) ? g0[(size_t)r * strip_step] : 0.0;
+  if (PEND) {
+    b[ARITY] = (mine && a.pend) ? gp[0] : 0.0;
+    b[ARITY + 1] = 0.0;
+  }
   const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
 #ifdef XK_CAQR_PROBE
   double sink = 0; for (int r = 0; r < RPL; ++r) sink += b[r];
   asm volatile("" :: "v"(sink));
   const long long t1 = clock64(), w1 = wall_clock64();
 #endif
-#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL>(b, cidx, mine, part, ubuf, sc);
+#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL, REREAD>(b, cidx, mine, part, ubuf, sc);
   XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
   XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
 #undef XK_STEP
 #ifdef XK_CAQR_PROBE
   const long long w2 = wall_clock64();
-  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (a.dbg && group == 0 && split == 0 && threadIdx.x == 0) {
     a.dbg[1] = clock64() - t1; a.dbg[2] = w2 - w1; a.dbg[3] = nsteps;
     a.dbg[4] = w0; a.dbg[5] = w1; a.dbg[6] = w2;
   }
@@ -683,24 +731,55 @@ __global__ __launch_bounds__(RPL > 20 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
   if (!mine) return;
   if (panel) {
     // the merged panel block = register 0 across the 16 lanes; split 0 publishes it
-    if (blockIdx.y == 0) {
+    if (split == 0) {
       const double v = (part > cidx) ? 0.0 : b[0];   // eliminated entries are not zeroed in registers
       if (a.final_level) { if (a.c0 + part < a.C1) a.Rout[(size_t)(a.c0 + part) * a.C1P + col] = v; }
-      else a.pout[(size_t)blockIdx.x * 256 + part * 16 + cidx] = v;
+      else a.pout[(size_t)group * 256 + part * 16 + cidx] = v;
     }
   } else {
     if (a.final_level) {                              // row `part` of the root strip = row c0 + part of R
       if (a.c0 + part < a.C1) a.Rout[(size_t)(a.c0 + part) * a.C1P + col] = b[0];
       b[0] = 0.0;
     }
+    g00[0] = b[0];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r)
+    for (int r = 1; r < ARITY; ++r)
       if (r < nstrips) g0[(size_t)r * strip_step] = b[r];
+    if (PEND) { if (a.pend) gp[0] = b[ARITY]; }
   }
 #ifdef XK_CAQR_PROBE
-  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+  if (a.dbg && group == 0 && split == 0 && threadIdx.x == 0) {
     __builtin_amdgcn_s_waitcnt(0);
     a.dbg[7] = wall_clock64();
   }
 #endif
+}
+
+template <int RPL>
+__global__ __launch_bounds__(RPL > 22 ? 512 : 1024) void xk_caqr_merge(XkCaqrArgs a) {
+  constexpr int NP = 16, RPLP = RPL + 2;
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  xk_caqr_merge_body<RPL, false>(a, blockIdx.x, blockIdx.y, ubuf, sc);
+}
+
+// Overlapped schedule (two merge levels).  The last merge level of panel k only touches the pivot strips of
+// the first-level group leaders; every other row is final for panel k once the first level has run.  So ONE
+// launch runs the last level of panel k (workgroups [0, n_last), the first 384 threads of each) next to the
+// tile step of panel k+1 (the rest of the grid), in which the leaders leave those 16 rows out (their "hole")
+// and use the other 16 of their first 32 rows as the pivot strip.  The rows the last level leaves behind join
+// the first level of panel k+1 as a 21st (41st) dense strip.  Per panel: 2 dependent launches instead of 3.
+template <int RPL, bool CSPLIT>
+__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_fused(XkCaqrArgs ta, XkCaqrArgs la, int n_last, int tsplit) {
+  constexpr int LRPL = 20, LDS_T = 2 * 4 * (RPL + 2), LDS_L = 2 * 16 * (LRPL + 2);
+  __shared__ __attribute__((aligned(16))) double ubuf[LDS_T > LDS_L ? LDS_T : LDS_L];
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  const int id = blockIdx.x;
+  if (id < n_last) {
+    if ((int)threadIdx.x >= 16 * (16 + la.chalf)) return;        // whole waves: 16 * 24 = 384 threads
+    xk_caqr_merge_body<LRPL, true>(la, 0, id, ubuf, sc);
+  } else {
+    const int w = id - n_last;
+    xk_caqr_tile_body<RPL, CSPLIT>(ta, CSPLIT ? w / tsplit : w, CSPLIT ? w % tsplit : 0, ubuf, sc);
+  }
 }
