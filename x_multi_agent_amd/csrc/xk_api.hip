@@ -694,6 +694,14 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
   }
   // blocked Cholesky with the right-hand sides carried along: one launch per 32-column block step
   const int ncols = c + n + 1;
+  static const int whole_env = env_int("XK_CHOL_WHOLE", 1);
+  if (whole_env && c <= 16 * XK_CHOLW_MAXB) {
+    // small systems: every block step inside one launch, one workgroup per 16 right-hand-side columns
+    XkCholWholeArgs d;
+    d.Maug = h->d_Maug; d.ld = LDA; d.c = c; d.ncols = ncols; d.X = h->d_X; d.status = h->d_status;
+    xk_cholw_table((c + 15) / 16, d.tab);
+    hipLaunchKernelGGL(xk_chol_whole, dim3((n + 1 + 15) / 16), dim3(64 * XK_CHOLW_WAVES), 0, h->stream, d);
+  } else
   for (int kb = 0; kb < c; kb += XK_CHOL_NB) {
     const int nb = std::min(XK_CHOL_NB, c - kb);
     const int rest = ncols - (kb + nb), mrem = c - kb - nb;

@@ -287,6 +287,238 @@ __global__ __launch_bounds__(64) void xk_chol_step(XkCholStepArgs a) {
   XK_CSTAMP(5);
 }
 
+// Cholesky factor of one 16 x 16 block and the inverse of the factor, in ONE wave and without LDS traffic
+// or scalar broadcasts inside the pivot chain.  Lane t (every row of 16 lanes runs the same thing) keeps row t
+// of the block (v) and COLUMN t of L^-1 (w).  Step k needs L(j,k) of every other row j -- for the block,
+// A(t,j) -= L(t,k) L(j,k), and for the inverse, W(j,t) -= L(j,k) W(k,t) -- which is one lane's value of ONE
+// register: exactly what the 64-bit DPP control row_newbcast:j delivers inside v_fmac_f64.  A step is then
+// the pivot's rsqrt chain plus 2 (15 - k) multiply-adds, ~200 clocks instead of ~700 through LDS.
+template <int LANE>
+__device__ __forceinline__ double xk_fmac_bcast(double acc, double src, double mul) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+  return acc;
+}
+template <int LANE>
+__device__ __forceinline__ double xk_mov_bcast(double src) {
+  double r;
+  // (a DPP read needs two wait states after the VALU write of its source)
+  asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
+  return r;
+}
+template <int K>
+__device__ __forceinline__ void xk_chol16_step(double (&v)[16], double (&w)[16], bool &bad) {
+  const double piv = xk_mov_bcast<K>(v[K]);
+  if (!(piv > 0.0)) bad = true;
+  double inv = __builtin_amdgcn_rsq(piv);
+  const double h = -0.5 * piv;
+  inv = inv * fma(h * inv, inv, 1.5);
+  inv = inv * fma(h * inv, inv, 1.5);
+  const double lik = v[K] * inv;          // L(t,K); rows t < K carry dead values
+  double lneg;
+  asm("v_mul_f64 %0, %1, %2\n\ts_nop 1" : "=v"(lneg) : "v"(v[K]), "v"(-inv));
+  const double wk = w[K] * inv;           // W(K,t), final
+  w[K] = wk;
+#define XK_CJ(J) if (J > K) { v[J] = xk_fmac_bcast<J>(v[J], lneg, lik); w[J] = xk_fmac_bcast<J>(w[J], lneg, wk); }
+  XK_CJ(1) XK_CJ(2) XK_CJ(3) XK_CJ(4) XK_CJ(5) XK_CJ(6) XK_CJ(7) XK_CJ(8)
+  XK_CJ(9) XK_CJ(10) XK_CJ(11) XK_CJ(12) XK_CJ(13) XK_CJ(14) XK_CJ(15)
+#undef XK_CJ
+}
+// blk: the block, row-major 16 x 16 (LDS);  linv: L^-1, rows padded to 17 (LDS).  Returns true on a bad pivot.
+__device__ __forceinline__ bool xk_chol16_bcast(const double *blk, double *linv, int lane) {
+  const int tt = lane & 15;
+  double v[16], w[16];
+#pragma unroll
+  for (int q = 0; q < 16; q += 2) {
+    const xk_d2 p = *reinterpret_cast<const xk_d2 *>(&blk[16 * tt + q]);
+    v[q] = p[0]; v[q + 1] = p[1];
+    w[q] = (tt == q) ? 1.0 : 0.0; w[q + 1] = (tt == q + 1) ? 1.0 : 0.0;
+  }
+  bool bad = false;
+  xk_chol16_step<0>(v, w, bad); xk_chol16_step<1>(v, w, bad); xk_chol16_step<2>(v, w, bad); xk_chol16_step<3>(v, w, bad);
+  xk_chol16_step<4>(v, w, bad); xk_chol16_step<5>(v, w, bad); xk_chol16_step<6>(v, w, bad); xk_chol16_step<7>(v, w, bad);
+  xk_chol16_step<8>(v, w, bad); xk_chol16_step<9>(v, w, bad); xk_chol16_step<10>(v, w, bad); xk_chol16_step<11>(v, w, bad);
+  xk_chol16_step<12>(v, w, bad); xk_chol16_step<13>(v, w, bad); xk_chol16_step<14>(v, w, bad); xk_chol16_step<15>(v, w, bad);
+  if (lane < 16) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) linv[q * 17 + tt] = w[q];
+  }
+  return bad;
+}
+
+// ----------------------------------------------------------------------------
+// The same factorisation for c <= 192 in ONE launch (xk_chol_whole): a block step is 16 pivots deep
+// whoever runs it, so six launches of xk_chol_step are mostly six launch latencies.  Here a workgroup
+// keeps the WHOLE upper triangle of S in registers -- 16 x 16 tiles in the MFMA C/D layout, dealt to 9
+// worker waves -- plus one 16-column chunk of the right-hand sides [W | z]; there is one workgroup per
+// chunk, each factoring S redundantly (same reasoning as above: the pivot chain is sequential anyway
+// and the other 240 CUs are idle).  One more wave does nothing but the pivot chains.  Block step j:
+//   F  (factor wave) tile (j,j) -> L_jj^-1                      dbuf -> Ls      | workers: C of step j-1
+//   -- barrier 1 --
+//   B  (workers) row j:  X_jk = L_jj^-1 S_jk  for their tiles k > j and the chunk tile -> Xs, X rows (HBM);
+//      the wave that owns (j,j+1) also owns (j+1,j+1) and updates it from its own registers -> dbuf
+//   -- barrier 2 --
+//   C  (workers) S_ik -= X_ji^T X_jk for j < i <= k and the chunk tiles i > j: operands straight from Xs,
+//      because a C/D-layout register is both the A operand of X^T X and its B operand.
+// The critical path per step is F + B (~4000 clocks); C hides behind the next F.
+// The tile -> (wave, slot) table comes from the host: slots 0,1 = the wave's diagonal tiles, slots 2,3 = the
+// tiles above them, slots 4..10 = the rest round-robin; slots 11,12 (chunk tiles) are filled in here.
+// ----------------------------------------------------------------------------
+#define XK_CHOLW_MAXB 12    // 16-row blocks: c <= 192
+#define XK_CHOLW_NW 9       // worker waves (waves 0,1,2, 4,5,6, 8,9,10 of 11: SIMD 3 is left to the factor wave)
+#define XK_CHOLW_WAVES 11
+#define XK_CHOLW_NS 11      // S tiles per worker wave
+
+struct XkCholWholeTab {
+  unsigned char i[XK_CHOLW_NW][XK_CHOLW_NS], k[XK_CHOLW_NW][XK_CHOLW_NS];   // 255 = empty slot
+};
+// host side: the slot table for nbk row blocks
+static inline void xk_cholw_table(int nbk, XkCholWholeTab &t) {
+  for (int w = 0; w < XK_CHOLW_NW; ++w)
+    for (int s = 0; s < XK_CHOLW_NS; ++s) t.i[w][s] = t.k[w][s] = 255;
+  for (int d = 0; d < nbk; ++d) {
+    const int w = d % XK_CHOLW_NW, s = d / XK_CHOLW_NW;       // s = 0, 1 (nbk <= 16)
+    t.i[w][s] = t.k[w][s] = (unsigned char)d;
+    if (d > 0) { t.i[w][2 + s] = (unsigned char)(d - 1); t.k[w][2 + s] = (unsigned char)d; }
+  }
+  int fill[XK_CHOLW_NW];
+  for (int w = 0; w < XK_CHOLW_NW; ++w) fill[w] = 4;
+  int w = 0;
+  for (int i = 0; i < nbk; ++i)
+    for (int k = i + 2; k < nbk; ++k) {
+      while (fill[w] >= XK_CHOLW_NS) w = (w + 1) % XK_CHOLW_NW;
+      t.i[w][fill[w]] = (unsigned char)i; t.k[w][fill[w]] = (unsigned char)k;
+      ++fill[w];
+      w = (w + 1) % XK_CHOLW_NW;
+    }
+}
+
+struct XkCholWholeArgs {
+  const double *Maug;   // [c][ld] row-major  [S | W | z]
+  int ld, c, ncols;     // ncols = c + n + 1
+  double *X;            // [c][ld]: X[:, c:ncols] = L^-1 [W | z]   (the S columns are not written)
+  int *status;          // set to 2 (XK_ESINGULAR) if a pivot is not positive
+  XkCholWholeTab tab;
+#ifdef XK_CHOLW_PROBE
+  long long *dbg;       // [wave][8] clock64 stamps of block step XK_CHOLW_PROBE, workgroup 0
+#endif
+};
+#ifdef XK_CHOLW_PROBE
+#define XK_WSTAMP(i) do { if (blockIdx.x == 0 && lane == 0 && j == XK_CHOLW_PROBE) a.dbg[wave * 8 + (i)] = clock64(); } while (0)
+#else
+#define XK_WSTAMP(i)
+#endif
+
+__global__ __launch_bounds__(64 * XK_CHOLW_WAVES) void xk_chol_whole(XkCholWholeArgs a) {
+  constexpr int NW = XK_CHOLW_NW, NS = XK_CHOLW_NS, NT = NS + 2, XR = XK_CHOLW_MAXB;
+  __shared__ __attribute__((aligned(16))) double Xs[2][XK_CHOLW_MAXB + 1][256];   // X_j tiles (slot 12: the chunk)
+  __shared__ __attribute__((aligned(16))) double Ls[2][16 * 17];   // L_jj^-1, padded rows (MFMA A-operand gathers)
+  __shared__ __attribute__((aligned(16))) double dbuf[256];        // tile (j,j), row-major
+  // waves go to the four SIMDs of the CU round-robin: the factor wave (3) has SIMD 3 to itself -- its FP64
+  // multiply-adds would otherwise queue behind the workers' FP64 MFMAs, which use the same pipe
+  const int lane = threadIdx.x & 63, hw = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (hw == 7) return;
+  const int wave = (hw & 3) == 3 ? NW : (hw >> 2) * 3 + (hw & 3);
+  const int nbk = (a.c + 15) / 16;
+  if (wave == NW) {
+    // ---- the factor wave
+    bool bad = false;
+    __syncthreads();
+    for (int j = 0; j < nbk; ++j) {
+      XK_WSTAMP(0);
+      if (xk_chol16_bcast(dbuf, Ls[j & 1], lane)) bad = true;
+      XK_WSTAMP(1);
+      __syncthreads();                                             // barrier 1
+      if (j + 1 == nbk) break;
+      __syncthreads();                                             // barrier 2
+    }
+    if (bad && lane == 0) *a.status = 2;
+    return;
+  }
+  // ---- worker waves
+  const int li = lane & 15, lk = lane >> 4;
+  int si[NT], sk[NT];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int i = a.tab.i[wave][s], k = a.tab.k[wave][s];
+    si[s] = (i == 255) ? -1 : i;
+    sk[s] = (i == 255) ? -1 : k;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {                                    // chunk tiles: row blocks wave, wave + NW
+    si[NS + u] = (wave + NW * u < nbk) ? wave + NW * u : -1;
+    sk[NS + u] = XR;
+  }
+  const int rcol = a.c + 16 * (int)blockIdx.x + li;                // the chunk's column of Maug / X
+  const bool rc_ok = rcol < a.ncols;
+  xk_d4 T[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * si[s] + lk + 4 * r, col = (s < NS) ? 16 * sk[s] + li : rcol;
+      double v = 0.0;
+      if (si[s] >= 0) {
+        if (s < NS) v = (row < a.c && col < a.c) ? a.Maug[(size_t)row * a.ld + col] : (row == col ? 1.0 : 0.0);
+        else v = (rc_ok && row < a.c) ? a.Maug[(size_t)row * a.ld + col] : 0.0;
+      }
+      T[s][r] = v;
+    }
+  }
+  if (wave == 0) {                                                 // tile (0,0) = wave 0, slot 0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dbuf[64 * r + lane] = T[0][r];
+  }
+  __syncthreads();
+  for (int j = 0; j < nbk; ++j) {
+    const int par = j & 1;
+    XK_WSTAMP(0);
+    __syncthreads();                                               // barrier 1: Ls[par] = L_jj^-1
+    XK_WSTAMP(2);
+    // ---- B: row j of X (the tile above the next diagonal tile first)
+    double lv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lv[q] = Ls[par][li * 17 + 4 * q + lk];
+#pragma unroll
+    for (int s = 2; s < NT; ++s) {
+      if (si[s] == j) {
+        xk_d4 x = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[q], T[s][q], x, 0, 0, 0);
+        if (s == 2 || s == 3) {
+          // (j,j+1) -> the next diagonal tile, from registers: S -= X^T X
+#pragma unroll
+          for (int q = 0; q < 4; ++q) T[s - 2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[q], x[q], T[s - 2], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dbuf[64 * r + lane] = T[s - 2][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xs[par][sk[s]][64 * r + lane] = x[r];
+        if (s >= NS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * j + lk + 4 * r;
+            if (rc_ok && row < a.c) a.X[(size_t)row * a.ld + rcol] = x[r];
+          }
+        }
+      }
+    }
+    XK_WSTAMP(3);
+    if (j + 1 == nbk) break;
+    __syncthreads();                                               // barrier 2: Xs[par], dbuf
+    XK_WSTAMP(4);
+    // ---- C: trailing update (FP64-MFMA bound: three waves per SIMD hide the operand fetches)
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+      if (si[s] > j && !(si[s] == j + 1 && sk[s] == j + 1)) {
+        const double *xi = &Xs[par][si[s]][lane], *xk = &Xs[par][sk[s]][lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) T[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[64 * q], xk[64 * q], T[s], 0, 0, 0);
+      }
+    }
+    XK_WSTAMP(5);
+  }
+}
+
 // corr[i] = sum_k X[k][xoff+i] * y[k] - ct[i]      (K z' - corr_tot, updater.cpp:126)
 struct XkCorrArgs {
   const double *X;
