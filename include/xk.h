@@ -251,6 +251,50 @@ long xk_payload_doubles(int n_poses_max, int n_feat_max);
 int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, const double *dyn16,
                     double *d_dst, double **d_payload);
 
+/* ---- place-recognition request filter + keyframe store ---------------------------
+ * The reference answers another agent's request by scoring the request's binary VLAD against its own keyframe
+ * database and returning the best keyframe's SimpleState + tracks (VIO::processOtherRequests, vio.cpp:462-496 ->
+ * PlaceRecognition::findPlace, place_recognition.cpp:677-683 -> Database::findCandidate, database.cpp:30-49); the
+ * requester then matches the returned descriptors against its own (findCorrespondences, place_recognition.cpp:249).
+ * The keyframes (payload in xk_pack_payload layout, packed tracks, descriptors, VLAD) stay in device memory, so a
+ * response is sent straight from HBM.  Descriptors are rows of desc_bytes bytes (ORB: 32). */
+typedef struct xk_pr xk_pr;
+
+/* Vocabulary = a DBoW3 tree (PRVocabulary, types.h:33): k, L, node descriptors [n_nodes][desc_bytes], children
+ * [n_nodes][kmax] (-1 padded, in file order), word_of_node [n_nodes] (-1 for inner nodes), node_of_word [n_words].
+ * payload_doubles / tracks_doubles: sizes of the per-keyframe device buffers; max_desc: most descriptors per call. */
+int xk_pr_create(xk_handle *h, int k, int L, int n_nodes, int kmax, int desc_bytes, const unsigned char *node_desc,
+                 const int *children, const int *word_of_node, const int *node_of_word, int n_words,
+                 long payload_doubles, long tracks_doubles, int max_desc, xk_pr **out);
+void xk_pr_destroy(xk_pr *p);
+int xk_pr_vlad_bytes(const xk_pr *p);   /* k^L * desc_bytes (vlad.cpp:27-31: v_length_ / 8) */
+int xk_pr_size(const xk_pr *p);         /* keyframes in the store (<= 15, database.h:70) */
+
+/* VLAD::computeVLAD (vlad.cpp:40-66) / Database::computeVLAD (database.cpp:26-28): desc HOST [n][desc_bytes] ->
+ * vlad_out HOST [xk_pr_vlad_bytes]. */
+int xk_pr_compute_vlad(xk_pr *p, const unsigned char *desc, int n, unsigned char *vlad_out);
+
+/* Database::addKeyframe (database.cpp:51-61): VLAD of the keyframe's descriptors (Keyframe::getDescriptors order:
+ * MSCKF, SLAM, OPP tracks, keyframe.cpp:40-52), stored with the DEVICE payload / tracks buffers (copied; may be NULL)
+ * and a caller tag; the oldest keyframe is dropped beyond 15. */
+int xk_pr_add_keyframe(xk_pr *p, const unsigned char *desc, int n_desc, const double *d_payload, const double *d_tracks,
+                       long tag);
+
+/* Database::findCandidate (database.cpp:30-49): best-scoring keyframe with score > pr_score_thr that has not yet
+ * been sent to `uav_id` (Keyframe::findOtherUavId); marks it as sent.  *index = position in the store, oldest
+ * first, or -1; *score = (v_length - hamming) / v_length of the winner (VLAD::computeScore, vlad.cpp:68-75). */
+int xk_pr_find_candidate(xk_pr *p, int uav_id, const unsigned char *query_vlad, double pr_score_thr, int *index,
+                         double *score, long *tag);
+
+/* The stored keyframe `index`: DEVICE pointers of its payload / tracks (what VIO::processOtherRequests hands back,
+ * vio.cpp:489-495), its descriptor count and tag; desc_out (HOST, optional) receives the descriptors. */
+int xk_pr_keyframe(xk_pr *p, int index, const double **d_payload, const double **d_tracks, int *n_desc, long *tag,
+                   unsigned char *desc_out);
+
+/* matcher_->knnMatch(query = received, train = current, k = 2) with NORM_HAMMING (place_recognition.cpp:68-69,249):
+ * idx / dist HOST [nq][2], ascending (distance, train index); idx = -1 where the train set is too short. */
+int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned char *train, int nt, int *idx, int *dist);
+
 /* ---- measurement ----------------------------------------------------- */
 
 #define XK_NSTAGE 6

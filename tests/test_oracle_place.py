@@ -1,0 +1,123 @@
+"""CPU tests of the place-recognition oracle (oracle/ref_pr.py) and of the host half of the product's matching
+logic (x_multi_agent_amd/place.py): the vocabulary fixture unpacked from the reference's own data files,
+VLAD / score / database semantics (src/x/place_recognition/{vlad,database,keyframe}.cpp), 2-NN matching."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ref_pr
+from x_multi_agent_amd import place, synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", ["visual", "thermal"])
+def test_reference_vocabulary_fixture(name):
+    v = dict(np.load(os.path.join(GOLDEN, f"vocab_{name}.npz")))
+    voc = ref_pr.Vocabulary(v)
+    assert (voc.k, voc.L) == (4, 3)                       # Vocabulary/*_voc_3_4_*: depth 3, branching 4
+    assert voc.desc.shape == (85, 32) and len(voc.node_of_word) == 64
+    assert voc.clusters_n == 64 and voc.v_length == 64 * 32 * 8
+    leaves = [i for i in range(85) if voc.children[i][0] < 0]
+    assert sorted(voc.word_of_node[leaves]) == list(range(64))
+    assert all(voc.word_of_node[i] == -1 for i in range(85) if i not in leaves)
+    for w in range(64):
+        assert voc.word_of_node[voc.node_of_word[w]] == w
+    # every inner node has exactly k children whose parent it is
+    for i in range(85):
+        kids = [c for c in voc.children[i] if c >= 0]
+        assert len(kids) in (0, 4) and all(v["parent"][c] == i for c in kids)
+    # a word of the vocabulary is its own nearest centroid at the last level at least: descent ends on a leaf
+    for d in synth.make_descriptors(50, 32, seed=3):
+        assert 0 <= voc.transform(d) < 64
+
+
+def test_vlad_properties():
+    voc = ref_pr.Vocabulary(place.load_vocabulary("visual"))
+    x = synth.make_descriptors(120, 32, seed=5)
+    v = ref_pr.compute_vlad(voc, x)
+    assert v.shape == (64, 32) and v.dtype == np.uint8
+    # OR-linearity: the VLAD of a union is the OR of the VLADs; order does not matter
+    a, b = ref_pr.compute_vlad(voc, x[:50]), ref_pr.compute_vlad(voc, x[50:])
+    assert np.array_equal(v, a | b)
+    assert np.array_equal(v, ref_pr.compute_vlad(voc, x[::-1]))
+    assert np.array_equal(ref_pr.compute_vlad(voc, np.zeros((0, 32), np.uint8)), np.zeros((64, 32), np.uint8))
+    # a descriptor equal to its centroid contributes nothing
+    w = voc.transform(x[0])
+    cen = voc.get_word(w)
+    if voc.transform(cen) == w:
+        assert not ref_pr.compute_vlad(voc, cen[None, :]).any()
+    assert ref_pr.compute_score(voc, v, v) == 1.0
+    assert ref_pr.compute_score(voc, a, b) == ref_pr.compute_score(voc, b, a)
+    assert ref_pr.compute_score(voc, v, ~v) == 0.0
+
+
+def test_database_semantics():
+    voc = ref_pr.Vocabulary(synth.make_vocabulary(3, 2, 32, seed=1))
+    db = ref_pr.Database(voc, 0.6)
+    base = synth.make_descriptors(40, 32, seed=2)
+    for i in range(17):                                    # 17 keyframes: the two oldest are dropped
+        db.add_keyframe(ref_pr.Keyframe(synth.observe_descriptors(base, 3 * i, seed=i), tag=i))
+    assert [k.tag for k in db.keyframes] == list(range(2, 17))
+    q = ref_pr.compute_vlad(voc, base)
+    kf, idx, sc = db.find_candidate(4, q)
+    assert kf is not None and kf.tag == 2 + idx and sc > 0.6
+    scores = [ref_pr.compute_score(voc, q, k.vlad) for k in db.keyframes]
+    assert idx == int(np.argmax(scores)) and sc == max(scores)      # strict '>' keeps the first maximum
+    kf2, idx2, sc2 = db.find_candidate(4, q)               # already sent to uav 4: next best
+    assert idx2 != idx and (kf2 is None or sc2 <= sc)
+    kf3, idx3, _ = db.find_candidate(5, q)                 # another agent still gets the best one
+    assert idx3 == idx
+    assert ref_pr.Database(voc, 1.0).find_candidate(0, q) == (None, -1, 0.0)   # empty store
+    hi = ref_pr.Database(voc, 0.999999)
+    hi.add_keyframe(ref_pr.Keyframe(synth.observe_descriptors(base, 40, seed=9)))
+    assert hi.find_candidate(0, q)[0] is None              # below the threshold
+
+
+def test_knn2_against_sort_and_ties():
+    rng = np.random.default_rng(0)
+    train = synth.make_descriptors(30, 32, seed=4)
+    train[7] = train[3]                                    # exact duplicates: the earlier index must win
+    train[21] = train[3]
+    query = np.vstack([train[3], synth.observe_descriptors(train[10:20], 5, seed=1), rng.integers(0, 256, (5, 32), dtype=np.uint8)])
+    idx, dist = ref_pr.knn2(query, train)
+    assert tuple(idx[0]) == (3, 7) and tuple(dist[0]) == (0, 0)
+    for q in range(len(query)):
+        d = np.array([ref_pr.hamming(query[q], t) for t in train])
+        order = sorted(range(len(train)), key=lambda t: (d[t], t))[:2]
+        assert list(idx[q]) == order and list(dist[q]) == [d[order[0]], d[order[1]]]
+    i1, d1 = ref_pr.knn2(query, train[:1])
+    assert (i1[:, 1] == -1).all() and (i1[:, 0] == 0).all()
+    i0, _ = ref_pr.knn2(query, train[:0])
+    assert (i0 == -1).all()
+
+
+def test_good_matches_and_classification():
+    # received: 3 MSCKF, 2 SLAM, 2 OPP tracks; current: 2 MSCKF, 2 SLAM, 3 OPP tracks
+    idx = np.array([[4, 0], [5, 1], [0, 1], [2, 3], [6, 2], [4, 5], [6, 0]], np.int32)
+    dist = np.array([[10, 40], [12, 13], [5, 30], [8, 50], [9, 60], [20, 70], [11, 90]], np.int32)
+    good = ref_pr.good_matches(idx, dist, 50.0, 0.8)
+    # query 1 fails the ratio test (12 >= 13 * 0.8); queries 0 and 5 claim train 4, queries 4 and 6 claim train 6
+    assert place.good_matches(idx, dist, 50.0, 0.8) == good
+    assert (1, 5) not in good
+    trains = [t for _, t in good]
+    assert len(set(trains)) == len(trains)
+    cls = ref_pr.classify(good, 2, 2, 3, 2)
+    assert place.classify(good, 2, 2, 3, 2) == cls
+    kinds = {c[0] for c in cls}
+    assert kinds <= {"msckf", "slam", "opp_slam", "opp_opp"}
+    for kind, cur, rec in cls:
+        assert cur >= 0 and rec >= 0
+    # a mask drops the masked matches before the duplicate pass
+    assert ref_pr.good_matches(idx, dist, 50.0, 0.8, inlier_mask=[False] * 6) == []
+    assert ref_pr.good_matches(idx[:0], dist[:0], 50.0, 0.8) == []
+
+
+def test_keyframe_rule():
+    f = np.zeros(30)
+    f[3::3] = 0.2                                          # the reference reads elements 3, 6, 9, .. (vio_updater.cpp:458)
+    assert not ref_pr.is_keyframe(10, [1, 0, 0], [0, 0, 0], f, 50)        # needs more than 10 frames
+    assert ref_pr.is_keyframe(11, [1, 0, 0], [0, 0, 0], f, 50)
+    assert not ref_pr.is_keyframe(11, [0.1, 0, 0], [0, 0, 0], f, 50)      # parallax too small
+    assert not ref_pr.is_keyframe(11, [1, 0, 0], [0, 0, 0], f, 10)        # not enough tracks

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1610,3 +1611,224 @@ extern "C" int xk_debug_feature_phases(xk_handle *h, double sigma_img, long long
   return rc;
 }
 #endif
+
+// ---------------------------------------------------------------------------
+// Place-recognition request filter + keyframe store: the component either side of the CI
+// exchange on the communication axis.  Mirrors VLAD / Database / Keyframe of src/x/place_recognition.
+// ---------------------------------------------------------------------------
+#include "xk_place.hip.h"
+
+#define XK_PR_MAX_KEYFRAMES 15   // database.h:70
+
+struct xk_pr {
+  xk_handle *h;
+  int k, L, n_nodes, kmax, W, n_words, clusters, VW, max_desc;
+  long pay_n, trk_n;
+  unsigned int *d_node_desc;
+  int *d_children, *d_word_of_node, *d_node_of_word;
+  // keyframe store: slot s of the ring holds one keyframe; order[] lists the live slots oldest first
+  unsigned int *d_vlad;       // [15][VW]
+  unsigned int *d_kfdesc;     // [15][max_desc][W]
+  double *d_payload;          // [15][pay_n]
+  double *d_tracks;           // [15][trk_n]
+  int n_desc[XK_PR_MAX_KEYFRAMES];
+  long tag[XK_PR_MAX_KEYFRAMES];
+  std::vector<int> *uav_ids[XK_PR_MAX_KEYFRAMES];   // Keyframe::uav_ids_ (a std::set in the reference)
+  int order[XK_PR_MAX_KEYFRAMES], live;
+  // scratch
+  unsigned int *d_q, *d_t, *d_qvlad;
+  int *d_ham, *d_knn;
+  int *h_int;                 // pinned
+  unsigned int *h_words;      // pinned staging for descriptors / VLADs
+  size_t h_words_cap;
+};
+
+extern "C" void xk_pr_destroy(xk_pr *p) {
+  if (!p) return;
+  hipFree(p->d_node_desc); hipFree(p->d_children); hipFree(p->d_word_of_node); hipFree(p->d_node_of_word);
+  hipFree(p->d_vlad); hipFree(p->d_kfdesc); hipFree(p->d_payload); hipFree(p->d_tracks);
+  hipFree(p->d_q); hipFree(p->d_t); hipFree(p->d_qvlad); hipFree(p->d_ham); hipFree(p->d_knn);
+  if (p->h_int) hipHostFree(p->h_int);
+  if (p->h_words) hipHostFree(p->h_words);
+  for (auto &u : p->uav_ids) delete u;
+  free(p);
+}
+
+extern "C" int xk_pr_create(xk_handle *h, int k, int L, int n_nodes, int kmax, int desc_bytes,
+                            const unsigned char *node_desc, const int *children, const int *word_of_node,
+                            const int *node_of_word, int n_words, long payload_doubles, long tracks_doubles,
+                            int max_desc, xk_pr **out) {
+  if (!h || !out || !node_desc || !children || !word_of_node || !node_of_word) return XK_EINVAL;
+  if (k < 1 || L < 1 || n_nodes < 2 || kmax < 1 || n_words < 1 || max_desc < 1 || payload_doubles < 0 || tracks_doubles < 0)
+    return fail(h, XK_EINVAL, "xk_pr_create: bad sizes");
+  if (desc_bytes < 4 || desc_bytes % 4 || desc_bytes > 4 * XK_PR_MAXW)
+    return fail(h, XK_EINVAL, "xk_pr_create: descriptor size must be a multiple of 4 bytes, at most 64");
+  double cl = 1.0;
+  for (int i = 0; i < L; ++i) cl *= k;                       // pow(k, L), vlad.cpp:27-28
+  if (cl * desc_bytes > (double)(64 << 20)) return fail(h, XK_ECAPACITY, "xk_pr_create: VLAD larger than 64 MB");
+  for (int i = 0; i < n_nodes; ++i)
+    if (word_of_node[i] >= n_words || word_of_node[i] >= (int)cl) return fail(h, XK_EINVAL, "xk_pr_create: word id out of range");
+  xk_pr *p = (xk_pr *)calloc(1, sizeof(xk_pr));
+  if (!p) return XK_ENOMEM;
+  p->h = h; p->k = k; p->L = L; p->n_nodes = n_nodes; p->kmax = kmax; p->W = desc_bytes / 4; p->n_words = n_words;
+  p->clusters = (int)cl; p->VW = p->clusters * p->W; p->max_desc = max_desc; p->pay_n = payload_doubles; p->trk_n = tracks_doubles;
+  for (auto &u : p->uav_ids) u = new std::vector<int>();
+  const size_t wcap = std::max((size_t)max_desc * p->W * 2, (size_t)p->VW * 2);
+  p->h_words_cap = wcap;
+  bool ok = dalloc(&p->d_node_desc, (size_t)n_nodes * p->W) == hipSuccess && dalloc(&p->d_children, (size_t)n_nodes * kmax) == hipSuccess &&
+            dalloc(&p->d_word_of_node, (size_t)n_nodes) == hipSuccess && dalloc(&p->d_node_of_word, (size_t)n_words) == hipSuccess &&
+            dalloc(&p->d_vlad, (size_t)XK_PR_MAX_KEYFRAMES * p->VW) == hipSuccess &&
+            dalloc(&p->d_kfdesc, (size_t)XK_PR_MAX_KEYFRAMES * max_desc * p->W) == hipSuccess &&
+            dalloc(&p->d_payload, (size_t)XK_PR_MAX_KEYFRAMES * payload_doubles) == hipSuccess &&
+            dalloc(&p->d_tracks, (size_t)XK_PR_MAX_KEYFRAMES * tracks_doubles) == hipSuccess &&
+            dalloc(&p->d_q, (size_t)max_desc * p->W) == hipSuccess && dalloc(&p->d_t, (size_t)max_desc * p->W) == hipSuccess &&
+            dalloc(&p->d_qvlad, (size_t)p->VW) == hipSuccess && dalloc(&p->d_ham, (size_t)XK_PR_MAX_KEYFRAMES) == hipSuccess &&
+            dalloc(&p->d_knn, (size_t)max_desc * 4) == hipSuccess &&
+            hipHostMalloc((void **)&p->h_int, sizeof(int) * ((size_t)max_desc * 4 + 64)) == hipSuccess &&
+            hipHostMalloc((void **)&p->h_words, sizeof(unsigned int) * wcap) == hipSuccess;
+  if (ok) {
+    ok = hipMemcpy(p->d_node_desc, node_desc, (size_t)n_nodes * desc_bytes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_children, children, sizeof(int) * (size_t)n_nodes * kmax, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_word_of_node, word_of_node, sizeof(int) * (size_t)n_nodes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_node_of_word, node_of_word, sizeof(int) * (size_t)n_words, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok) { xk_pr_destroy(p); return fail(h, XK_ENOMEM, "xk_pr_create: allocation failed"); }
+  *out = p;
+  return XK_OK;
+}
+
+extern "C" int xk_pr_vlad_bytes(const xk_pr *p) { return p ? p->VW * 4 : 0; }
+extern "C" int xk_pr_size(const xk_pr *p) { return p ? p->live : 0; }
+
+// descriptors (host) -> VLAD in `d_dst` (device); the descriptors stay in p->d_q afterwards
+static int pr_vlad_device(xk_pr *p, const unsigned char *desc, int n, unsigned int *d_dst) {
+  xk_handle *h = p->h;
+  if (n < 0 || n > p->max_desc) return fail(h, XK_ECAPACITY, "place recognition: more descriptors than max_desc");
+  HIPCHK(h, hipMemsetAsync(d_dst, 0, sizeof(unsigned int) * p->VW, h->stream));
+  if (n > 0) {
+    if (!desc) return fail(h, XK_EINVAL, "place recognition: null descriptors");
+    memcpy(p->h_words, desc, (size_t)n * p->W * 4);
+    HIPCHK(h, hipMemcpyAsync(p->d_q, p->h_words, (size_t)n * p->W * 4, hipMemcpyHostToDevice, h->stream));
+    XkVladArgs a{p->d_q, n, p->W, p->d_node_desc, p->d_children, p->kmax, p->d_word_of_node, p->d_node_of_word, d_dst};
+    hipLaunchKernelGGL(xk_vlad_build, dim3((n + 255) / 256), dim3(256), 0, h->stream, a);
+  }
+  return XK_OK;
+}
+
+extern "C" int xk_pr_compute_vlad(xk_pr *p, const unsigned char *desc, int n, unsigned char *vlad_out) {
+  if (!p || !vlad_out) return XK_EINVAL;
+  xk_handle *h = p->h;
+  int rc = pr_vlad_device(p, desc, n, p->d_qvlad);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(p->h_words, p->d_qvlad, sizeof(unsigned int) * p->VW, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memcpy(vlad_out, p->h_words, sizeof(unsigned int) * p->VW);
+  return XK_OK;
+}
+
+extern "C" int xk_pr_add_keyframe(xk_pr *p, const unsigned char *desc, int n_desc, const double *d_payload,
+                                  const double *d_tracks, long tag) {
+  if (!p) return XK_EINVAL;
+  xk_handle *h = p->h;
+  // slot: a free one, or the oldest keyframe's (erase(begin()), database.cpp:56-58)
+  int slot;
+  if (p->live < XK_PR_MAX_KEYFRAMES) {
+    bool used[XK_PR_MAX_KEYFRAMES] = {false};
+    for (int i = 0; i < p->live; ++i) used[p->order[i]] = true;
+    slot = 0;
+    while (used[slot]) ++slot;
+  } else {
+    slot = p->order[0];
+    for (int i = 1; i < p->live; ++i) p->order[i - 1] = p->order[i];
+    --p->live;
+  }
+  int rc = pr_vlad_device(p, desc, n_desc, p->d_vlad + (size_t)slot * p->VW);
+  if (rc != XK_OK) return rc;
+  if (n_desc > 0)
+    HIPCHK(h, hipMemcpyAsync(p->d_kfdesc + (size_t)slot * p->max_desc * p->W, p->d_q, (size_t)n_desc * p->W * 4,
+                             hipMemcpyDeviceToDevice, h->stream));
+  if (d_payload && p->pay_n)
+    HIPCHK(h, hipMemcpyAsync(p->d_payload + (size_t)slot * p->pay_n, d_payload, sizeof(double) * p->pay_n, hipMemcpyDeviceToDevice, h->stream));
+  if (d_tracks && p->trk_n)
+    HIPCHK(h, hipMemcpyAsync(p->d_tracks + (size_t)slot * p->trk_n, d_tracks, sizeof(double) * p->trk_n, hipMemcpyDeviceToDevice, h->stream));
+  p->n_desc[slot] = n_desc; p->tag[slot] = tag; p->uav_ids[slot]->clear();
+  p->order[p->live++] = slot;
+  return XK_OK;
+}
+
+extern "C" int xk_pr_find_candidate(xk_pr *p, int uav_id, const unsigned char *query_vlad, double pr_score_thr, int *index,
+                                    double *score, long *tag) {
+  if (!p || !query_vlad || !index) return XK_EINVAL;
+  xk_handle *h = p->h;
+  *index = -1;
+  if (score) *score = 0.0;
+  if (tag) *tag = -1;
+  if (p->live == 0) return XK_OK;
+  memcpy(p->h_words, query_vlad, sizeof(unsigned int) * p->VW);
+  HIPCHK(h, hipMemcpyAsync(p->d_qvlad, p->h_words, sizeof(unsigned int) * p->VW, hipMemcpyHostToDevice, h->stream));
+  XkVladHamArgs a{p->d_qvlad, p->d_vlad, p->VW, p->d_ham};
+  hipLaunchKernelGGL(xk_vlad_hamming, dim3(XK_PR_MAX_KEYFRAMES), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipMemcpyAsync(p->h_int, p->d_ham, sizeof(int) * XK_PR_MAX_KEYFRAMES, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  // the selection loop of Database::findCandidate (database.cpp:32-45), keyframes oldest first
+  const double v_length = (double)p->VW * 32.0;
+  double best = 0.0;
+  int best_pos = -1;
+  for (int i = 0; i < p->live; ++i) {
+    const int s = p->order[i];
+    bool seen = false;
+    for (int u : *p->uav_ids[s]) seen |= (u == uav_id);
+    if (seen) continue;
+    const double sc = (v_length - (double)p->h_int[s]) / v_length;      // vlad.cpp:71
+    if (sc > pr_score_thr && sc > best) { best = sc; best_pos = i; }
+  }
+  if (best_pos >= 0) {
+    p->uav_ids[p->order[best_pos]]->push_back(uav_id);
+    *index = best_pos;
+    if (score) *score = best;
+    if (tag) *tag = p->tag[p->order[best_pos]];
+  }
+  return XK_OK;
+}
+
+extern "C" int xk_pr_keyframe(xk_pr *p, int index, const double **d_payload, const double **d_tracks, int *n_desc, long *tag,
+                              unsigned char *desc_out) {
+  if (!p) return XK_EINVAL;
+  xk_handle *h = p->h;
+  if (index < 0 || index >= p->live) return fail(h, XK_EINVAL, "xk_pr_keyframe: no such keyframe");
+  const int s = p->order[index];
+  if (d_payload) *d_payload = p->d_payload + (size_t)s * p->pay_n;
+  if (d_tracks) *d_tracks = p->d_tracks + (size_t)s * p->trk_n;
+  if (n_desc) *n_desc = p->n_desc[s];
+  if (tag) *tag = p->tag[s];
+  if (desc_out && p->n_desc[s] > 0) {
+    HIPCHK(h, hipMemcpyAsync(p->h_words, p->d_kfdesc + (size_t)s * p->max_desc * p->W, (size_t)p->n_desc[s] * p->W * 4,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    memcpy(desc_out, p->h_words, (size_t)p->n_desc[s] * p->W * 4);
+  }
+  return XK_OK;
+}
+
+extern "C" int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned char *train, int nt, int *idx,
+                               int *dist) {
+  if (!p || !idx || !dist || nq < 0 || nt < 0) return XK_EINVAL;
+  xk_handle *h = p->h;
+  if (nq > p->max_desc || nt > p->max_desc) return fail(h, XK_ECAPACITY, "xk_pr_knn_match: more descriptors than max_desc");
+  if (nq == 0) return XK_OK;
+  if (!query || (nt > 0 && !train)) return fail(h, XK_EINVAL, "xk_pr_knn_match: null descriptors");
+  const size_t qb = (size_t)nq * p->W * 4, tb = (size_t)nt * p->W * 4;
+  memcpy(p->h_words, query, qb);
+  if (nt) memcpy(p->h_words + (size_t)nq * p->W, train, tb);
+  HIPCHK(h, hipMemcpyAsync(p->d_q, p->h_words, qb, hipMemcpyHostToDevice, h->stream));
+  if (nt) HIPCHK(h, hipMemcpyAsync(p->d_t, p->h_words + (size_t)nq * p->W, tb, hipMemcpyHostToDevice, h->stream));
+  XkKnnArgs a{p->d_q, p->d_t, nq, nt, p->W, p->d_knn, p->d_knn + 2 * (size_t)p->max_desc};
+  hipLaunchKernelGGL(xk_desc_knn2, dim3((nq + 255) / 256), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipMemcpyAsync(p->h_int, p->d_knn, sizeof(int) * 2 * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(p->h_int + 2 * (size_t)nq, p->d_knn + 2 * (size_t)p->max_desc, sizeof(int) * 2 * (size_t)nq,
+                           hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memcpy(idx, p->h_int, sizeof(int) * 2 * (size_t)nq);
+  memcpy(dist, p->h_int + 2 * (size_t)nq, sizeof(int) * 2 * (size_t)nq);
+  return XK_OK;
+}

@@ -310,3 +310,53 @@ MANAGE_SEQUENCES = {
     # headline-sized state
     "manage_n30_m0": dict(n_poses_max=30, n_feat_max=0, n_steps=3, seed=0x5EED3003, start_poses=29),
 }
+
+
+# ---- place recognition: synthetic binary descriptors and vocabularies ------------------
+def make_vocabulary(k, L, desc_bytes=32, seed=7, prune=0.0):
+    """A random DBoW3-shaped vocabulary tree: every inner node has up to k children (a fraction `prune` of the
+    non-first children is dropped, so child counts differ), depth L, random binary node descriptors; leaves are the
+    words, numbered in depth-first file order like Vocabulary::toStream writes them."""
+    rng = np.random.default_rng(seed)
+    parent, depth = [-1], [0]
+    children = [[]]
+    stack = [0]
+    while stack:                                   # depth-first, the order DBoW3 saves nodes in
+        pid = stack.pop()
+        if depth[pid] == L:
+            continue
+        kids = []
+        for c in range(k):
+            if c > 0 and rng.random() < prune:
+                continue
+            nid = len(parent)
+            parent.append(pid); depth.append(depth[pid] + 1); children.append([])
+            kids.append(nid)
+        children[pid] = kids
+        stack.extend(reversed(kids))
+    nn = len(parent)
+    desc = rng.integers(0, 256, size=(nn, desc_bytes), dtype=np.uint8)
+    ch = np.full((nn, k), -1, np.int32)
+    for i, c in enumerate(children):
+        ch[i, :len(c)] = c
+    leaves = [i for i in range(1, nn) if not children[i]]
+    word_of_node = np.full(nn, -1, np.int32)
+    word_of_node[leaves] = np.arange(len(leaves), dtype=np.int32)
+    return dict(k=np.int32(k), L=np.int32(L), desc=desc, children=ch, word_of_node=word_of_node,
+                node_of_word=np.asarray(leaves, np.int32), parent=np.asarray(parent, np.int32))
+
+
+def make_descriptors(n, desc_bytes=32, seed=11):
+    """n random binary descriptors (one per landmark)."""
+    return np.random.default_rng(seed).integers(0, 256, size=(n, desc_bytes), dtype=np.uint8)
+
+
+def observe_descriptors(base, flip_bits, seed):
+    """What another view of the same landmarks extracts: every descriptor with `flip_bits` random bits flipped."""
+    rng = np.random.default_rng(seed)
+    out = np.array(base, dtype=np.uint8, copy=True)
+    nbits = out.shape[1] * 8
+    for i in range(out.shape[0]):
+        for b in rng.choice(nbits, size=flip_bits, replace=False):
+            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
