@@ -32,6 +32,7 @@ sys.path.insert(0, HERE)
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
 CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
 CI_TRACKS = 2             # shared MSCKF tracks fused per CI round
+PR_SCORE_THR = 0.6        # pr_score_thr (vio.cpp:670): minimum VLAD similarity for a keyframe to be sent back
 CI_MSCKF_W = 0.05         # fixed CI weight per other agent (w0 = 1 - k*w > 0 for k <= 7)
 
 
@@ -175,6 +176,17 @@ def main():
     tex = fleet.Exchange(dist, world, rank, CI_TRACKS * (1 + 2 * N), xdev)
     tex.send.copy_(torch.from_numpy(fleet.pack_tracks(sc, CI_TRACKS, N).ravel()))
     ci_stats = {"rounds": 0, "fused": 0}
+    if args.config == 5 and world > 1:
+        # keyframe database + request filter on the device (place.Database = x::Database, reference vocabulary)
+        from x_multi_agent_amd import place
+        trk_n = CI_TRACKS * (1 + 2 * N)
+        kdb = place.Database(eng, place.load_vocabulary("visual"), PR_SCORE_THR, payload_doubles=pay_n, tracks_doubles=trk_n,
+                             max_desc=256)
+        pr_scene = synth.make_descriptors(96, 32, seed=0x5EED)        # the place every agent of the fleet looks at
+        vex = fleet.Exchange(dist, world, rank, kdb.vlad_bytes, xdev, dtype=torch.uint8)
+        rex = fleet.Exchange(dist, world, rank, 2 + pay_n + trk_n, xdev)
+        resp_dev = torch.zeros(2 + pay_n + trk_n, dtype=torch.float64, device=f"cuda:{dev}")
+        trk_dev = torch.zeros(trk_n, dtype=torch.float64, device=f"cuda:{dev}")
 
     def exchange(step):
         """CI round: all-gather the snapshots over RCCL, then fuse the shared tracks against them on the device."""
@@ -183,16 +195,34 @@ def main():
         eng.pack_payload_into(rank, float(step), dyn16, pay_dev.data_ptr())   # packed on the device ...
         ex.send.copy_(pay_dev)                                                # ... into the RCCL send buffer
         if args.config == 5:
-            # request/response mode (VIO::processOtherRequests, vio.cpp:462-496): one responder per requester and tick
-            reqs = fleet.ring_requests(world, step // ci_every)
-            gp, gt = ex.request_response(reqs), tex.request_response(reqs)
-            (rsp, rp), = gp.items()
-            allp, allt = torch.stack([ex.send, rp]), torch.stack([tex.send, gt[rsp]])
+            # request/response mode (VIO::processOtherRequests, vio.cpp:462-496): every tick an agent stores a keyframe
+            # (snapshot + tracks + descriptors, all resident in HBM), sends the binary VLAD of what it sees to one
+            # responder, and fuses against the keyframe that comes back -- if the responder's database has one
+            tick = step // ci_every
+            trk_dev.copy_(tex.send)
+            kdb.add_keyframe(synth.observe_descriptors(pr_scene, 4, seed=7919 * rank + tick), pay_dev.data_ptr(),
+                             trk_dev.data_ptr(), tag=step)
+            my_vlad = torch.from_numpy(kdb.compute_vlad(synth.observe_descriptors(pr_scene, 4, seed=104729 * rank + tick)).ravel())
+
+            def answer(requester, vlad):
+                idx, _score, tag = kdb.find_candidate(int(requester), vlad.cpu().numpy())
+                if idx >= 0:
+                    kdb.copy_keyframe(idx, resp_dev.data_ptr() + 16, resp_dev.data_ptr() + 8 * (2 + pay_n))
+                    resp_dev[0], resp_dev[1] = 1.0, float(tag)
+                    rex.send.copy_(resp_dev)
+
+            got = fleet.request_round(vex, rex, fleet.ring_requests(world, tick), my_vlad, answer)
+            (rsp, buf), = got.items()
+            ci_stats["rounds"] += 1
+            if float(buf[0]) == 0.0:
+                return
+            allp = torch.stack([ex.send, buf[2:2 + pay_n]])
+            allt = torch.stack([tex.send, buf[2 + pay_n:]])
             if allp.device.type != "cuda":
                 allp, allt = allp.cuda(dev), allt.cuda(dev)
             fused, _ = fleet.ci_round_device(eng, sc, 0, 2, allp, allt, CI_TRACKS, CI_MSCKF_W)
-            ci_stats["rounds"] += 1
             ci_stats["fused"] += fused
+            ci_stats["keyframes_received"] = ci_stats.get("keyframes_received", 0) + 1
             return
         allp, allt = ex.all_gather(), tex.all_gather()
         if allp.device.type != "cuda":           # gloo functional mode: the exchange ran on host tensors
@@ -267,11 +297,12 @@ def main():
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: one agent per GPU, window N={N}, "
                                       f"K={K} MSCKF tracks (L=N), M={M} SLAM features, n={15 + 6 * N + 3 * M}; "
-                                      + (f"CI payload request/response (ring) every {ci_every} updates" if args.config == 5
+                                      + (f"request/response every {ci_every} updates: binary-VLAD request, best keyframe of the responder's database back (ring)" if args.config == 5
                                          else f"CI payload all-gather every {ci_every} updates"),
                           "n_poses_max": N, "k_msckf": K, "m_slam": M, "agents": world,
                           "ci_every": ci_every, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
-                          "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"]},
+                          "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"],
+                          **({"keyframes_received_rank0": ci_stats.get("keyframes_received", 0)} if args.config == 5 else {})},
                "roofline": roof, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
         print(json.dumps(out), flush=True)

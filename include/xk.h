@@ -291,6 +291,10 @@ int xk_pr_find_candidate(xk_pr *p, int uav_id, const unsigned char *query_vlad, 
 int xk_pr_keyframe(xk_pr *p, int index, const double **d_payload, const double **d_tracks, int *n_desc, long *tag,
                    unsigned char *desc_out);
 
+/* Copies the stored keyframe's payload / tracks into caller-owned DEVICE buffers (e.g. the RCCL send buffer of the
+ * response) and waits for the copy. */
+int xk_pr_copy_keyframe(xk_pr *p, int index, double *d_payload_dst, double *d_tracks_dst);
+
 /* matcher_->knnMatch(query = received, train = current, k = 2) with NORM_HAMMING (place_recognition.cpp:68-69,249):
  * idx / dist HOST [nq][2], ascending (distance, train index); idx = -1 where the train set is too short. */
 int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned char *train, int nt, int *idx, int *dist);

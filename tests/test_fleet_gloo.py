@@ -77,6 +77,66 @@ def test_two_agents_exchange_over_gloo():
     assert res[0][2] > 0 and res[1][2] > 0
 
 
+def _rr_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from oracle import ref_pr
+    from x_multi_agent_amd import fleet, place, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the protocol with the CPU restatement as the keyframe store (the product uses place.Database on the GPU)
+        voc = ref_pr.Vocabulary(place.load_vocabulary("visual"))
+        db = ref_pr.Database(voc, 0.6)
+        scene = synth.make_descriptors(80, 32, seed=77)                       # both agents look at the same place
+        pay_n = 5
+        vex = fleet.Exchange(dist, world, rank, voc.clusters_n * voc.d_length, "cpu", dtype=torch.uint8)
+        rex = fleet.Exchange(dist, world, rank, 2 + pay_n, "cpu")
+        log = []
+        for tick in range(3):
+            db.add_keyframe(ref_pr.Keyframe(synth.observe_descriptors(scene, 3, seed=10 * rank + tick),
+                                            payload=np.full(pay_n, 100.0 * rank + tick), tag=tick))
+            mine = ref_pr.compute_vlad(voc, synth.observe_descriptors(scene, 3, seed=500 + 10 * rank + tick))
+
+            def answer(requester, vlad):
+                kf, idx, sc = db.find_candidate(requester, vlad.numpy().reshape(voc.clusters_n, voc.d_length))
+                if kf is not None:
+                    rex.send[0], rex.send[1] = 1.0, float(kf.tag)
+                    rex.send[2:] = torch.from_numpy(kf.payload)
+
+            got = fleet.request_round(vex, rex, fleet.ring_requests(world, tick), torch.from_numpy(mine.ravel()), answer)
+            (rsp, buf), = got.items()
+            log.append((int(rsp), float(buf[0]), float(buf[1]), float(buf[2])))
+        q.put((rank, "ok", log))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "fail: " + repr(e), []))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_request_response_protocol_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rr_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    for rank, _, log in res:
+        other = 1 - rank
+        assert [e[0] for e in log] == [other] * 3 and all(e[1] == 1.0 for e in log)
+        tags = [e[2] for e in log]
+        assert len(set(tags)) == 3                     # a keyframe goes to the same requester only once
+        assert all(e[3] == 100.0 * other + e[2] for e in log)      # the payload that came back is that keyframe's
+
+
 def test_payload_roundtrip_and_layout():
     sys.path.insert(0, ROOT)
     from x_multi_agent_amd import engine, fleet, synth

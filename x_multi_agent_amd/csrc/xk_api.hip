@@ -1810,6 +1810,19 @@ extern "C" int xk_pr_keyframe(xk_pr *p, int index, const double **d_payload, con
   return XK_OK;
 }
 
+extern "C" int xk_pr_copy_keyframe(xk_pr *p, int index, double *d_payload_dst, double *d_tracks_dst) {
+  if (!p) return XK_EINVAL;
+  xk_handle *h = p->h;
+  if (index < 0 || index >= p->live) return fail(h, XK_EINVAL, "xk_pr_copy_keyframe: no such keyframe");
+  const int s = p->order[index];
+  if (d_payload_dst && p->pay_n)
+    HIPCHK(h, hipMemcpyAsync(d_payload_dst, p->d_payload + (size_t)s * p->pay_n, sizeof(double) * p->pay_n, hipMemcpyDeviceToDevice, h->stream));
+  if (d_tracks_dst && p->trk_n)
+    HIPCHK(h, hipMemcpyAsync(d_tracks_dst, p->d_tracks + (size_t)s * p->trk_n, sizeof(double) * p->trk_n, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return XK_OK;
+}
+
 extern "C" int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned char *train, int nt, int *idx,
                                int *dist) {
   if (!p || !idx || !dist || nq < 0 || nt < 0) return XK_EINVAL;

@@ -7,7 +7,8 @@ src/x/vio/vio.cpp:447-450).  Agents therefore shard one per rank with NO
 data-path collective inside an update; every `ci_every` updates the payloads
 are exchanged:
   broadcast mode   (VIO::getDataToSend, vio.cpp:440-451)     -> one all-gather
-  request/response (VIO::processOtherRequests, vio.cpp:462-496) -> send/recv pairs
+  request/response (VIO::processOtherRequests, vio.cpp:462-496) -> send/recv pairs: the requester's binary
+                   VLAD goes out, the responder's best keyframe (place.Database, xk_pr_*) comes back
 The same functions run over RCCL (backend "nccl", GPU tensors) in bench.py and
 over gloo (CPU tensors) in tests/test_fleet_gloo.py.
 
@@ -73,12 +74,13 @@ def unpack_payload(buf, N, M):
 class Exchange:
     """CI message exchange over torch.distributed (RCCL on GPUs, gloo on CPU)."""
 
-    def __init__(self, dist, world, rank, payload_doubles, device):
+    def __init__(self, dist, world, rank, payload_doubles, device, dtype=None):
         import torch
         self.dist, self.world, self.rank, self.n = dist, world, rank, payload_doubles
         self.torch = torch
-        self.send = torch.zeros(payload_doubles, dtype=torch.float64, device=device)
-        self.recv = torch.zeros(payload_doubles * max(world, 1), dtype=torch.float64, device=device)
+        dtype = dtype or torch.float64           # torch.uint8 for the binary VLAD of a request
+        self.send = torch.zeros(payload_doubles, dtype=dtype, device=device)
+        self.recv = torch.zeros(payload_doubles * max(world, 1), dtype=dtype, device=device)
 
     def all_gather(self):
         """Broadcast mode: every agent receives every agent's payload (config 4)."""
@@ -107,6 +109,24 @@ class Exchange:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
         return got
+
+
+def request_round(vex, rex, requests, my_vlad, answer):
+    """One request/response tick of the reference's REQUEST_COMM mode.  Every requester's binary VLAD
+    (VIO::getDescriptors, vio.cpp:455-460 -> Database::computeVLAD) travels to its responder over `vex`; on the
+    responder `answer(requester, vlad_tensor)` runs the keyframe search (VIO::processOtherRequests, vio.cpp:462-496)
+    and fills `rex.send` -- word 0 = 1.0 if a keyframe goes back, followed by its SimpleState payload and tracks;
+    the responses travel back over `rex` (-> VIO::processOtherMeasurements, vio.cpp:498-570).
+    requests: [(requester, responder)], at most one request per responder and tick.
+    Returns {responder: response tensor} for the requests this rank made."""
+    vex.send.copy_(my_vlad)
+    asked = vex.request_response([(rsp, req) for req, rsp in requests])   # requests flow requester -> responder
+    if len(asked) > 1:
+        raise ValueError("more than one request per responder and tick")
+    rex.send[0] = 0.0
+    for requester, vlad in asked.items():
+        answer(requester, vlad)
+    return rex.request_response(requests)
 
 
 def ring_requests(world, tick):

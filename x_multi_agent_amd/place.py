@@ -103,6 +103,12 @@ class Database:
             out["descriptors"] = buf[:nd.value].copy()
         return out
 
+    def copy_keyframe(self, index, payload_dst_ptr=None, tracks_dst_ptr=None):
+        """The stored keyframe's payload / tracks into caller-owned DEVICE buffers (the response's send buffer)."""
+        pp = C.cast(C.c_void_p(payload_dst_ptr), c_dp) if payload_dst_ptr else None
+        tp = C.cast(C.c_void_p(tracks_dst_ptr), c_dp) if tracks_dst_ptr else None
+        self._chk(self.L.xk_pr_copy_keyframe(self.p, C.c_int(index), pp, tp), "xk_pr_copy_keyframe")
+
     def knn_match(self, query, train):
         """BFMatcher(NORM_HAMMING).knnMatch(query, train, 2) -> (idx [nq,2], dist [nq,2])."""
         q, qp = _u8(np.asarray(query, np.uint8).reshape(-1, self.desc_bytes))
