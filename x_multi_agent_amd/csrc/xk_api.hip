@@ -1836,7 +1836,7 @@ extern "C" int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, con
   HIPCHK(h, hipMemcpyAsync(p->d_q, p->h_words, qb, hipMemcpyHostToDevice, h->stream));
   if (nt) HIPCHK(h, hipMemcpyAsync(p->d_t, p->h_words + (size_t)nq * p->W, tb, hipMemcpyHostToDevice, h->stream));
   XkKnnArgs a{p->d_q, p->d_t, nq, nt, p->W, p->d_knn, p->d_knn + 2 * (size_t)p->max_desc};
-  hipLaunchKernelGGL(xk_desc_knn2, dim3((nq + 255) / 256), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(xk_desc_knn2, dim3((nq + XK_KNN_Q - 1) / XK_KNN_Q), dim3(256), 0, h->stream, a);
   HIPCHK(h, hipMemcpyAsync(p->h_int, p->d_knn, sizeof(int) * 2 * (size_t)nq, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(p->h_int + 2 * (size_t)nq, p->d_knn + 2 * (size_t)p->max_desc, sizeof(int) * 2 * (size_t)nq,
                            hipMemcpyDeviceToHost, h->stream));

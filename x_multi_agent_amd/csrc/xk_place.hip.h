@@ -80,16 +80,25 @@ __global__ __launch_bounds__(256) void xk_vlad_hamming(XkVladHamArgs a) {
 }
 
 // Two nearest train descriptors of every query in ascending (distance, train index) order; -1 / INT_MAX-ish
-// where the train set has fewer than two rows.  One thread per query, the train set walked through LDS tiles.
+// where the train set has fewer than two rows.  A workgroup takes 32 queries; its 256 threads are 32 queries x 8
+// segments of every 256-row train tile (streamed through LDS), and the eight partial top-2 lists of a query are
+// merged lexicographically on (distance, index) -- so the result does not depend on how the scan was split.
 struct XkKnnArgs {
   const unsigned int *query, *train;   // [nq][W], [nt][W]
   int nq, nt, W;
   int *idx, *dist;                     // [nq][2]
 };
 #define XK_KNN_TILE 256
+#define XK_KNN_Q 32
+__device__ __forceinline__ void xk_knn_push(int d, int i, int &d0, int &i0, int &d1, int &i1) {
+  if (d < d0 || (d == d0 && i < i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+  else if (d < d1 || (d == d1 && i < i1)) { d1 = d; i1 = i; }
+}
 __global__ __launch_bounds__(256) void xk_desc_knn2(XkKnnArgs a) {
   __shared__ unsigned int tile[XK_KNN_TILE * XK_PR_MAXW];
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ int part[8][XK_KNN_Q][4];
+  const int ql = threadIdx.x & (XK_KNN_Q - 1), seg = threadIdx.x >> 5;
+  const int q = blockIdx.x * XK_KNN_Q + ql;
   unsigned int d[XK_PR_MAXW];
 #pragma unroll
   for (int w = 0; w < XK_PR_MAXW; ++w) d[w] = (q < a.nq && w < a.W) ? a.query[(size_t)q * a.W + w] : 0u;
@@ -99,18 +108,26 @@ __global__ __launch_bounds__(256) void xk_desc_knn2(XkKnnArgs a) {
     __syncthreads();
     for (int i = threadIdx.x; i < cnt * a.W; i += blockDim.x) tile[i] = a.train[(size_t)base * a.W + i];
     __syncthreads();
-    for (int t = 0; t < cnt; ++t) {
+    const int t1 = min(cnt, 32 * seg + 32);
+    for (int t = 32 * seg; t < t1; ++t) {
       int dist = 0;
 #pragma unroll
       for (int w = 0; w < XK_PR_MAXW; ++w)
         if (w < a.W) dist += __popc(d[w] ^ tile[t * a.W + w]);
-      // train indices arrive in ascending order, so strict '<' keeps the earlier index on ties
+      // (within a thread the train indices arrive in ascending order: strict '<' keeps the earlier one on ties)
       if (dist < d0) { d1 = d0; i1 = i0; d0 = dist; i0 = base + t; }
       else if (dist < d1) { d1 = dist; i1 = base + t; }
     }
   }
-  if (q < a.nq) {
-    a.idx[2 * q] = i0; a.idx[2 * q + 1] = i1;
-    a.dist[2 * q] = d0; a.dist[2 * q + 1] = d1;
+  part[seg][ql][0] = d0; part[seg][ql][1] = i0; part[seg][ql][2] = d1; part[seg][ql][3] = i1;
+  __syncthreads();
+  if (seg == 0 && q < a.nq) {
+    int e0 = 1 << 30, j0 = -1, e1 = 1 << 30, j1 = -1;
+    for (int s = 0; s < 8; ++s) {
+      if (part[s][ql][1] >= 0) xk_knn_push(part[s][ql][0], part[s][ql][1], e0, j0, e1, j1);
+      if (part[s][ql][3] >= 0) xk_knn_push(part[s][ql][2], part[s][ql][3], e0, j0, e1, j1);
+    }
+    a.idx[2 * q] = j0; a.idx[2 * q + 1] = j1;
+    a.dist[2 * q] = e0; a.dist[2 * q + 1] = e1;
   }
 }
