@@ -701,6 +701,40 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   }
   __syncthreads();
   XK_STAMP(5);
+  // ---- tile write: rows 3.. of Q^T [J | res] over the active columns (:431-432,468-479), by the threads
+  //      t0, t0 + 1, .. of a group of `nthr`
+  auto tile_write = [&](int t0, int nthr) {
+    double *tile = a.A + (size_t)k * a.DB * a.C1P;
+    const int N3 = 3 * a.n_poses_max;
+    for (int c = t0; c < a.C1P; c += nthr) {
+      if (c == a.na) {
+        for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = res[r];
+        continue;
+      }
+      int i = -1, comp = 0;
+      const double *blk = nullptr;
+      if (c < N3) { i = c / 3 - p0; comp = c % 3; blk = Jp; }
+      else if (c < 2 * N3) { i = (c - N3) / 3 - p0; comp = (c - N3) % 3; blk = Ja; }
+      if (c >= a.na || i < 0 || i >= L) {
+        for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = 0.0;
+        continue;
+      }
+      const double x0 = blk[6 * i + comp], x1 = blk[6 * i + 3 + comp];
+      const int r0 = 2 * i;
+      const double a0 = V[r0] * x0 + V[r0 + 1] * x1;
+      const double a1 = V[m2 + r0] * x0 + V[m2 + r0 + 1] * x1;
+      const double a2 = V[2 * m2 + r0] * x0 + V[2 * m2 + r0 + 1] * x1;
+      const double w0 = tau0 * a0;
+      const double w1 = tau1 * (a1 - w0 * g01);
+      const double w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
+      for (int r = 3; r < m2; ++r) {
+        double v = -w0 * V[r] - w1 * V[m2 + r] - w2 * V[2 * m2 + r];
+        if (r == r0) v += x0;
+        if (r == r0 + 1) v += x1;
+        tile[(size_t)(r - 3) * a.C1P + c] = v;
+      }
+    }
+  };
   // ---- Cholesky of S = M[3:,3:] (d x d) with the residual as an extra row d (:457-458):
   //      y = L^-1 r0 falls out of the factorisation, gamma = |y|^2
   // Right-looking, un-normalised: S(i,j) -= S(i,k) S(j,k) / S(k,k) for i >= j > k touches only
@@ -714,6 +748,8 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
     double *colbuf = scal + 32 + 12 * Lmax + 64;
     colbuf += ((size_t)colbuf >> 3) & 1;
     if (tid < 64) xk_chol_gate_wave(Mm, ldm, d, tid, scal, colbuf);
+    else if (a.A) tile_write(tid - 64, XK_FEAT_THREADS - 64);   // the other three waves write the tile meanwhile: a
+                                                                 // rejected track's tile is masked by tile_rows = 0
   } else {
     xk_chol_gate<8>(Mm, ldm, d, tid, scal);
   }
@@ -772,37 +808,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
   }
   if (scal[11] == 0.0 || !a.A) { XK_WG_END(); return; }
 
-  // ---- tile write: rows 3.. of Q^T [J | res] over the active columns (:431-432,468-479)
-  double *tile = a.A + (size_t)k * a.DB * a.C1P;
-  const int N3 = 3 * a.n_poses_max;
-  for (int c = tid; c < a.C1P; c += XK_FEAT_THREADS) {
-    if (c == a.na) {
-      for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = res[r];
-      continue;
-    }
-    int i = -1, comp = 0;
-    const double *blk = nullptr;
-    if (c < N3) { i = c / 3 - p0; comp = c % 3; blk = Jp; }
-    else if (c < 2 * N3) { i = (c - N3) / 3 - p0; comp = (c - N3) % 3; blk = Ja; }
-    if (c >= a.na || i < 0 || i >= L) {
-      for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = 0.0;
-      continue;
-    }
-    const double x0 = blk[6 * i + comp], x1 = blk[6 * i + 3 + comp];
-    const int r0 = 2 * i;
-    const double a0 = V[r0] * x0 + V[r0 + 1] * x1;
-    const double a1 = V[m2 + r0] * x0 + V[m2 + r0 + 1] * x1;
-    const double a2 = V[2 * m2 + r0] * x0 + V[2 * m2 + r0 + 1] * x1;
-    const double w0 = tau0 * a0;
-    const double w1 = tau1 * (a1 - w0 * g01);
-    const double w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
-    for (int r = 3; r < m2; ++r) {
-      double v = -w0 * V[r] - w1 * V[m2 + r] - w2 * V[2 * m2 + r];
-      if (r == r0) v += x0;
-      if (r == r0 + 1) v += x1;
-      tile[(size_t)(r - 3) * a.C1P + c] = v;
-    }
-  }
+  if (d >= 64) tile_write(tid, XK_FEAT_THREADS);   // (shorter windows wrote the tile next to the single-wave gate)
   XK_STAMP(7);
   XK_WG_END();
 }
