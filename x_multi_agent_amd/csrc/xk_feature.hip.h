@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "xk_chol16.hip.h"
+
 #define XK_CORE 15
 typedef double xk_f2 __attribute__((ext_vector_type(2)));
 #define XK_FEAT_THREADS 256
@@ -293,13 +295,102 @@ __device__ __forceinline__ void xk_chol_gate_wave(const double *Mm, int ldm, int
   if (lane == 0 && bad) scal[10] = 1.0;
 }
 
+// The same gate for d <= 63 as a blocked Cholesky on ONE wave, 16 x 16 tiles in the MFMA C/D layout, all of
+// them (<= 10 of S plus <= 4 of the residual, which rides along as a right-hand-side column) in this wave's
+// registers: per block step the diagonal tile is factored and inverted by the DPP row-broadcast pivot chain
+// (xk_chol16_bcast, ~3.1 k clocks for 16 pivots against ~12 k through LDS above), row j becomes
+// X_jk = L_jj^-1 S_jk on the matrix cores, and the trailing tiles take S_ik -= X_ji^T X_jk straight from
+// registers (a C/D-layout register is both operands of X^T X).  gamma = |L^-1 r|^2 = the squares of the
+// residual column of X.  work: 256 + 16*17 doubles of LDS (diagonal tile row-major, L_jj^-1).
+__device__ __forceinline__ void xk_chol_gate_blocked(const double *Mm, int ldm, int d, int lane, double *scal, double *work) {
+#define XK_S(i, j) Mm[(size_t)(3 + (i)) * ldm + 3 + (j)]      // lower triangle valid; row d = the residual
+  constexpr int NB = 4;
+  const int nb = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
+  double *dbuf = work, *Ls = work + 256;
+  xk_d4 T[NB][NB], R[NB];                                     // T[i][k], i <= k
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+#pragma unroll
+    for (int k = i; k < NB; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * i + lk + 4 * q, c = 16 * k + li;  // element (r, c), r <= c off the diagonal tile
+        double v = (r == c) ? 1.0 : 0.0;                      // identity padding past d
+        if (i < nb && k < nb && r < d && c < d) v = (r >= c) ? XK_S(r, c) : XK_S(c, r);
+        T[i][k][q] = v;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 16 * i + lk + 4 * q;
+      R[i][q] = (li == 0 && r < d) ? XK_S(d, r) : 0.0;        // residual in column 0 of its tile
+    }
+  }
+  bool bad = false;
+  double g = 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j < nb) {                                             // uniform
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dbuf[64 * q + lane] = T[j][j][q];   // C/D layout == row-major 16 x 16
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (xk_chol16_bcast(dbuf, Ls, lane)) bad = true;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double lv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lv[q] = Ls[li * 17 + 4 * q + lk];
+      // row j
+#pragma unroll
+      for (int k = j + 1; k < NB; ++k) {
+        if (k < nb) {
+          xk_d4 x = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[q], T[j][k][q], x, 0, 0, 0);
+          T[j][k] = x;
+        }
+      }
+      {
+        xk_d4 x = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[q], R[j][q], x, 0, 0, 0);
+        R[j] = x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g = fma(x[q], x[q], g);   // only column 0 (lanes li == 0) is non-zero
+      }
+      // trailing tiles
+#pragma unroll
+      for (int i = j + 1; i < NB; ++i) {
+        if (i < nb) {
+#pragma unroll
+          for (int k = i; k < NB; ++k) {
+            if (k < nb) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) T[i][k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[j][i][q], T[j][k][q], T[i][k], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) R[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[j][i][q], R[j][q], R[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  g = xk_wave_sum(g);
+  if (lane == 0) {
+    scal[12] = g;
+    if (bad) scal[10] = 1.0;
+  }
+#undef XK_S
+}
+
 // LDS size in bytes for n_poses window poses.
 static inline size_t xk_feature_lds_bytes(int n_poses) {
   const int L = n_poses, m2 = 2 * L, ldm = m2 + 1;
-  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 134);
+  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 134 + 2 + 256 + 272);
 }
 
-__global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a_in) {
+__global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   XkFeatArgs a = a_in;
   if (a_in.batch) {
@@ -747,7 +838,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_feature(XkFeatArgs a
     // (the broadcast buffer is read two doubles at a time: 16-byte aligned)
     double *colbuf = scal + 32 + 12 * Lmax + 64;
     colbuf += ((size_t)colbuf >> 3) & 1;
-    if (tid < 64) xk_chol_gate_wave(Mm, ldm, d, tid, scal, colbuf);
+    if (tid < 64) xk_chol_gate_blocked(Mm, ldm, d, tid, scal, colbuf + 134);
     else if (a.A) tile_write(tid - 64, XK_FEAT_THREADS - 64);   // the other three waves write the tile meanwhile: a
                                                                  // rejected track's tile is masked by tile_rows = 0
   } else {
