@@ -592,7 +592,8 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu
   __syncthreads();
 
   XK_STAMP(2);
-  // ---- Householder QR of Hf (2L x 3) -> three reflectors (:423)
+  // ---- wave 0: Householder QR of Hf (2L x 3) -> three reflectors (:423), then the residual r' = Q^T res;
+  //      waves 1-3 meanwhile: the gate matrix (independent of the reflectors)
   if (tid < 64) {
     const int lane = tid;
     for (int kk = 0; kk < 3; ++kk) {
@@ -647,54 +648,9 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu
     g02 = xk_wave_sum(g02);
     g12 = xk_wave_sum(g12);
     if (lane == 0) { scal[3] = g01; scal[4] = g02; scal[5] = g12; }
-  }
-  __syncthreads();
-  const double tau0 = scal[0], tau1 = scal[1], tau2 = scal[2];
-  const double g01 = scal[3], g02 = scal[4], g12 = scal[5];
-
-  XK_STAMP(3);
-  // ---- gate matrix M = J P J^T + sigma^2 I from 6x6 blocks of P (:452-457)
-  {
-    const int n = a.n;
-    const double *P = a.P;
-    for (int idx = tid; idx < L * L; idx += XK_FEAT_THREADS) {
-      const int ia = idx / L, ib = idx - ia * L;
-      if (ia > ib) continue;
-      const int cpa = XK_CORE + 3 * (p0 + ia), caa = cpa + 3 * a.n_poses_max;
-      const int cpb = XK_CORE + 3 * (p0 + ib), cab = cpb + 3 * a.n_poses_max;
-      const double *jpa = Jp + 6 * ia, *jaa = Ja + 6 * ia, *jpb = Jp + 6 * ib, *jab = Ja + 6 * ib;
-      double t1[2][3], t2[2][3];  // rows of J_a times P[.., pos_b cols] / P[.., att_b cols]
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double *pc1 = P + (size_t)(cpb + c) * n, *pc2 = P + (size_t)(cab + c) * n;
-        const double p00 = pc1[cpa], p01 = pc1[cpa + 1], p02 = pc1[cpa + 2];
-        const double p10 = pc1[caa], p11 = pc1[caa + 1], p12 = pc1[caa + 2];
-        const double q00 = pc2[cpa], q01 = pc2[cpa + 1], q02 = pc2[cpa + 2];
-        const double q10 = pc2[caa], q11 = pc2[caa + 1], q12 = pc2[caa + 2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          t1[r][c] = jpa[3 * r] * p00 + jpa[3 * r + 1] * p01 + jpa[3 * r + 2] * p02 + jaa[3 * r] * p10 +
-                     jaa[3 * r + 1] * p11 + jaa[3 * r + 2] * p12;
-          t2[r][c] = jpa[3 * r] * q00 + jpa[3 * r + 1] * q01 + jpa[3 * r + 2] * q02 + jaa[3 * r] * q10 +
-                     jaa[3 * r + 1] * q11 + jaa[3 * r + 2] * q12;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          double v = t1[r][0] * jpb[3 * s] + t1[r][1] * jpb[3 * s + 1] + t1[r][2] * jpb[3 * s + 2] +
-                     t2[r][0] * jab[3 * s] + t2[r][1] * jab[3 * s + 1] + t2[r][2] * jab[3 * s + 2];
-          if (ia == ib && r == s) v += a.var_img;
-          if (ia == ib && r > s) continue;  // keep the diagonal block symmetric: use upper entry
-          Mm[(size_t)(2 * ia + r) * ldm + 2 * ib + s] = v;
-          Mm[(size_t)(2 * ib + s) * ldm + 2 * ia + r] = v;
-        }
-    }
-  }
-  // residual r' = Q^T res  (wave 0), overlapped with the M build
-  if (tid < 64) {
-    const int lane = tid;
+    // residual r' = Q^T res
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
     for (int kk = 0; kk < 3; ++kk) {
       const double tk = scal[kk];
       double w = 0.0;
@@ -706,9 +662,58 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
     }
+  } else {
+    // ---- gate matrix M = J P J^T + sigma^2 I from 6x6 blocks of P (:452-457)
+    {
+      const int n = a.n;
+      const double *P = a.P;
+      // Pairs (ia <= ib) are dealt so that the lanes of a group share ib and walk ia: P is column-major, so a
+      // load then touches 3-double runs 24 bytes apart in ONE column (a dozen cache lines per wave) instead of 64
+      // scattered lines.  Column ib = c carries c + 1 pairs and column L-1-c carries L - c: together L + 1 slots,
+      // one group of G lanes per such couple of columns.
+      const int G = (L + 1 <= 32) ? 32 : (L + 1 <= 64) ? 64 : 128, ncouple = (L + 1) / 2;
+      for (int idx = tid - 64; idx < ncouple * G; idx += XK_FEAT_THREADS - 64) {
+        const int cpl = idx / G, u = idx - cpl * G, ib2 = L - 1 - cpl;
+        if (u > L || (u > cpl && ib2 == cpl)) continue;          // past the slots / the middle column of an odd L
+        const int ia = (u <= cpl) ? u : u - cpl - 1, ib = (u <= cpl) ? cpl : ib2;
+        const int cpa = XK_CORE + 3 * (p0 + ia), caa = cpa + 3 * a.n_poses_max;
+        const int cpb = XK_CORE + 3 * (p0 + ib), cab = cpb + 3 * a.n_poses_max;
+        const double *jpa = Jp + 6 * ia, *jaa = Ja + 6 * ia, *jpb = Jp + 6 * ib, *jab = Ja + 6 * ib;
+        double t1[2][3], t2[2][3];  // rows of J_a times P[.., pos_b cols] / P[.., att_b cols]
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const double *pc1 = P + (size_t)(cpb + c) * n, *pc2 = P + (size_t)(cab + c) * n;
+          const double p00 = pc1[cpa], p01 = pc1[cpa + 1], p02 = pc1[cpa + 2];
+          const double p10 = pc1[caa], p11 = pc1[caa + 1], p12 = pc1[caa + 2];
+          const double q00 = pc2[cpa], q01 = pc2[cpa + 1], q02 = pc2[cpa + 2];
+          const double q10 = pc2[caa], q11 = pc2[caa + 1], q12 = pc2[caa + 2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            t1[r][c] = jpa[3 * r] * p00 + jpa[3 * r + 1] * p01 + jpa[3 * r + 2] * p02 + jaa[3 * r] * p10 +
+                       jaa[3 * r + 1] * p11 + jaa[3 * r + 2] * p12;
+            t2[r][c] = jpa[3 * r] * q00 + jpa[3 * r + 1] * q01 + jpa[3 * r + 2] * q02 + jaa[3 * r] * q10 +
+                       jaa[3 * r + 1] * q11 + jaa[3 * r + 2] * q12;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            double v = t1[r][0] * jpb[3 * s] + t1[r][1] * jpb[3 * s + 1] + t1[r][2] * jpb[3 * s + 2] +
+                       t2[r][0] * jab[3 * s] + t2[r][1] * jab[3 * s + 1] + t2[r][2] * jab[3 * s + 2];
+            if (ia == ib && r == s) v += a.var_img;
+            if (ia == ib && r > s) continue;  // keep the diagonal block symmetric: use upper entry
+            Mm[(size_t)(2 * ia + r) * ldm + 2 * ib + s] = v;
+            Mm[(size_t)(2 * ib + s) * ldm + 2 * ia + r] = v;
+          }
+      }
+    }
   }
   __syncthreads();
+  const double tau0 = scal[0], tau1 = scal[1], tau2 = scal[2];
+  const double g01 = scal[3], g02 = scal[4], g12 = scal[5];
 
+  XK_STAMP(3);
   XK_STAMP(4);
   // ---- M <- Q^T M Q with Q = H0 H1 H2 = I - V T V^T (compact WY):
   //        Q^T M Q = M - V Z^T - Z V^T,   Z = Y T - V B / 2,  Y = M V,  B = T^T (V^T Y) T
