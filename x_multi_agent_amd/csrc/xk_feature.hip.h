@@ -251,54 +251,11 @@ __device__ __forceinline__ void xk_chol_gate(double *Mm, int ldm, int d, int tid
 #undef XK_S
 }
 
-// The same gate for d <= 63 on ONE wave: lane t keeps row t of [S; r] in registers (static indexing, fully
-// unrolled), column k travels through LDS as a wave-wide broadcast.  A wave issues one instruction per 4
-// clocks whatever it does, so what counts is the instruction count of a step: ~16 wide LDS reads + ~32 FMAs
-// here against ~150 LDS operations per wave for the 2-D version above (8 us instead of 37 us at d = 57).
-__device__ __forceinline__ void xk_chol_gate_wave(const double *Mm, int ldm, int d, int lane, double *scal, double *colbuf /*[2][66]*/) {
-  constexpr int B = 63;   // columns
-  typedef double xk_g2 __attribute__((ext_vector_type(2)));
-  double v[B + 1];
-#pragma unroll
-  for (int j = 0; j < B; ++j) v[j] = (lane <= d && j <= lane && j < d) ? Mm[(size_t)(3 + lane) * ldm + 3 + j] : 0.0;
-  v[B] = 0.0;
-  double g = 0.0;
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < B; ++k) {
-    if (k < d && !bad) {   // uniform
-      const long long pq = __builtin_bit_cast(long long, v[k]);
-      const int plo = __builtin_amdgcn_readlane((int)(pq & 0xffffffffLL), k), phi = __builtin_amdgcn_readlane((int)(pq >> 32), k);
-      const double piv = __builtin_bit_cast(double, ((long long)phi << 32) | (unsigned int)plo);
-      if (!(piv > 0.0)) { bad = true; }
-      double rp = __builtin_amdgcn_rcp(piv);
-      rp = fma(rp, fma(-piv, rp, 1.0), rp);
-      rp = fma(rp, fma(-piv, rp, 1.0), rp);
-      double *cb = colbuf + (k & 1) * 66;
-      cb[lane] = v[k];                       // S(lane, k): meaningful for lane > k, the only ones read
-      const double m = v[k] * rp;            // S(t,k) / S(k,k)
-      g = fma(v[k] * v[k], rp, g);           // lane d: gamma += S(d,k)^2 / S(k,k)
-      __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0)
-      __builtin_amdgcn_wave_barrier();
-      // pairs from the even index at or below k+1 (the extra entry v[k] is dead by now)
-#pragma unroll
-      for (int j = (k + 1) & ~1; j < B + 1; j += 2) {
-        const xk_g2 c = *reinterpret_cast<const xk_g2 *>(cb + j);
-        v[j] = fma(-m, c[0], v[j]);
-        v[j + 1] = fma(-m, c[1], v[j + 1]);
-      }
-#pragma unroll
-      for (int j = k + 1; j < B; ++j) asm volatile("" : "+v"(v[j]));
-    }
-  }
-  if (lane == d) scal[12] = g;
-  if (lane == 0 && bad) scal[10] = 1.0;
-}
-
 // The same gate for d <= 63 as a blocked Cholesky on ONE wave, 16 x 16 tiles in the MFMA C/D layout, all of
 // them (<= 10 of S plus <= 4 of the residual, which rides along as a right-hand-side column) in this wave's
 // registers: per block step the diagonal tile is factored and inverted by the DPP row-broadcast pivot chain
-// (xk_chol16_bcast, ~3.1 k clocks for 16 pivots against ~12 k through LDS above), row j becomes
+// (xk_chol16_bcast, ~3.1 k clocks for 16 pivots; the row-per-lane version with the column broadcast through LDS that
+// this replaces took ~12 k), row j becomes
 // X_jk = L_jj^-1 S_jk on the matrix cores, and the trailing tiles take S_ik -= X_ji^T X_jk straight from
 // registers (a C/D-layout register is both operands of X^T X).  gamma = |L^-1 r|^2 = the squares of the
 // residual column of X.  work: 256 + 16*17 doubles of LDS (diagonal tile row-major, L_jj^-1).
@@ -387,7 +344,7 @@ __device__ __forceinline__ void xk_chol_gate_blocked(const double *Mm, int ldm, 
 // LDS size in bytes for n_poses window poses.
 static inline size_t xk_feature_lds_bytes(int n_poses) {
   const int L = n_poses, m2 = 2 * L, ldm = m2 + 1;
-  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 134 + 2 + 256 + 272);
+  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 2 + 256 + 272);
 }
 
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
@@ -840,10 +797,10 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu
   for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)m2 * ldm + 3 + j] = res[3 + j];
   __syncthreads();
   if (d < 64) {
-    // (the broadcast buffer is read two doubles at a time: 16-byte aligned)
-    double *colbuf = scal + 32 + 12 * Lmax + 64;
-    colbuf += ((size_t)colbuf >> 3) & 1;
-    if (tid < 64) xk_chol_gate_blocked(Mm, ldm, d, tid, scal, colbuf + 134);
+    // (the work area is read two doubles at a time: 16-byte aligned)
+    double *work = scal + 32 + 12 * Lmax + 64;
+    work += ((size_t)work >> 3) & 1;
+    if (tid < 64) xk_chol_gate_blocked(Mm, ldm, d, tid, scal, work);
     else if (a.A) tile_write(tid - 64, XK_FEAT_THREADS - 64);   // the other three waves write the tile meanwhile: a
                                                                  // rejected track's tile is masked by tile_rows = 0
   } else {
