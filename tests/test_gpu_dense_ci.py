@@ -38,6 +38,42 @@ def test_apply_update_dense_matches_reference_form(xk, oracle_c, sc):
     eng.close()
 
 
+def test_kalman_stage_across_measurement_counts(xk):
+    """The Cholesky of S runs in one launch up to 192 rows (xk_chol_whole) and one launch per 32-row block step
+    above; both against the closed form, at block boundaries and at ragged sizes, plus the not-positive-definite exit."""
+    rng = np.random.default_rng(17)
+    eng = xk.Engine(30, 0, 4)
+    n = eng.n                                               # 195
+    B = rng.standard_normal((n, n)) * 0.2
+    P = B @ B.T + 1e-3 * np.eye(n)
+    for m in (1, 3, 15, 16, 17, 47, 48, 96, 130, 176, 191, 192, 193, 196):
+        H = rng.standard_normal((m, n)) * 0.3
+        r = rng.standard_normal(m) * 1e-2
+        R = 10.0 ** rng.uniform(-5, -1, size=m)
+        Pg, cg, _ = eng.apply_update_dense(P, H, r, R)
+        S = H @ P @ H.T + np.diag(R)
+        K = np.linalg.solve(S, H @ P).T
+        Po = P - K @ H @ P
+        Po = 0.5 * (Po + Po.T)
+        assert rel(Pg, Po) <= 1e-9, m
+        assert rel(cg, K @ r) <= 1e-8, m
+        assert np.array_equal(Pg, Pg.T)
+    # a covariance that is not positive makes S indefinite (one negative direction that every H below sees, found
+    # only after the first pivots): both paths must say so instead of returning NaNs
+    u = rng.standard_normal(n)
+    Pbad = P - 40.0 * np.outer(u, u)
+    for m in (40, 196):
+        H = rng.standard_normal((m, n))
+        with pytest.raises(xk.XkError) as e:
+            eng.apply_update_dense(Pbad, H, np.zeros(m), np.full(m, 1e-6))
+        assert e.value.status == 2, m
+        assert np.linalg.eigvalsh(H @ Pbad @ H.T).min() < -1.0
+        # the handle stays usable afterwards
+        Pg, _, _ = eng.apply_update_dense(P, H, np.zeros(m), np.full(m, 1e-3))
+        assert np.isfinite(Pg).all()
+    eng.close()
+
+
 def test_apply_update_with_total_correction_on_compressed_system(xk, oracle_c, sc):
     eng = xk.Engine(8, 2, 24)
     eng.stage(sc)
