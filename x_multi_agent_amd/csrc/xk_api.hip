@@ -568,7 +568,14 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
     for (int c0 = 0, k = 0; c0 < h->C1; c0 += 16, ++k) {
       const int trail = std::max(0, h->C1 - c0 - 16);
       const int csplit = std::max(1, (trail + chalf - 1) / chalf);
-      static const int lchalf = 4 * std::max(1, env_int("XK_CAQR_LCHALF", 8) / 4);   // whole waves: 16 lanes per column
+      // last level inside the fused launch: 32 lanes per column next to 64-row tiles (768-thread workgroups),
+      // 16 next to 128-row tiles (512-thread workgroups); whole waves either way
+      // (2 trailing columns per workgroup next to 64-row tiles: 9 waves; measured 22.5 us per fused launch against
+      //  23.4 at 4-8 columns -- the fewer waves share a step, the shorter it is, and there are CUs to spare)
+      static const int lchalf_env = env_int("XK_CAQR_LCHALF", 0);
+      const int llanes = (h->DB == 64) ? 32 : 16;
+      const int lchalf = (h->DB == 64) ? std::min(8, 2 * std::max(1, (lchalf_env ? lchalf_env : 2) / 2))
+                                       : std::min(16, 4 * std::max(1, (lchalf_env ? lchalf_env : 8) / 4));
       const int lsplit = std::max(1, (trail + lchalf - 1) / lchalf);
       const int lead_off = (k & 1) ? 16 : 0;
       if (k == 0) {
@@ -592,7 +599,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
         t.hole_stride = arity1; t.lead_off = 16 - lead_off;
         int tsplit, tthreads;
         tile_geom(t.c0, tsplit, t.chalf, tthreads);
-                const dim3 grid(lsplit + ntiles * tsplit), block(std::max(tthreads, round_up(16 * (16 + lchalf), 64)));
+                const dim3 grid(lsplit + ntiles * tsplit), block(std::max(tthreads, round_up(llanes * (16 + lchalf), 64)));
         if (h->DB == 64) {
           if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<16, false>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<16, true>), grid, block, 0, h->stream, t, l, lsplit, tsplit);

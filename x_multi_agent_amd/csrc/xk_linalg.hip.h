@@ -937,21 +937,145 @@ __global__ __launch_bounds__(RPL > 22 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
   xk_caqr_merge_body<RPL, false>(a, blockIdx.x, blockIdx.y, ubuf, sc);
 }
 
+// The last merge level again, for the copy that shares a kernel (and its 80-VGPR budget) with the tile step:
+// 32 lanes per column, lane (h, p) = row p of strips 10h .. 10h+9, so a lane holds 10 rows and the reflector
+// (10 more) stays in registers -- the 16-lane layout above needs 20 + 20 and had to fetch the reflector twice.
+// The reduction over a column's 32 lanes is the 16-lane DPP butterfly plus ONE v_permlane16_swap (rows 2i and
+// 2i+1 of the wave trade places: x + swap(x) is the sum over the row pair in both rows).
+__device__ __forceinline__ double xk_rowpair_sum(double x) {
+  const long long q = __builtin_bit_cast(long long, x);
+  const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double a = __builtin_bit_cast(double, ((long long)r1[0] << 32) | (unsigned int)r0[0]);
+  const double b = __builtin_bit_cast(double, ((long long)r1[1] << 32) | (unsigned int)r0[1]);
+  return a + b;
+}
+template <int KK, int RH>
+__device__ __forceinline__ void xk_caqr_mstep32(double (&b)[RH], int rel, bool live, int part, double *ubuf, double *sc) {
+  constexpr int NP = 32, RHP = RH + 2;
+  constexpr int pb = KK & 1;
+  const int p = part & 15, half = part >> 4;
+  xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RHP);
+  double *scp = sc + pb * 4;
+  if (rel == KK) {
+    // strip 0 (register 0 of half 0) is the pivot strip: its rows above the pivot are not part of the reflector
+    const double below = (half || p > KK) ? 1.0 : 0.0, at_or_below = (half || p >= KK) ? 1.0 : 0.0;
+    {
+      xk_d2 t0 = {b[0] * at_or_below, b[1]};
+      useg[0] = t0;
+    }
+#pragma unroll
+    for (int r = 2; r < RH; r += 2) {
+      xk_d2 tt = {b[r], b[r + 1]};
+      useg[r >> 1] = tt;
+    }
+    double s0 = (b[0] * below) * b[0], s1 = 0.0;
+#pragma unroll
+    for (int r = 1; r < RH; ++r) {
+      if (r & 1) s1 = fma(b[r], b[r], s1); else s0 = fma(b[r], b[r], s0);
+    }
+    const double tail = xk_rowpair_sum(xk_group_sum<16>(s0 + s1));
+    if (part == KK) {
+      const double c0v = b[0];
+      double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+      if (tail > 2.2250738585072014e-308) {
+        const double n2 = fma(c0v, c0v, tail);
+        double y = __builtin_amdgcn_rsq(n2);
+        y = y * fma(-0.5 * n2 * y, y, 1.5);
+        y = y * fma(-0.5 * n2 * y, y, 1.5);
+        const double ab = n2 * y;
+        beta = (c0v >= 0) ? -ab : ab;
+        vp = c0v - beta;
+        y2 = y * y;
+        tden = fma(fabs(c0v), y, 1.0);
+      }
+      double rt = __builtin_amdgcn_rcp(tden);
+      rt = fma(rt, fma(-tden, rt, 1.0), rt);
+      rt = fma(rt, fma(-tden, rt, 1.0), rt);
+      const double mtt = -(y2 * rt);
+      ubuf[(pb * NP + part) * RHP] = vp;                 // the pivot entry of the reflector
+      scp[0] = mtt;
+      b[0] = beta;
+    }
+  }
+  __syncthreads();
+  const double mtt = scp[0];
+  if (rel > KK && live && mtt != 0.0) {
+    xk_d2 u[RH / 2];
+#pragma unroll
+    for (int r = 0; r < RH / 2; ++r) u[r] = useg[r];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RH / 2; ++r) { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+    const double w = mtt * xk_rowpair_sum(xk_group_sum<16>(d0 + d1));
+#pragma unroll
+    for (int r = 0; r < RH / 2; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+    }
+  }
+}
+
+// Last-level merge body in that layout: ONE group of up to 20 strips (all of them pivot strips of first-level
+// group leaders: lead_all), `split` = which trailing columns.  Same addressing as xk_caqr_merge_body.
+__device__ __forceinline__ void xk_caqr_last32_body(const XkCaqrArgs &a, int split, double *ubuf, double *sc) {
+  constexpr int NP = 32, RH = 10, ARITY = 20;
+  const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
+  const int p = part & 15, half = part >> 4;
+  const bool panel = cidx < 16;
+  const int col = panel ? a.c0 + cidx : a.c0 + 16 + split * a.chalf + (cidx - 16);
+  const bool mine = col < a.C1 && (panel || cidx - 16 < a.chalf);
+  const size_t lane_off = panel ? (size_t)p * 16 + cidx : (size_t)p * a.C1P + col;
+  const size_t strip_step = panel ? 256 : (size_t)a.stride * a.TS * a.C1P;
+  double *g0 = (panel ? const_cast<double *>(a.pin) + lane_off : a.A + lane_off + (size_t)a.lead_off * a.C1P) + (size_t)(RH * half) * strip_step;
+  const int nstrips = min(ARITY, (a.ntiles + a.stride - 1) / a.stride) - RH * half;   // of this half
+  double b[RH];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) b[r] = (mine && r < nstrips) ? g0[(size_t)r * strip_step] : 0.0;
+  const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
+#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep32<K, RH>(b, cidx, mine, part, ubuf, sc);
+  XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
+  XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
+#undef XK_STEP
+  if (!mine) return;
+  const bool root = half == 0;                               // register 0 of half 0 = the root strip
+  if (panel) {
+    if (split == 0 && root) {
+      const double v = (p > cidx) ? 0.0 : b[0];              // eliminated entries are not zeroed in registers
+      if (a.c0 + p < a.C1) a.Rout[(size_t)(a.c0 + p) * a.C1P + col] = v;
+    }
+  } else {
+    if (root) {                                              // row p of the root strip = row c0 + p of R
+      if (a.c0 + p < a.C1) a.Rout[(size_t)(a.c0 + p) * a.C1P + col] = b[0];
+      b[0] = 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < RH; ++r)
+      if (r < nstrips) g0[(size_t)r * strip_step] = b[r];
+  }
+}
+
 // Overlapped schedule (two merge levels).  The last merge level of panel k only touches the pivot strips of
 // the first-level group leaders; every other row is final for panel k once the first level has run.  So ONE
-// launch runs the last level of panel k (workgroups [0, n_last), the first 384 threads of each) next to the
+// launch runs the last level of panel k (workgroups [0, n_last)) next to the
 // tile step of panel k+1 (the rest of the grid), in which the leaders leave those 16 rows out (their "hole")
 // and use the other 16 of their first 32 rows as the pivot strip.  The rows the last level leaves behind join
 // the first level of panel k+1 as a 21st (41st) dense strip.  Per panel: 2 dependent launches instead of 3.
 template <int RPL, bool CSPLIT>
 __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_fused(XkCaqrArgs ta, XkCaqrArgs la, int n_last, int tsplit) {
-  constexpr int LRPL = 20, LDS_T = 2 * 4 * (RPL + 2), LDS_L = 2 * 16 * (LRPL + 2);
+  constexpr int LDS_T = 2 * 4 * (RPL + 2), LDS_L = (RPL == 16) ? 2 * 32 * (10 + 2) : 2 * 16 * (20 + 2);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_T > LDS_L ? LDS_T : LDS_L];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
   const int id = blockIdx.x;
   if (id < n_last) {
-    if ((int)threadIdx.x >= 16 * (16 + la.chalf)) return;        // whole waves: 16 * 24 = 384 threads
-    xk_caqr_merge_body<LRPL, true>(la, 0, id, ubuf, sc);
+    if (RPL == 16) {                                             // 80-VGPR budget: the 32-lane layout
+      if ((int)threadIdx.x >= 32 * (16 + la.chalf)) return;      // whole waves
+      xk_caqr_last32_body(la, id, ubuf, sc);
+    } else {                                                     // 128-row tiles leave room for the 16-lane one
+      if ((int)threadIdx.x >= 16 * (16 + la.chalf)) return;      // whole waves: chalf % 4 == 0
+      xk_caqr_merge_body<20, false>(la, 0, id, ubuf, sc);
+    }
   } else {
     const int w = id - n_last;
     xk_caqr_tile_body<RPL, CSPLIT>(ta, CSPLIT ? w / tsplit : w, CSPLIT ? w % tsplit : 0, ubuf, sc);
