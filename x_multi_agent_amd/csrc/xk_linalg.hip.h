@@ -758,9 +758,7 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
 //     addressed by one uniform stride.
 // (~25 fewer instructions on the owner's path of a step; measured step time is unchanged -- the owner is
 //  not what the other waves wait for -- so this layout is kept for its simpler addressing.)
-// REREAD: the reflector is fetched twice (dot product, then update) instead of being held in RPL more
-// registers -- for the copy of this code that shares a kernel, and an 80-VGPR budget, with the tile step.
-template <int KK, int RPL, bool REREAD>
+template <int KK, int RPL>
 __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool live, int part, double *ubuf, double *sc) {
   constexpr int NP = 16, RPLP = RPL + 2;
   constexpr int pb = KK & 1;
@@ -815,45 +813,27 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
   const double mtt = scp[0];
   if (rel > KK && live && mtt != 0.0) {
     // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
-    if (REREAD) {
-      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    xk_d2 u[RPL / 2];
 #pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) {
-        const xk_d2 u = useg[r];
-        if (r & 1) { d2 = fma(u[0], b[2 * r], d2); d3 = fma(u[1], b[2 * r + 1], d3); }
-        else { d0 = fma(u[0], b[2 * r], d0); d1 = fma(u[1], b[2 * r + 1], d1); }
-      }
-      const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
-      asm volatile("" ::: "memory");                      // the second fetch is not merged with the first
+    for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
 #pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) {
-        const xk_d2 u = useg[r];
-        b[2 * r] = fma(w, u[0], b[2 * r]);
-        b[2 * r + 1] = fma(w, u[1], b[2 * r + 1]);
-      }
-    } else {
-      xk_d2 u[RPL / 2];
+    for (int r = 0; r < RPL / 2; ++r) {
+      if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+      else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+    }
+    const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
 #pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
-      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) {
-        if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
-        else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
-      }
-      const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
-#pragma unroll
-      for (int r = 0; r < RPL / 2; ++r) {
-        b[2 * r] = fma(w, u[r][0], b[2 * r]);
-        b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
-      }
+    for (int r = 0; r < RPL / 2; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
     }
   }
 }
 
 // Merge body.  RPL = ARITY (20, 40) or ARITY + 2 (22, 42: register ARITY is the pending strip of the
 // overlapped schedule).  `group` / `split` = which strips / which trailing columns this workgroup owns.
-template <int RPL, bool REREAD>
+template <int RPL>
 __device__ __forceinline__ void xk_caqr_merge_body(const XkCaqrArgs &a, int group, int split, double *ubuf, double *sc) {
   constexpr int NP = 16, ARITY = (RPL % 20 == 0) ? RPL : RPL - 2;
   constexpr bool PEND = ARITY != RPL;
@@ -891,7 +871,7 @@ __device__ __forceinline__ void xk_caqr_merge_body(const XkCaqrArgs &a, int grou
   asm volatile("" :: "v"(sink));
   const long long t1 = clock64(), w1 = wall_clock64();
 #endif
-#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL, REREAD>(b, cidx, mine, part, ubuf, sc);
+#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL>(b, cidx, mine, part, ubuf, sc);
   XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
   XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
 #undef XK_STEP
@@ -934,7 +914,7 @@ __global__ __launch_bounds__(RPL > 22 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
   constexpr int NP = 16, RPLP = RPL + 2;
   __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
-  xk_caqr_merge_body<RPL, false>(a, blockIdx.x, blockIdx.y, ubuf, sc);
+  xk_caqr_merge_body<RPL>(a, blockIdx.x, blockIdx.y, ubuf, sc);
 }
 
 // The last merge level again, for the copy that shares a kernel (and its 80-VGPR budget) with the tile step:
@@ -1074,7 +1054,7 @@ __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_
       xk_caqr_last32_body(la, id, ubuf, sc);
     } else {                                                     // 128-row tiles leave room for the 16-lane one
       if ((int)threadIdx.x >= 16 * (16 + la.chalf)) return;      // whole waves: chalf % 4 == 0
-      xk_caqr_merge_body<20, false>(la, 0, id, ubuf, sc);
+      xk_caqr_merge_body<20>(la, 0, id, ubuf, sc);
     }
   } else {
     const int w = id - n_last;
