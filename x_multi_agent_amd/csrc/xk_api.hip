@@ -574,7 +574,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       //  23.4 at 4-8 columns -- the fewer waves share a step, the shorter it is, and there are CUs to spare)
       static const int lchalf_env = env_int("XK_CAQR_LCHALF", 0);
       const int llanes = (h->DB == 64) ? 32 : 16;
-      const int lchalf = (h->DB == 64) ? std::min(8, 2 * std::max(1, (lchalf_env ? lchalf_env : 2) / 2))
+      // (about 84 last-level workgroups at most: wider systems take more columns per workgroup)
+      const int lauto = std::min(8, 2 * std::max(1, (trail + 2 * 84 - 1) / (2 * 84)));
+      const int lchalf = (h->DB == 64) ? std::min(8, 2 * std::max(1, (lchalf_env ? lchalf_env : lauto) / 2))
                                        : std::min(16, 4 * std::max(1, (lchalf_env ? lchalf_env : 8) / 4));
       const int lsplit = std::max(1, (trail + lchalf - 1) / lchalf);
       const int lead_off = (k & 1) ? 16 : 0;
