@@ -587,10 +587,17 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
         if (mid) hipEventRecord(mid, h->stream);
       }
       XkCaqrArgs m = a;                            // first level: leaders' pivot strips at lead_off, + the pending strips
-      m.c0 = c0; m.stride = 1; m.final_level = 0; m.pin = h->d_panel[0]; m.pout = h->d_panel[1]; m.chalf = chalf;
+      // columns per workgroup: at least `chalf`, and enough that groups x splits fits one workgroup per CU -- two
+      // merge workgroups on a CU run ~1.6x longer than one (28.8 us at 420 workgroups, 17-19 us below 256)
+      static const int adapt = env_int("XK_CAQR_ADAPT", 1);
+      static const int cus = env_int("XK_CAQR_CUS", 256);
+      const int per_cu = std::max(1, cus / groups1);
+      const int mchalf = adapt ? std::min(arity1 == 40 ? 16 : 32, std::max(chalf, 2 * ((trail + 2 * per_cu - 1) / (2 * per_cu)))) : chalf;
+      const int msplit = std::max(1, (trail + mchalf - 1) / mchalf);
+      m.c0 = c0; m.stride = 1; m.final_level = 0; m.pin = h->d_panel[0]; m.pout = h->d_panel[1]; m.chalf = mchalf;
       m.lead_off = lead_off; m.lead_all = 0; m.pend = (k > 0) ? 1 : 0;
-      if (arity1 == 40) launch_merge<42>(h, m, groups1, csplit);
-      else launch_merge<22>(h, m, groups1, csplit);
+      if (arity1 == 40) launch_merge<42>(h, m, groups1, msplit);
+      else launch_merge<22>(h, m, groups1, msplit);
       ++launches;
       XkCaqrArgs l = a;                            // last level: the leaders' pivot strips -> 16 rows of R
       l.c0 = c0; l.stride = arity1; l.final_level = 1; l.pin = h->d_panel[1]; l.pout = h->d_panel[0]; l.chalf = lchalf;
