@@ -92,14 +92,30 @@ __device__ __forceinline__ double xk_dpp_f64(double x) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 // All-lanes sum over the wave: four DPP stages inside each 16-lane row (quad xor 1, quad xor 2,
-// half-row mirror, row mirror), then two cross-row shuffles.  Every lane gets the same value.
+// half-row mirror, row mirror), then two cross-row lane swaps.  Every lane gets the same value.
 __device__ __forceinline__ double xk_wave_sum(double v) {
   v += xk_dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
   v += xk_dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
   v += xk_dpp_f64<0x141>(v);   // row_half_mirror
   v += xk_dpp_f64<0x140>(v);   // row_mirror
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  // across the four rows: v_permlane16_swap (rows 2i <-> 2i+1) and v_permlane32_swap (halves) on two copies of
+  // the value -- a + b is the pair sum in both partners; VALU only, no trip through the LDS crossbar
+  {
+    const long long q = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __builtin_bit_cast(double, ((long long)r1[0] << 32) | (unsigned int)r0[0]) +
+        __builtin_bit_cast(double, ((long long)r1[1] << 32) | (unsigned int)r0[1]);
+  }
+  {
+    const long long q = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __builtin_bit_cast(double, ((long long)r1[0] << 32) | (unsigned int)r0[0]) +
+        __builtin_bit_cast(double, ((long long)r1[1] << 32) | (unsigned int)r0[1]);
+  }
   return v;
 }
 
