@@ -1461,7 +1461,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     const int nchunk = (n + XK_CI_CHUNK - 1) / XK_CI_CHUNK;
     hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), h->stream, ha);
     XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal};
-    hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(64), 0, h->stream, ca);
+    hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, h->stream, ca);
     // the two gate decisions (own chi-square test :180, joint test :243-250)
     HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[8], dint, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->h_pin, dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -423,9 +423,11 @@ struct XkCiCombineArgs {
   double *S_gate, *S_ci;  // m x m column-major
   double *gamma;
 };
-__global__ __launch_bounds__(64) void xk_ci_combine(XkCiCombineArgs a) {
+// 512 threads: one entry of the m x m matrices per thread for the sum over agents and chunks (k1 * nchunk
+// dependent-free loads each; on 64 threads this loop was 100 of the kernel's 110 us), then the small Cholesky.
+__global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
   const int m = a.m;
-  for (int e = threadIdx.x; e < m * m; e += 64) {
+  for (int e = threadIdx.x; e < m * m; e += 512) {
     double g = 0.0, c = 0.0;
     for (int i = 0; i < a.k1; ++i) {
       double v = 0.0;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(64) void xk_ci_combine(XkCiCombineArgs a) {
   // forward substitution (one wave: the barriers are wave barriers)
   __shared__ double A[24][25], y[24];
   const int t = threadIdx.x;
-  for (int e = t; e < m * m; e += 64) A[e % m][e / m] = a.S_gate[e];
+  for (int e = t; e < m * m; e += 512) A[e % m][e / m] = a.S_gate[e];
   if (t < m) y[t] = a.res[t];
   __syncthreads();
   bool bad = false;
