@@ -52,6 +52,8 @@ struct xk_handle {
   double *d_ciws;          // workspace of the device-resident CI round (lazily allocated)
   XkFeatBatch *d_batch;    // per-agent descriptors of the batched feature launch, [8 tracks][8 agents]
   XkFeatBatch *h_batch;    // pinned staging of the same
+  int *h_ci_cols;          // pinned: per shared track, the block columns of xk_scale_blocks [8][128]
+  double *h_ci_w;          // pinned: per shared track, 1/w0 [8]
   int *h_trk_off;          // host copy of the staged track offsets
   // MSCKF-SLAM tracks (features being initialised this frame)
   int K2;
@@ -219,6 +221,8 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_ciws) hipFree(h->d_ciws);
   if (h->d_batch) hipFree(h->d_batch);
   if (h->h_batch) hipHostFree(h->h_batch);
+  if (h->h_ci_cols) hipHostFree(h->h_ci_cols);
+  if (h->h_ci_w) hipHostFree(h->h_ci_w);
   free(h->h_trk_off);
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
@@ -1391,6 +1395,8 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     HIPCHK(h, hipMalloc((void **)&h->d_ciws, sizeof(double) * ((size_t)9 * 8 * 64 + 8 * upsz + (size_t)21 * 8 * n + 8 * XK_CI_MAXCHUNK * 576 + 2 * 576 + 512)));
     HIPCHK(h, hipMalloc((void **)&h->d_batch, sizeof(XkFeatBatch) * 64));
     HIPCHK(h, hipHostMalloc((void **)&h->h_batch, sizeof(XkFeatBatch) * 64));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_cols, sizeof(int) * 8 * 128));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_w, sizeof(double) * 8));
     hipFuncSetAttribute((const void *)xk_ci_hph, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   }
   double *ws = h->d_ciws;
@@ -1471,15 +1477,15 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     if (!h->h_pin_i[8] || !(h->h_pin[0] < XK_CHI2_095[dof])) continue;
     // P_j: diagonal 3x3 blocks of the observed poses scaled by 1/w0 (:256-267), then applyCI (updater.cpp:144-161)
     const int L = aL[0];
-    int *hc = h->h_pin_i + 16;
+    int *hc = h->h_ci_cols + 128 * j;            // per-track staging: no need to wait before the next track reuses it
     for (int i = 0; i < L; ++i) {
       const int pos = h->n_poses - L + i;
       hc[2 * i] = XK_CORE + 3 * pos;
       hc[2 * i + 1] = XK_CORE + 3 * pos + 3 * N;
     }
-    h->h_pin[1] = 1.0 / w0;
+    h->h_ci_w[j] = 1.0 / w0;
     HIPCHK(h, hipMemcpyAsync(dint + 32, hc, sizeof(int) * 2 * L, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dscal + 1, h->h_pin + 1, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(dscal + 1, h->h_ci_w + j, sizeof(double), hipMemcpyHostToDevice, h->stream));
     XkScaleArgs sc{h->d_P, h->d_tmpP, n, 2 * L, dint + 32, dscal + 1};
     hipLaunchKernelGGL(xk_scale_blocks, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, sc);
     UpdateSpec u;
@@ -1492,8 +1498,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     int rc = launch_update(h, u);
     if (rc != XK_OK) return rc;
     if (corrections) HIPCHK(h, hipMemcpyAsync(corrections + (size_t)fused * n, h->d_corr, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));   // h_pin staging is reused by the next track
-    ++fused;
+    ++fused;                                       // (the next track's gate decision, or read_status below, waits)
   }
   if (fused) {
     int rc = read_status(h);
