@@ -192,8 +192,11 @@ def main():
         """CI round: all-gather the snapshots over RCCL, then fuse the shared tracks against them on the device."""
         if world == 1:
             return
-        eng.pack_payload_into(rank, float(step), dyn16, pay_dev.data_ptr())   # packed on the device ...
-        ex.send.copy_(pay_dev)                                                # ... into the RCCL send buffer
+        if ex.send.is_cuda and args.config != 5:
+            eng.pack_payload_into(rank, float(step), dyn16, ex.send.data_ptr())   # packed on the device straight into the RCCL send buffer
+        else:
+            eng.pack_payload_into(rank, float(step), dyn16, pay_dev.data_ptr())   # (gloo functional mode / keyframe snapshot)
+            ex.send.copy_(pay_dev)
         if args.config == 5:
             # request/response mode (VIO::processOtherRequests, vio.cpp:462-496): every tick an agent stores a keyframe
             # (snapshot + tracks + descriptors, all resident in HBM), sends the binary VLAD of what it sees to one
