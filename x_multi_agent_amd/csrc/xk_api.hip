@@ -1391,25 +1391,38 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   HIPCHK(h, hipSetDevice(h->device));
   const size_t upsz = 3 * (size_t)n + 16;
   const size_t Lcap = (size_t)k1 * 64;
+  const size_t ci_ws_doubles = (size_t)9 * 8 * 64 + 8 * upsz + (size_t)21 * 8 * n + 8 * XK_CI_MAXCHUNK * 576 + 2 * 576 + 512;
     if (!h->d_ciws) {
-    HIPCHK(h, hipMalloc((void **)&h->d_ciws, sizeof(double) * ((size_t)9 * 8 * 64 + 8 * upsz + (size_t)21 * 8 * n + 8 * XK_CI_MAXCHUNK * 576 + 2 * 576 + 512)));
+    HIPCHK(h, hipMalloc((void **)&h->d_ciws, sizeof(double) * 8 * ci_ws_doubles));   // one region per shared track
     HIPCHK(h, hipMalloc((void **)&h->d_batch, sizeof(XkFeatBatch) * 64));
     HIPCHK(h, hipHostMalloc((void **)&h->h_batch, sizeof(XkFeatBatch) * 64));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_cols, sizeof(int) * 8 * 128));
-    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_w, sizeof(double) * 8));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_cols, sizeof(int) * (8 * 128 + 8)));   // + the per-track own-gate flags
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_w, sizeof(double) * 16));   // [0..7] 1/w0, [8..15] joint gamma
     hipFuncSetAttribute((const void *)xk_ci_hph, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
   }
-  double *ws = h->d_ciws;
-  double *dq = ws, *dp = dq + 4 * Lcap, *dobs = dp + 3 * Lcap, *up = dobs + 2 * Lcap;
-  double *Hs = up + k1 * upsz, *Si = Hs + (size_t)std::max(m, 1) * k1 * n, *S1 = Si + (size_t)k1 * XK_CI_MAXCHUNK * 576, *S2 = S1 + 576;
-  double *dres = S2 + 576, *dgpf = dres + 24, *dscal = dgpf + 8;   // dscal[0] ci gamma, [1] w_result, [2..] per-agent gamma
-  int *dint = (int *)(dscal + 16);   // [0..7] inlier per agent, [8..15] tile rows, [16..31] gn iters, [32..159] block columns, [192..] landmarks
+  // per-track workspace (the stages before the gate of every shared track are queued back to back, then ONE
+  // synchronisation fetches all the gate results)
+  struct CiWs { double *dq, *dp, *dobs, *up, *Hs, *Si, *S1, *S2, *dres, *dgpf, *dscal; int *dint; };
+  auto ci_ws = [&](int j) {
+    CiWs w;
+    double *ws = h->d_ciws + (size_t)j * ci_ws_doubles;
+    w.dq = ws; w.dp = w.dq + 4 * Lcap; w.dobs = w.dp + 3 * Lcap; w.up = w.dobs + 2 * Lcap;
+    w.Hs = w.up + k1 * upsz; w.Si = w.Hs + (size_t)std::max(m, 1) * k1 * n; w.S1 = w.Si + (size_t)k1 * XK_CI_MAXCHUNK * 576; w.S2 = w.S1 + 576;
+    w.dres = w.S2 + 576; w.dgpf = w.dres + 24; w.dscal = w.dgpf + 8;   // dscal[0] ci gamma, [1] w_result, [2..] per-agent gamma
+    w.dint = (int *)(w.dscal + 16);   // [0..7] inlier per agent, [8..15] tile rows, [16..31] gn iters, [32..159] block columns, [192..] landmarks
+    return w;
+  };
   // payload layout (fleet.py / xk_pack_payload): hdr[8] dyn[16] pos[3N] att[4N] feat[3M] anchors[M] cov[n*n]
   const size_t o_pos = 24, o_att = o_pos + 3 * (size_t)N, o_cov = o_att + 4 * (size_t)N + 4 * (size_t)h->Mmax;
   const size_t trk_stride = 1 + 2 * (size_t)N;
   const double w0 = 1.0 - (double)k * ci_msckf_w, var_img = sigma_img * sigma_img;
   int fused = 0;
+  int trk_L0[8], trk_dof[8];
   for (int j = 0; j < n_tracks; ++j) {
+    const CiWs w = ci_ws(j);
+    double *dq = w.dq, *dp = w.dp, *dobs = w.dobs, *up = w.up, *Hs = w.Hs, *Si = w.Si, *S1 = w.S1, *S2 = w.S2;
+    double *dres = w.dres, *dgpf = w.dgpf, *dscal = w.dscal;
+    int *dint = w.dint;
     const int st = self_track[j];
     if (st < 0 || st >= h->K) return fail(h, XK_EINVAL, "shared track index outside the staged tracks");
     // agent order: index 0 = self, 1.. = the others by rank
@@ -1468,15 +1481,21 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), h->stream, ha);
     XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal};
     hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, h->stream, ca);
-    // the two gate decisions (own chi-square test :180, joint test :243-250)
-    HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[8], dint, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_pin, dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int dof = 2 * Ltot - 3;
-    if (dof >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
-    if (!h->h_pin_i[8] || !(h->h_pin[0] < XK_CHI2_095[dof])) continue;
+    // the two gate decisions (own chi-square test :180, joint test :243-250) come back per track
+    HIPCHK(h, hipMemcpyAsync(&h->h_ci_cols[1024 + j], dint, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&h->h_ci_w[8 + j], dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    trk_L0[j] = aL[0];
+    trk_dof[j] = 2 * Ltot - 3;
+    if (trk_dof[j] >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
+  }
+  if (n_tracks > 0) HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int j = 0; j < n_tracks; ++j) {
+    if (!h->h_ci_cols[1024 + j] || !(h->h_ci_w[8 + j] < XK_CHI2_095[trk_dof[j]])) continue;
+    const CiWs w = ci_ws(j);
+    double *Hs = w.Hs, *S2 = w.S2, *dres = w.dres, *dscal = w.dscal;
+    int *dint = w.dint;
     // P_j: diagonal 3x3 blocks of the observed poses scaled by 1/w0 (:256-267), then applyCI (updater.cpp:144-161)
-    const int L = aL[0];
+    const int L = trk_L0[j];
     int *hc = h->h_ci_cols + 128 * j;            // per-track staging: no need to wait before the next track reuses it
     for (int i = 0; i < L; ++i) {
       const int pos = h->n_poses - L + i;
@@ -1490,7 +1509,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     hipLaunchKernelGGL(xk_scale_blocks, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, sc);
     UpdateSpec u;
     memset(&u, 0, sizeof(u));
-    u.T = pa.H[0]; u.str = 1; u.stc = m;
+    u.T = Hs; u.str = 1; u.stc = m;      // H of agent 0 (self)
     u.c = m; u.kdim = n; u.col0 = 0;
     u.z = dres; u.sz = 1;
     u.S = S2; u.ssr = 1; u.ssc = m;
