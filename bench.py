@@ -9,7 +9,10 @@ rank r is agent r with its own synthetic window/tracks/prior (seed
 visual update (per-feature build -> CAQR compression -> Kalman update) on
 inputs already resident in HBM; P stays on the device.  Every CI_EVERY steps
 the agents exchange their SimpleState payloads (state + full covariance) with
-one RCCL all-gather.  value = (N * K updates) / max-over-ranks wall time.
+one RCCL all-gather and fuse the shared tracks against them on the device
+(config 4); --config 5 runs the reference's request/response protocol instead,
+every 6 updates: binary-VLAD request, the responder's best keyframe back.
+value = (N * K updates) / max-over-ranks wall time.
 
 The JSON line also carries
   roofline      fp64 compute roofline of the dominant stage (CAQR kernels),
