@@ -99,10 +99,8 @@ def test_database_sequence_matches_oracle(eng, vname, thr):
                 assert np.array_equal(kf["descriptors"], okf.descriptors)
                 got_p = torch.empty(pay_n, dtype=torch.float64, device="cuda")
                 got_t = torch.empty(trk_n, dtype=torch.float64, device="cuda")
-                import ctypes as C
-                hip = C.CDLL("libamdhip64.so")
-                assert hip.hipMemcpy(C.c_void_p(got_p.data_ptr()), C.c_void_p(kf["payload_ptr"]), C.c_size_t(8 * pay_n), C.c_int(3)) == 0
-                assert hip.hipMemcpy(C.c_void_p(got_t.data_ptr()), C.c_void_p(kf["tracks_ptr"]), C.c_size_t(8 * trk_n), C.c_int(3)) == 0
+                db.copy_keyframe(idx, got_p.data_ptr(), got_t.data_ptr())      # what a response sends back
+                torch.cuda.synchronize()
                 assert np.array_equal(got_p.cpu().numpy(), payloads[tag][0])
                 assert np.array_equal(got_t.cpu().numpy(), payloads[tag][1])
     assert [k.tag for k in ora.keyframes] == list(range(7, 22))
