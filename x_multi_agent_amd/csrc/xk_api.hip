@@ -1574,6 +1574,25 @@ extern "C" int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, 
 extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
   if (!h || steps < 0 || !(sigma_img > 0.0)) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
+  static const int use_graph = env_int("XK_GRAPH", 0);
+  if (use_graph && steps > 1) {
+    // experiment: the 30 launches of one update captured once and replayed
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = launch_build(h, sigma_img);
+    if (rc == XK_OK) rc = launch_compress(h);
+    if (rc == XK_OK) { UpdateSpec u = compressed_spec(h, nullptr, 1); rc = launch_update(h, u); }
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc != XK_OK) return rc;
+    if (e != hipSuccess) return fail(h, XK_EDEVICE, "graph capture", e);
+    HIPCHK(h, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int it = 0; it < steps; ++it) HIPCHK(h, hipGraphLaunch(ge, h->stream));
+    rc = read_status(h);
+    hipGraphExecDestroy(ge);
+    hipGraphDestroy(g);
+    return rc;
+  }
   for (int it = 0; it < steps; ++it) {
     int rc = launch_build(h, sigma_img);
     if (rc != XK_OK) return rc;
