@@ -19,7 +19,7 @@ int main() {
     const int trail = C1 - c0 - 16;
     for (int rep = 0; rep < 2; ++rep) {
       for (int i = 0; i < NL; ++i) {
-        XkCaqrArgs a{A, rows, nt, 64, 64, C1P, C1, c0, (i & 1) ? 20 : 1, 0, R, 8, P0, P1, 0, 0, 0, 0, dbg + 8 * i};
+        XkCaqrArgs a{A, rows, nt, 64, 64, C1P, C1, c0, (i & 1) ? 20 : 1, 0, R, 8, P0, P1, 0, 0, 0, 0, dbg + 8 * i, 0};
         hipLaunchKernelGGL(xk_caqr_merge<20>, dim3((i & 1) ? 1 : 20, (trail + 7) / 8), dim3(384), 0, 0, a);
       }
       hipDeviceSynchronize();

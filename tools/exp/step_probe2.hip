@@ -22,7 +22,7 @@ int main() {
   for (int c0 : {0, 96, 160}) {
     const int trail = C1 - c0 - 16 > 0 ? C1 - c0 - 16 : 0;
     for (int mode = 0; mode < 3; ++mode) {
-      XkCaqrArgs a{A, rows, nt, 64, 64, C1P, C1, c0, 1, 0, R, 8, P0, P1, 0, 0, 0, 0, dbg};
+      XkCaqrArgs a{A, rows, nt, 64, 64, C1P, C1, c0, 1, 0, R, 8, P0, P1, 0, 0, 0, 0, dbg, 0};
       float ms; long long d[4];
       const int reps = 200;
       int threads, gx, gy = 1;

@@ -16,6 +16,7 @@
 #include "xk_feature.hip.h"
 #include "xk_slaminit.hip.h"
 #include "xk_linalg.hip.h"
+#include "xk_caqr_persist.hip.h"
 #include "xk_ci.hip.h"
 
 #define XK_VERSION_NUM 100
@@ -40,6 +41,12 @@ struct xk_handle {
   double *d_gam, *d_gam_s, *d_gpf;
   double *d_R;
   int nleaf, nlevels;   // of the last compression
+  // single-launch CAQR (xk_caqr_persist.hip.h): cross-XCD exchange slabs and the sync words
+  double *d_x1, *d_x1p, *d_x2;
+  unsigned *d_psync;
+  long long *d_pdbg;
+  int n_cu;
+  bool persist_ok;      // cleared when a launch gave up (workgroups not co-resident): the multi-launch schedule takes over
   bool have_rows, have_R;
   double sigma_img;
   // update workspace
@@ -149,7 +156,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
   HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
-  for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max + 2) * 256));
+  for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max + 10) * 256));
   HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_inl_s, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_gn, (size_t)k_max));
@@ -158,6 +165,21 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_R, (size_t)h->C1P * h->C1P));
   HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    h->n_cu = prop.multiProcessorCount;
+    h->persist_ok = h->DB == 64 && h->C1 <= 192 && h->n_cu == 256;
+    if (h->persist_ok) {
+      const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * XK_PERSIST_MAXG * 16;
+      HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
+      HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
+      HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
+      HIPCHK(h, dalloc(&h->d_psync, (size_t)XK_PS_WORDS * 16));
+      HIPCHK(h, dalloc(&h->d_pdbg, (size_t)256 + 64 * 256));
+      HIPCHK(h, hipMemset(h->d_pdbg, 0, sizeof(long long) * (256 + 64 * 256)));
+    }
+  }
   HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_X, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n));
@@ -218,6 +240,8 @@ extern "C" int xk_destroy(xk_handle *h) {
   free(h->h_trk2_off);
   if (h->d_csr_i) hipFree(h->d_csr_i);
   if (h->d_csr_v) hipFree(h->d_csr_v);
+  for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
+    if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
   if (h->d_batch) hipFree(h->d_batch);
   if (h->h_batch) hipHostFree(h->h_batch);
@@ -533,6 +557,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   XkCaqrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles; a.TS = h->DB;
   a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
+  static const int wt_env = env_int("XK_CAQR_WT", 0);
+  a.wt = wt_env;
   {   // tallest tile: 2 L_max - 3 rows for the track tiles, full slots for packed SLAM rows
     const int lmax = std::max(h->K > 0 ? h->h_pin_i[0] : 0, h->K2 > 0 ? h->h_pin_i[1] : 0);
     a.rows_max = (h->M > 0) ? h->DB : std::min(h->DB, std::max(16, 2 * lmax - 3));
@@ -549,6 +575,35 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   const bool overlap = overlap_env && (arity1 == 20 || arity1 == 40) && groups1 >= 2 && groups1 <= 20;
   a.hole_stride = 0; a.lead_off = 0; a.lead_all = 0; a.pend = 0;
   int launches = 0;
+  // single-launch schedule (xk_caqr_persist.hip.h): every workgroup of the grid must be resident at once (2 per CU)
+  static const int persist_env = env_int("XK_CAQR_PERSIST", 0);
+  static const int persist_min = env_int("XK_CAQR_PERSIST_MIN", 64);
+  if (persist_env && h->persist_ok && ntiles >= persist_min && ntiles <= 8 * 50) {
+    XkCaqrPersistArgs pa;
+    pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.ntiles = ntiles; pa.rows_max = std::max(a.rows_max, 32);
+    pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.PB1 = h->d_panel[0];
+    pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.sync = h->d_psync;
+    pa.TPX = (ntiles + 7) / 8;
+    pa.G = pa.TPX > 27 ? 2 : 1;                       // first-level arity <= 27 (14 rows per lane, one of them pending)
+    pa.A1 = (pa.TPX + pa.G - 1) / pa.G;
+    const int trail0 = std::max(0, h->C1 - 16);
+    pa.NT = std::min(50, std::max(pa.TPX, pa.G * std::max(1, (trail0 + 7) / 8)));
+    const int NL = 8 * (2 * h->n_cu / 8 - pa.NT);
+    pa.lchalf = std::min(8, 2 * std::max(1, (trail0 + 2 * NL - 1) / (2 * NL)));
+    pa.status = h->d_status;
+    static const int pdbg = env_int("XK_CAQR_PERSIST_DBG", 0);
+    pa.dbg = pdbg ? h->d_pdbg : nullptr;
+    if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * XK_PS_WORDS * 16, h->stream) != hipSuccess)
+      return fail(h, XK_EDEVICE, "sync words");
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_persist<14>), dim3(2 * h->n_cu), dim3(XK_PERSIST_THREADS), 0, h->stream, pa);
+    if (mid) hipEventRecord(mid, h->stream);
+    h->nleaf = ntiles;
+    h->nlevels = 1;
+    h->have_R = true;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
+    return XK_OK;
+  }
   auto tile_geom = [&](int c0, int &tsplit, int &tchalf, int &tthreads) {
     const int trail = std::max(0, h->C1 - c0 - 16);
     tsplit = std::max(1, (trail + (tile_cols - 16) - 1) / (tile_cols - 16));
@@ -761,16 +816,23 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
   return u;
 }
 
-static int read_status(xk_handle *h) {
-  int st = 0;
-  HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[4], h->d_status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+#define XK_RETRY_CLASSIC 1000   // internal: the single-launch CAQR gave up, the multi-launch schedule must redo the update
+static int read_status(xk_handle *h, bool allow_retry = false) {
+  HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[4], h->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  st = h->h_pin_i[4];
-  if (st != 0) {
-    hipMemsetAsync(h->d_status, 0, sizeof(int), h->stream);
+  const int st = h->h_pin_i[4], pst = h->h_pin_i[5];
+  if (st != 0 || pst != 0) {
+    hipMemsetAsync(h->d_status, 0, 2 * sizeof(int), h->stream);
     hipStreamSynchronize(h->stream);
-    return fail(h, st, "innovation covariance not positive definite");
   }
+  if (pst != 0) {
+    // reasons: 1 grid not resident, 2 XCD barrier, 3 uneven XCD placement, 4/5 waiting for the last / first level
+    h->persist_ok = false;
+    h->have_rows = h->have_R = false;
+    snprintf(h->err, sizeof(h->err), "single-launch CAQR gave up (reason %d): workgroups not co-resident; using the multi-launch schedule from now on", pst);
+    return allow_retry ? XK_RETRY_CLASSIC : XK_EDEVICE;
+  }
+  if (st != 0) return fail(h, st, "innovation covariance not positive definite");
   return XK_OK;
 }
 
@@ -800,7 +862,13 @@ extern "C" int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc = launch_compress(h);
   if (rc != XK_OK) return rc;
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  rc = read_status(h, true);
+  if (rc == XK_RETRY_CLASSIC) {                  // rebuild the rows (the tiles were worked on in place) and compress the slow way
+    if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
+    if ((rc = launch_compress(h)) != XK_OK) return rc;
+    rc = read_status(h);
+  }
+  if (rc != XK_OK) return rc;
   if (T_H || z) {
     if (T_H && ldt < h->n) return XK_EINVAL;
     std::vector<double> R((size_t)h->C1 * h->C1P);
@@ -848,17 +916,21 @@ extern "C" int xk_visual_update_staged(xk_handle *h, double sigma_img, double *c
     for (int i = 0; i < h->n; ++i) correction[i] = 0.0;
     return XK_OK;
   }
-  int rc = launch_build(h, sigma_img);
-  if (rc != XK_OK) return rc;
-  rc = launch_compress(h);
-  if (rc != XK_OK) return rc;
-  UpdateSpec u = compressed_spec(h, nullptr, 1);
-  rc = launch_update(h, u);
-  if (rc != XK_OK) return rc;
-  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
-  rc = fetch_flags(h, inlier_msckf, gamma_msckf, inlier_slam, gamma_slam);
-  if (rc != XK_OK) return rc;
-  rc = read_status(h);
+  int rc = XK_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    rc = launch_build(h, sigma_img);
+    if (rc != XK_OK) return rc;
+    rc = launch_compress(h);
+    if (rc != XK_OK) return rc;
+    UpdateSpec u = compressed_spec(h, nullptr, 1);
+    rc = launch_update(h, u);
+    if (rc != XK_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    rc = fetch_flags(h, inlier_msckf, gamma_msckf, inlier_slam, gamma_slam);
+    if (rc != XK_OK) return rc;
+    rc = read_status(h, attempt == 0);
+    if (rc != XK_RETRY_CLASSIC) break;           // (the prior is untouched in d_P: the whole update is simply redone)
+  }
   if (rc != XK_OK) return rc;
   std::swap(h->d_P, h->d_Pout);
   h->have_rows = h->have_R = false;
@@ -1653,6 +1725,17 @@ extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
   const double waves = (double)blocks * 4;
   const double flops = use_mfma ? waves * iters * 4.0 * (2.0 * 16 * 16 * 4) : waves * 64.0 * iters * 8.0 * 2.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
+  return XK_OK;
+}
+
+// Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST_DBG=1): per panel k, out[8k + 0..5] = role-T
+// workgroup (XCD 0, slot 0): tile step start / end, after barrier 1, first-level merge start, end, after barrier 2;
+// out[8k + 6..7] = last-level workgroup 0: roots complete -> its strips published.  tools/exp/persist_trace.py prints them.
+extern "C" int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out) {
+  if (!h || !out || !h->d_pdbg) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(out, h->d_pdbg, sizeof(long long) * (size_t)std::min(n_out, 256 + 64 * 256), hipMemcpyDeviceToHost));
   return XK_OK;
 }
 

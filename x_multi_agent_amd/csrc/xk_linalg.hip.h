@@ -577,7 +577,13 @@ struct XkCaqrArgs {
   int lead_all;           // merge: every strip is such a tile (last level) / only strip 0 (first level)
   int pend;               // merge (first level): the group leader's hole rows join as strip number ARITY
   long long *dbg;         // optional: clock stamps of workgroup 0 (probe builds only)
+  int wt;                 // experiment: write-through (sc1) stores for the rows a launch hands to the next one
 };
+
+__device__ __forceinline__ void xk_store_wt(double *p, double v, int wt) {
+  if (wt) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 
 // One Householder step of the in-place panel QR shared by the tile and merge kernels.
 //   b[RPL]   this lane's rows of its column;  rel = column index relative to the panel start
@@ -736,7 +742,7 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
   } else {
 #pragma unroll
     for (int r = 0; r < RPL; ++r)
-      if (r < rlim) rowp[(size_t)r * a.C1P] = b[r];
+      if (r < rlim) xk_store_wt(rowp + (size_t)r * a.C1P, b[r], a.wt);
   }
 }
 
@@ -895,11 +901,11 @@ __device__ __forceinline__ void xk_caqr_merge_body(const XkCaqrArgs &a, int grou
       if (a.c0 + part < a.C1) a.Rout[(size_t)(a.c0 + part) * a.C1P + col] = b[0];
       b[0] = 0.0;
     }
-    g00[0] = b[0];
+    xk_store_wt(g00, b[0], a.wt);
 #pragma unroll
     for (int r = 1; r < ARITY; ++r)
-      if (r < nstrips) g0[(size_t)r * strip_step] = b[r];
-    if (PEND) { if (a.pend) gp[0] = b[ARITY]; }
+      if (r < nstrips) xk_store_wt(g0 + (size_t)r * strip_step, b[r], a.wt);
+    if (PEND) { if (a.pend) xk_store_wt(gp, b[ARITY], a.wt); }
   }
 #ifdef XK_CAQR_PROBE
   if (a.dbg && group == 0 && split == 0 && threadIdx.x == 0) {
@@ -922,6 +928,9 @@ __global__ __launch_bounds__(RPL > 22 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
 // (10 more) stays in registers -- the 16-lane layout above needs 20 + 20 and had to fetch the reflector twice.
 // The reduction over a column's 32 lanes is the 16-lane DPP butterfly plus ONE v_permlane16_swap (rows 2i and
 // 2i+1 of the wave trade places: x + swap(x) is the sum over the row pair in both rows).
+// doubles per lane of the reflector broadcast buffer: RH + 2, bumped when that makes the lane stride a multiple of 128 B
+// (RH = 14: all 32 lanes of a column would sit on the same banks)
+#define XK_M32_STRIDE(RH) ((((RH) + 2) % 16 == 0) ? (RH) + 4 : (RH) + 2)
 __device__ __forceinline__ double xk_rowpair_sum(double x) {
   const long long q = __builtin_bit_cast(long long, x);
   const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
@@ -933,7 +942,7 @@ __device__ __forceinline__ double xk_rowpair_sum(double x) {
 }
 template <int KK, int RH>
 __device__ __forceinline__ void xk_caqr_mstep32(double (&b)[RH], int rel, bool live, int part, double *ubuf, double *sc) {
-  constexpr int NP = 32, RHP = RH + 2;
+  constexpr int NP = 32, RHP = XK_M32_STRIDE(RH);
   constexpr int pb = KK & 1;
   const int p = part & 15, half = part >> 4;
   xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RHP);
@@ -1032,7 +1041,7 @@ __device__ __forceinline__ void xk_caqr_last32_body(const XkCaqrArgs &a, int spl
     }
 #pragma unroll
     for (int r = 0; r < RH; ++r)
-      if (r < nstrips) g0[(size_t)r * strip_step] = b[r];
+      if (r < nstrips) xk_store_wt(g0 + (size_t)r * strip_step, b[r], a.wt);
   }
 }
 
