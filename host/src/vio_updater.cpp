@@ -68,16 +68,6 @@ void VioUpdater::constructUpdate(const State &state, Matrix &h, Matrix &res, Mat
     }
     check(xk_, xk_stage_msckf_slam(xk_, moff.data(), mobs.data(), (int)mt.size()), "xk_stage_msckf_slam");
   }
-  {   // MSCKF-SLAM tracks (vio_updater.cpp:311-321): their rows sit between the MSCKF and the SLAM rows (:413-419)
-    const TrackList &mt = measurement_.new_msckf_slam_tracks;
-    std::vector<int> moff(mt.size() + 1, 0);
-    std::vector<double> mobs;
-    for (size_t k = 0; k < mt.size(); ++k) {
-      moff[k + 1] = moff[k] + (int)mt[k].size();
-      for (const Feature &f : mt[k]) { mobs.push_back(f.getX()); mobs.push_back(f.getY()); }
-    }
-    check(xk_, xk_stage_msckf_slam(xk_, moff.data(), mobs.data(), (int)mt.size()), "xk_stage_msckf_slam");
-  }
   check(xk_, xk_upload_P(xk_, state.getCovariance().data(), n, n), "xk_upload_P");   // Matrix P = state.getCovariance()
   inlier_msckf_.assign(tr.size(), 0);
   inlier_slam_.assign(M, 0);

@@ -114,3 +114,69 @@ def test_cpp_mirror_update_then_post_update_initialises_features(tmp_path):
     assert rel(f_arr[9:18], g["exp_new_features"][9:18]) <= 1e-8
     # the features that already existed received their share of the correction (State::correct)
     assert rel(f_arr[:9], g["feat_full"][:9] + g["exp_correction"][15 + 6 * N:15 + 6 * N + 9]) <= 1e-9
+
+
+def test_update_with_only_msckf_slam_tracks(xk):
+    """K = 0, M = 0, K2 > 0: the MSCKF-SLAM rows alone are a non-empty h (vio_updater.cpp:311-321, 413-419), so the
+    Kalman update runs (updater.cpp:106) and the new features can be initialised afterwards."""
+    g = np.load(os.path.join(GOLDEN_DIR, "msckf_slam_n8.npz"))
+    N, M, sigma = int(g["n_poses_max"]), int(g["n_feat_max"]), float(g["sigma_img"])
+    off, obs = g["trk_off"], g["obs_xy"]
+    tracks = [obs[off[k]:off[k + 1]] for k in range(len(off) - 1)]
+    eng = xk.Engine(N, M, 16)
+    sc = dict(C_q_G=g["C_q_G"], G_p_C=g["G_p_C"], trk_off=np.zeros(1, np.int32), obs_xy=np.zeros((0, 2)), P=g["P_full"],
+              n_poses_max=N, sigma_img=sigma)
+    eng.stage(sc)
+    eng.stage_msckf_slam(tracks[10:13])
+    r = eng.visual_update_staged(sigma)
+    ref = ref_np.visual_update([], g["C_q_G"], g["G_p_C"], g["P_full"], N, sigma, msckf_slam_tracks=tracks[10:13])
+    assert np.linalg.norm(ref["correction"]) > 0
+    ms = eng.msckf_slam_results()
+    assert list(ms["inlier"]) == list(ref["msckf_slam"]["inlier"])
+    assert rel(eng.download_P(), ref["P"]) <= 1e-9 and rel(r["correction"], ref["correction"]) <= 1e-8
+    eng.init_msckf_slam_features(3, r["correction"], sigma)      # needs the column-space rows of THIS update
+    eng.close()
+
+
+def test_update_without_any_rows_is_a_no_op(xk):
+    """No usable track at all: the reference skips applyUpdate (h.size() == 0, updater.cpp:106); the reference-shaped
+    call sequence build -> compress -> update must not fail on the empty tile stack either."""
+    g = np.load(os.path.join(GOLDEN_DIR, "msckf_slam_n8.npz"))
+    N, M, sigma = int(g["n_poses_max"]), int(g["n_feat_max"]), float(g["sigma_img"])
+    eng = xk.Engine(N, M, 16)
+    sc = dict(C_q_G=g["C_q_G"], G_p_C=g["G_p_C"], trk_off=np.zeros(1, np.int32), obs_xy=np.zeros((0, 2)), P=g["P_full"],
+              n_poses_max=N, sigma_img=sigma)
+    eng.stage(sc)
+    eng.stage_msckf_slam([])
+    r = eng.visual_update_staged(sigma)
+    assert not r["correction"].any()
+    assert np.array_equal(eng.download_P(), g["P_full"])
+    eng.msckf_build(sigma)
+    T, z = eng.qr_compress()
+    assert not T.any() and not z.any()
+    corr = eng.apply_update()
+    assert not corr.any() and rel(eng.download_P(), g["P_full"]) <= 1e-15
+    eng.close()
+
+
+def test_slam_staging_rejects_stale_anchors(xk):
+    g = np.load(os.path.join(GOLDEN_DIR, "msckf_slam_n8.npz"))
+    N, M, sigma = int(g["n_poses_max"]), int(g["n_feat_max"]), float(g["sigma_img"])
+    eng = xk.Engine(N, M, 16)
+    base = dict(C_q_G=g["C_q_G"], G_p_C=g["G_p_C"], trk_off=np.zeros(1, np.int32), obs_xy=np.zeros((0, 2)), P=g["P_full"],
+                n_poses_max=N, sigma_img=sigma, slam_feat=g["feat_full"][:9], slam_z_last=g["slam_z_last"],
+                slam_track_sizes=g["slam_track_sizes"])
+    for bad in (np.array([-1, 0, 1]), np.array([0, N, 1])):        # an unused StateManager slot; past the window
+        with pytest.raises(xk.XkError) as e:
+            eng.stage(dict(base, slam_anchor_idxs=bad.astype(np.int32)))
+        assert e.value.status == 1
+    with pytest.raises(xk.XkError) as e:
+        eng.stage(dict(base, slam_anchor_idxs=g["slam_anchor_idxs"], slam_track_sizes=np.array([3, 0, 2], np.int32)))
+    assert e.value.status == 1
+    # anchors are rechecked against the window staged at build time
+    short = dict(base, C_q_G=g["C_q_G"][:2], G_p_C=g["G_p_C"][:2], slam_anchor_idxs=np.array([0, 1, 5], np.int32))
+    eng.stage(short)
+    with pytest.raises(xk.XkError) as e:
+        eng.msckf_build(sigma)
+    assert e.value.status == 1
+    eng.close()

@@ -152,3 +152,18 @@ def test_request_response_round(eng):
     assert {c[0] for c in cls} == {"slam", "opp_opp"}               # q == t: SLAM x SLAM and OPP x OPP pairs only
     assert responder.find_candidate(3, responder.compute_vlad(mine))[2] != 101       # not sent twice
     responder.close()
+
+
+def test_rejected_keyframe_leaves_a_full_database_untouched(eng):
+    """xk_pr_add_keyframe validates its descriptors BEFORE it drops the oldest keyframe of a full database."""
+    v = VOCS["visual"]()
+    nb = ref_pr.Vocabulary(v).d_length
+    db = place.Database(eng, v, 0.5, max_desc=64)
+    for i in range(15):
+        db.add_keyframe(synth.make_descriptors(20, nb, seed=i), tag=i)
+    assert len(db) == 15
+    with pytest.raises(engine.XkError):
+        db.add_keyframe(synth.make_descriptors(65, nb, seed=99), tag=99)     # more than max_desc
+    assert len(db) == 15
+    assert [db.keyframe(i)["tag"] for i in range(15)] == list(range(15))      # the oldest one is still there
+    db.close()

@@ -9,8 +9,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "xk_api.hip")
 OUT = os.path.join(HERE, "libxk.so")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("xk_api.hip", "xk_feature.hip.h", "xk_linalg.hip.h", "xk_ci.hip.h",
-                                               "xk_chi2_table.h")] + [os.path.join(HERE, "..", "include", "xk.h")]
+# every file xk_api.hip includes: a stale libxk.so after editing any of them would silently test old kernels
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
+              if f.endswith((".hip", ".h"))) + [os.path.join(HERE, "..", "include", "xk.h")]
 
 
 def build(force=False, verbose=True):

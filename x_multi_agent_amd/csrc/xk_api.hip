@@ -45,6 +45,8 @@ struct xk_handle {
   double *d_x1, *d_x1p, *d_x2;
   unsigned *d_psync;
   long long *d_pdbg;
+  long long *feat_dbg;  // probe builds only: per-workgroup phase stamps of xk_msckf_feature
+  bool attr_slaminit, attr_feat_batch;   // hipFuncSetAttribute done for this handle's device
   int n_cu;
   bool persist_ok;      // cleared when a launch gave up (workgroups not co-resident): the multi-launch schedule takes over
   bool have_rows, have_R;
@@ -63,6 +65,7 @@ struct xk_handle {
   double *h_ci_w;          // pinned: per shared track, 1/w0 [8]
   int *h_trk_off;          // host copy of the staged track offsets
   // MSCKF-SLAM tracks (features being initialised this frame)
+  int anchor_max;          // largest staged SLAM anchor index (rechecked against the staged window at build time)
   int K2;
   bool ms_built;           // their column-space rows on the device belong to the staged tracks
   int *d_trk2_off, *h_trk2_off, *d_inl2, *d_gn2;
@@ -113,13 +116,27 @@ static hipError_t dalloc(T **p, size_t count) {
   return hipMalloc((void **)p, sizeof(T) * (count ? count : 1));
 }
 
+static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out);
+extern "C" int xk_destroy(xk_handle *h);
+// (a failure part-way through releases everything allocated so far)
 extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out) {
-  if (!out || n_poses_max < 2 || n_poses_max > 64 || n_feat_max < 0 || k_max < 0) return XK_EINVAL;
+  if (!out) return XK_EINVAL;
+  *out = nullptr;
+  xk_handle *h = nullptr;
+  const int rc = create_impl(device, n_poses_max, n_feat_max, k_max, &h);
+  if (rc != XK_OK) { if (h) xk_destroy(h); return rc; }
+  *out = h;
+  return XK_OK;
+}
+
+static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out) {
+  if ( n_poses_max < 2 || n_poses_max > 64 || n_feat_max < 0 || k_max < 0) return XK_EINVAL;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XK_EDEVICE;
   if (device < 0 || device >= ndev) return XK_EINVAL;
   xk_handle *h = (xk_handle *)calloc(1, sizeof(xk_handle));
   if (!h) return XK_ENOMEM;
+  *out = h;   // the caller destroys it if anything below fails
   h->device = device;
   h->N = n_poses_max;
   h->Mmax = n_feat_max;
@@ -128,7 +145,7 @@ extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max,
   h->na = h->n - XK_CORE;
   h->C1 = h->na + 1;
   h->C1P = round_up(h->C1, 64);
-  if (h->C1P > 512) { free(h); return XK_ECAPACITY; }
+  if (h->C1P > 512) return XK_ECAPACITY;
   const int dmax = 2 * n_poses_max - 3;
   h->DB = dmax <= 64 ? 64 : 128;   // rows per tile slot (one track per tile; SLAM rows are packed DB per tile)
   const int slam_tiles = (2 * n_feat_max + h->DB - 1) / h->DB;
@@ -302,6 +319,12 @@ extern "C" int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor
                              const double *z_last, int M) {
   if (!h || M < 0 || (M > 0 && (!feat || !anchor_idxs || !track_sizes || !z_last))) return XK_EINVAL;
   if (M > h->Mmax) return fail(h, XK_ECAPACITY, "M > n_feat_max");
+  h->anchor_max = -1;
+  for (int j = 0; j < M; ++j) {   // a stale anchor (-1 in StateManager's unused slots) or size would index the window / chi-square table out of bounds
+    if (anchor_idxs[j] < 0 || anchor_idxs[j] >= h->N) return fail(h, XK_EINVAL, "SLAM anchor index outside [0, n_poses_max)");
+    if (track_sizes[j] < 1) return fail(h, XK_EINVAL, "SLAM track size < 1");
+    h->anchor_max = std::max(h->anchor_max, anchor_idxs[j]);
+  }
   if (M > 0) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(h->d_feat, feat, sizeof(double) * 3 * M, hipMemcpyHostToDevice, h->stream));
@@ -477,7 +500,6 @@ extern "C" int xk_download_P(xk_handle *h, double *P, int ldp, int n) {
 // ---------------------------------------------------------------------------
 // launch helpers (all asynchronous on h->stream)
 // ---------------------------------------------------------------------------
-static long long *g_feat_dbg = nullptr;  // probe builds only
 
 static int launch_build(xk_handle *h, double sigma_img) {
   if (h->n_poses < 2) return fail(h, XK_EINVAL, "window not staged");
@@ -490,7 +512,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
-    a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = g_feat_dbg;
+    a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
     const size_t lds = xk_feature_lds_bytes(h->n_poses);
     hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
   }
@@ -506,15 +528,15 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.tile_rows = h->d_tile_rows + h->K; a.inlier = h->d_inl2; a.gamma = h->d_gam2;
     a.H1 = h->d_H1; a.H2 = h->d_H2; a.r1 = h->d_r1; a.features = h->d_feat2;
     const size_t lds = xk_slaminit_lds_bytes(h->n_poses);
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!h->attr_slaminit) {   // per handle = per device: a process may hold handles on several GPUs
       hipFuncSetAttribute((const void *)xk_msckf_slam_init, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-      attr_done = true;
+      h->attr_slaminit = true;
     }
     hipLaunchKernelGGL(xk_msckf_slam_init, dim3(h->K2), dim3(XK_FEAT_THREADS), lds, h->stream, a);
     h->ms_built = true;
   }
   if (h->M > 0) {
+    if (h->anchor_max >= h->n_poses) return fail(h, XK_EINVAL, "SLAM anchor outside the staged window");
     XkSlamArgs s;
     s.q = h->d_q; s.p = h->d_p; s.n_poses = h->n_poses; s.n_poses_max = h->N;
     s.feat = h->d_feat; s.anchor_idxs = h->d_anchor; s.track_sizes = h->d_tsz; s.z_last = h->d_zlast; s.M = h->M;
@@ -553,6 +575,11 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   const int ntiles = h->K + h->K2 + slam_tiles;
+  if (ntiles == 0) {   // no measurement rows at all: [T_H | z] = 0 (the reference skips the update, updater.cpp:106)
+    if (hipMemsetAsync(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "R memset");
+    h->nleaf = 0; h->nlevels = 0; h->have_R = true;
+    return XK_OK;
+  }
   // (d_R was zeroed at creation; the merges rewrite the whole upper trapezoid every update and nothing else)
   XkCaqrArgs a;
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles; a.TS = h->DB;
@@ -912,7 +939,7 @@ extern "C" int xk_visual_update_staged(xk_handle *h, double sigma_img, double *c
                                        double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
   if (!h || !correction || !(sigma_img > 0.0)) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->K == 0 && h->M == 0) {  // h.size() == 0 -> no update (updater.cpp:106)
+  if (h->K == 0 && h->K2 == 0 && h->M == 0) {  // h.size() == 0 -> no update (updater.cpp:106); MSCKF-SLAM rows count (vio_updater.cpp:413-419)
     for (int i = 0; i < h->n; ++i) correction[i] = 0.0;
     return XK_OK;
   }
@@ -1743,13 +1770,13 @@ extern "C" int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out) 
 extern "C" int xk_debug_feature_phases(xk_handle *h, double sigma_img, long long *out, int n_out) {
   // out[12k ..]: 8 clock64 phase stamps, wall start, wall end, (XCC_ID << 32 | HW_ID) of workgroup k
   const size_t bytes = sizeof(long long) * (size_t)(12 * h->K);
-  hipMalloc((void **)&g_feat_dbg, bytes);
-  hipMemset(g_feat_dbg, 0, bytes);
+  hipMalloc((void **)&h->feat_dbg, bytes);
+  hipMemset(h->feat_dbg, 0, bytes);
   int rc = launch_build(h, sigma_img);
   hipStreamSynchronize(h->stream);
-  hipMemcpy(out, g_feat_dbg, std::min(bytes, sizeof(long long) * (size_t)n_out), hipMemcpyDeviceToHost);
-  hipFree(g_feat_dbg);
-  g_feat_dbg = nullptr;
+  hipMemcpy(out, h->feat_dbg, std::min(bytes, sizeof(long long) * (size_t)n_out), hipMemcpyDeviceToHost);
+  hipFree(h->feat_dbg);
+  h->feat_dbg = nullptr;
   return rc;
 }
 #endif
@@ -1860,6 +1887,7 @@ static int pr_vlad_device(xk_pr *p, const unsigned char *desc, int n, unsigned i
 extern "C" int xk_pr_compute_vlad(xk_pr *p, const unsigned char *desc, int n, unsigned char *vlad_out) {
   if (!p || !vlad_out) return XK_EINVAL;
   xk_handle *h = p->h;
+  HIPCHK(h, hipSetDevice(h->device));
   int rc = pr_vlad_device(p, desc, n, p->d_qvlad);
   if (rc != XK_OK) return rc;
   HIPCHK(h, hipMemcpyAsync(p->h_words, p->d_qvlad, sizeof(unsigned int) * p->VW, hipMemcpyDeviceToHost, h->stream));
@@ -1872,6 +1900,10 @@ extern "C" int xk_pr_add_keyframe(xk_pr *p, const unsigned char *desc, int n_des
                                   const double *d_tracks, long tag) {
   if (!p) return XK_EINVAL;
   xk_handle *h = p->h;
+  // (checked BEFORE the oldest keyframe is dropped: a rejected call leaves the database as it was)
+  if (n_desc < 0 || n_desc > p->max_desc) return fail(h, XK_ECAPACITY, "place recognition: more descriptors than max_desc");
+  if (n_desc > 0 && !desc) return fail(h, XK_EINVAL, "place recognition: null descriptors");
+  HIPCHK(h, hipSetDevice(h->device));
   // slot: a free one, or the oldest keyframe's (erase(begin()), database.cpp:56-58)
   int slot;
   if (p->live < XK_PR_MAX_KEYFRAMES) {
@@ -1902,6 +1934,7 @@ extern "C" int xk_pr_find_candidate(xk_pr *p, int uav_id, const unsigned char *q
                                     double *score, long *tag) {
   if (!p || !query_vlad || !index) return XK_EINVAL;
   xk_handle *h = p->h;
+  HIPCHK(h, hipSetDevice(h->device));
   *index = -1;
   if (score) *score = 0.0;
   if (tag) *tag = -1;
@@ -1937,6 +1970,7 @@ extern "C" int xk_pr_keyframe(xk_pr *p, int index, const double **d_payload, con
                               unsigned char *desc_out) {
   if (!p) return XK_EINVAL;
   xk_handle *h = p->h;
+  HIPCHK(h, hipSetDevice(h->device));
   if (index < 0 || index >= p->live) return fail(h, XK_EINVAL, "xk_pr_keyframe: no such keyframe");
   const int s = p->order[index];
   if (d_payload) *d_payload = p->d_payload + (size_t)s * p->pay_n;
@@ -1955,6 +1989,7 @@ extern "C" int xk_pr_keyframe(xk_pr *p, int index, const double **d_payload, con
 extern "C" int xk_pr_copy_keyframe(xk_pr *p, int index, double *d_payload_dst, double *d_tracks_dst) {
   if (!p) return XK_EINVAL;
   xk_handle *h = p->h;
+  HIPCHK(h, hipSetDevice(h->device));
   if (index < 0 || index >= p->live) return fail(h, XK_EINVAL, "xk_pr_copy_keyframe: no such keyframe");
   const int s = p->order[index];
   if (d_payload_dst && p->pay_n)
@@ -1969,6 +2004,7 @@ extern "C" int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, con
                                int *dist) {
   if (!p || !idx || !dist || nq < 0 || nt < 0) return XK_EINVAL;
   xk_handle *h = p->h;
+  HIPCHK(h, hipSetDevice(h->device));
   if (nq > p->max_desc || nt > p->max_desc) return fail(h, XK_ECAPACITY, "xk_pr_knn_match: more descriptors than max_desc");
   if (nq == 0) return XK_OK;
   if (!query || (nt > 0 && !train)) return fail(h, XK_EINVAL, "xk_pr_knn_match: null descriptors");
