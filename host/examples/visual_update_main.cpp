@@ -81,6 +81,7 @@ int main(int argc, char **argv) {
   Ekf ekf(updater);
   ekf.set(4, State(N, M), nullptr, 0.02);
   ekf.initializeFromState(s);
+  ekf.processImu(1.0, 0, Vector3(0, 0, 0), Vector3(0, 0, 9.81));   // first IMU message: stand-by -> initialised (ekf.cpp:82-93)
   std::optional<State> post = ekf.processUpdateMeasurement();
   if (!post) { fprintf(stderr, "no update applied\n"); return 3; }
 

@@ -32,6 +32,16 @@ class State {
   Vector3 computeCameraPosition() const;                                  // state.cpp:189-191
   // additive on p,v,b_w,b_a,p_array,f_array; q <- (q * dq(dtheta)).normalized() (state.cpp:197-249)
   void correct(const Vectorx &correction);
+  void setImu(double time, unsigned int seq, const Vector3 &w_m, const Vector3 &a_m) {   // state.cpp:145-151
+    time_ = time; seq_ = seq; w_m_ = w_m; a_m_ = a_m;
+  }
+  void setStaticStatesFrom(const State &s) {                              // state.cpp:153-161
+    b_w_ = s.b_w_; b_a_ = s.b_a_; q_ic_ = s.q_ic_; p_ic_ = s.p_ic_;
+    p_array_ = s.p_array_; q_array_ = s.q_array_; f_array_ = s.f_array_;
+  }
+  void computeUnbiasedImuMeasurements(Vector3 &e_w, Vector3 &e_a) const {  // state.cpp:177-182
+    for (int i = 0; i < 3; ++i) { e_w(i) = w_m_(i) - b_w_(i); e_a(i) = a_m_(i) - b_a_(i); }
+  }
 
   double time_ = kInvalid;
   unsigned int seq_ = 0;

@@ -17,6 +17,7 @@ class StateManager {
   StateManager(int n_poses_max, int n_features_max, xk_handle *xk)
       : n_poses_max_(n_poses_max), n_features_max_(n_features_max), anchor_idxs_(n_features_max, -1), xk_(xk) {}
 
+  void setEngine(xk_handle *xk) { xk_ = xk; }
   void clear();                                                          // state_manager.cpp:23-29
   // Removes the listed persistent features, slides the window if it is full (re-anchoring the features of
   // the oldest pose first) and augments state and covariance with the current camera pose.

@@ -1,37 +1,113 @@
-// Mirror of src/x/ekf/ekf.cpp + state_buffer.cpp for the update side of the filter loop.
+// Mirror of src/x/ekf/ekf.cpp + state_buffer.cpp.
 #include "x/ekf/ekf.h"
 
 #include <cmath>
 #include <stdexcept>
+#include <string>
+
+#include "xk.h"
 
 using namespace x;
 
-void Ekf::set(int sz, const State &default_state, Propagator *propagator, double time_margin) {
+namespace {
+void check(xk_handle *h, int rc, const char *what) {
+  if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + (h ? xk_last_error(h) : "") + ")");
+}
+CoreCovMatrix mul15(const CoreCovMatrix &a, const CoreCovMatrix &b) {
+  CoreCovMatrix c = CoreCovMatrix::Zero();
+  for (int j = 0; j < 15; ++j)
+    for (int k = 0; k < 15; ++k) {
+      const double bkj = b(k, j);
+      if (bkj == 0.0) continue;
+      for (int i = 0; i < 15; ++i) c(i, j) += a(i, k) * bkj;
+    }
+  return c;
+}
+CoreCovMatrix transpose15(const CoreCovMatrix &a) {
+  CoreCovMatrix t;
+  for (int i = 0; i < 15; ++i)
+    for (int j = 0; j < 15; ++j) t(i, j) = a(j, i);
+  return t;
+}
+}  // namespace
+
+void Ekf::set(int sz, const State &default_state, Propagator *propagator, double time_margin, double a_m_max, int delta_seq_imu) {
   buffer_.assign(sz, default_state);
   for (State &s : buffer_) s.time_ = State::kInvalid;
+  f_d_.assign(sz, CoreCovMatrix::Identity());
+  q_d_.assign(sz, CoreCovMatrix::Zero());
   propagator_ = propagator;
   time_margin_ = time_margin;
+  a_m_max_ = a_m_max;
+  delta_seq_imu_ = delta_seq_imu;
   tail_ = -1;
   n_valid_ = 0;
+  init_status_ = kNotInitialized;
+}
+
+void Ekf::setResident(bool on) {
+  resident_ = on;
+  updater_.setResident(on);
+  if (on)
+    for (State &s : buffer_) s.cov_ = Matrix();      // the ring keeps no host covariances
 }
 
 void Ekf::initializeFromState(const State &init_state) {                    // ekf.cpp:43-64
   if (buffer_.empty()) throw std::runtime_error("The EKF state buffer must have non-zero size.");
   if (init_state.p_array_.rows() != buffer_[0].p_array_.rows() || init_state.q_array_.rows() != buffer_[0].q_array_.rows() ||
-      init_state.f_array_.rows() != buffer_[0].f_array_.rows() || init_state.cov_.rows() != buffer_[0].cov_.rows())
+      init_state.f_array_.rows() != buffer_[0].f_array_.rows() ||
+      (!resident_ && init_state.cov_.rows() != buffer_[0].cov_.rows()))
     throw std::runtime_error("init_bfr_mismatch");
   for (State &s : buffer_) s.time_ = State::kInvalid;
   tail_ = 0;
   n_valid_ = 1;
   buffer_[0] = init_state;
-  initialized_ = true;
+  if (resident_) {
+    const int n = init_state.nErrorStates();
+    if (init_state.cov_.rows() != n) throw std::runtime_error("init_bfr_mismatch");
+    check(updater_.engine(), xk_upload_P(updater_.engine(), init_state.cov_.data(), n, n), "xk_upload_P");   // once
+    buffer_[0].cov_ = Matrix();
+    cov_idx_ = 0;
+  }
+  init_status_ = kStandBy;
+}
+
+std::optional<State> Ekf::processImu(double timestamp, unsigned int seq, const Vector3 &w_m, const Vector3 &a_m) {
+  if (init_status_ == kNotInitialized) return std::nullopt;
+  std::lock_guard<std::mutex> g(mutex_);
+  State &last_state = buffer_[tail_];
+  if (init_status_ == kStandBy) {                                         // first IMU message (:82-99)
+    if (a_m.norm() < a_m_max_) {
+      last_state.setImu(timestamp, seq, w_m, a_m);
+      last_seq_ = seq;
+      init_status_ = kInitialized;
+      return last_state;
+    }
+    return std::nullopt;
+  }
+  if (timestamp <= last_state.time_) return std::nullopt;                 // IMU going back in time (:102-108)
+  last_seq_ = seq;
+  const Vector3 a_m_smoothed = a_m.norm() < a_m_max_ ? a_m : last_state.a_m_;   // accelerometer spikes (:119-129)
+  const int next = (tail_ + 1) % (int)buffer_.size();                     // state_buffer_.enqueueInPlace()
+  if (resident_ && next == cov_idx_) throw std::runtime_error("Ekf: the state ring wrapped onto the slot whose covariance is resident");
+  State &next_state = buffer_[next];
+  next_state.setImu(timestamp, seq, w_m, a_m_smoothed);
+  if (!propagator_) throw std::runtime_error("Ekf::processImu: no propagator");
+  propagator_->propagateState(last_state, next_state);
+  if (resident_) propagator_->transition(last_state, next_state, f_d_[next], q_d_[next]);   // applied on the device later
+  else propagator_->propagateCovariance(last_state, next_state);
+  tail_ = next;
+  if (n_valid_ < (int)buffer_.size()) ++n_valid_;
+  return next_state;
 }
 
 void Ekf::pushPropagatedState(const State &s) {
   std::lock_guard<std::mutex> g(mutex_);
+  if (resident_) throw std::runtime_error("Ekf::pushPropagatedState: use processImu with a resident covariance");
   tail_ = (tail_ + 1) % (int)buffer_.size();
   buffer_[tail_] = s;
   if (n_valid_ < (int)buffer_.size()) ++n_valid_;
+  init_status_ = kInitialized;
 }
 
 int Ekf::closestIdx(double timestamp) const {                               // state_buffer.cpp:26-63
@@ -46,12 +122,69 @@ int Ekf::closestIdx(double timestamp) const {                               // s
   return best;
 }
 
+// resident mode: bring the device covariance from slot cov_idx_ to slot idx (forward in time only)
+bool Ekf::advanceDeviceCovariance(int idx) {
+  if (idx == cov_idx_) return true;
+  const int sz = (int)buffer_.size();
+  int steps = (idx - cov_idx_ + sz) % sz;
+  // idx must lie between cov_idx_ and the tail
+  if (steps > (tail_ - cov_idx_ + sz) % sz) return false;                   // older than the resident covariance
+  xk_handle *xk = updater_.engine();
+  if (!compose_steps_) {
+    for (int i = (cov_idx_ + 1) % sz, s = 0; s < steps; i = (i + 1) % sz, ++s)
+      check(xk, xk_cov_propagate(xk, f_d_[i].m, 15, q_d_[i].m, 15), "xk_cov_propagate");
+  } else {
+    // P_ii <- F P_ii F^T + Q over several steps is one congruence with Phi = F_k ... F_1 and
+    // Q_tot = sum_j (F_k ... F_{j+1}) Q_j (.)^T; P_iv <- Phi P_iv likewise.  15 x 15 products on the host, one launch.
+    CoreCovMatrix phi = CoreCovMatrix::Identity(), qt = CoreCovMatrix::Zero();
+    for (int i = (cov_idx_ + 1) % sz, s = 0; s < steps; i = (i + 1) % sz, ++s) {
+      const CoreCovMatrix fq = mul15(mul15(f_d_[i], qt), transpose15(f_d_[i]));
+      for (int k = 0; k < 225; ++k) qt.m[k] = fq.m[k] + q_d_[i].m[k];
+      phi = mul15(f_d_[i], phi);
+    }
+    check(xk, xk_cov_propagate(xk, phi.m, 15, qt.m, 15), "xk_cov_propagate");
+  }
+  cov_idx_ = idx;
+  return true;
+}
+
+Matrix Ekf::covarianceAt(int idx) {
+  std::lock_guard<std::mutex> g(mutex_);
+  if (idx < 0) idx = tail_;
+  if (!resident_) return buffer_[idx].cov_;
+  const int n = buffer_[idx].nErrorStates(), sz = (int)buffer_.size();
+  Matrix P(n, n);
+  check(updater_.engine(), xk_download_P(updater_.engine(), P.data(), n, n), "xk_download_P");
+  const int steps = (idx - cov_idx_ + sz) % sz;
+  std::vector<double> tmp(15);
+  for (int i = (cov_idx_ + 1) % sz, s = 0; s < steps; i = (i + 1) % sz, ++s) {   // propagator.cpp:166-205 on the host
+    const CoreCovMatrix &F = f_d_[i], &Q = q_d_[i];
+    // rows: P[0:15, :] <- F P[0:15, :]
+    for (int c = 0; c < n; ++c) {
+      for (int r = 0; r < 15; ++r) { double a = 0; for (int k = 0; k < 15; ++k) a += F(r, k) * P(k, c); tmp[r] = a; }
+      for (int r = 0; r < 15; ++r) P(r, c) = tmp[r];
+    }
+    // columns: P[:, 0:15] <- P[:, 0:15] F^T   (the core block thereby gets F P_ii F^T)
+    for (int r = 0; r < n; ++r) {
+      for (int c = 0; c < 15; ++c) { double a = 0; for (int k = 0; k < 15; ++k) a += P(r, k) * F(c, k); tmp[c] = a; }
+      for (int c = 0; c < 15; ++c) P(r, c) = tmp[c];
+    }
+    for (int r = 0; r < 15; ++r)
+      for (int c = 0; c < 15; ++c) P(r, c) += Q(r, c);
+  }
+  return P;
+}
+
 std::optional<State> Ekf::processUpdateMeasurement() {                       // ekf.cpp:179-213
-  if (!initialized_) return std::nullopt;
+  if (init_status_ != kInitialized) return std::nullopt;
   int idx;
   { std::lock_guard<std::mutex> g(mutex_); idx = closestIdx(updater_.getTime()); }
   if (idx < 0) return std::nullopt;
-  State update_state = buffer_[idx];        // copy, not under the lock (as the reference)
+  if (resident_) {
+    std::lock_guard<std::mutex> g(mutex_);
+    if (!advanceDeviceCovariance(idx)) return std::nullopt;                  // measurement older than the last update
+  }
+  State update_state = buffer_[idx];        // copy, not under the lock (as the reference); no covariance when resident
   updater_.update(update_state);            // <- plugin call; the mutex is NOT held
   bool ok;
   { std::lock_guard<std::mutex> g(mutex_); ok = repropagateFromStateAtIdx(update_state, idx); }
@@ -60,10 +193,14 @@ std::optional<State> Ekf::processUpdateMeasurement() {                       // 
 }
 
 std::optional<State> Ekf::processOthersMeasurement(double timestamp) {       // ekf.cpp:143-176
-  if (!initialized_) return std::nullopt;
+  if (init_status_ != kInitialized) return std::nullopt;
   int idx;
   { std::lock_guard<std::mutex> g(mutex_); idx = closestIdx(timestamp); }
   if (idx < 0) return std::nullopt;
+  if (resident_) {
+    std::lock_guard<std::mutex> g(mutex_);
+    if (!advanceDeviceCovariance(idx)) return std::nullopt;
+  }
   State update_state = buffer_[idx];
   updater_.collaborativeUpdate(update_state);
   bool ok;
@@ -80,7 +217,8 @@ bool Ekf::repropagateFromStateAtIdx(const State &state, int idx) {           // 
     const int next = (curr + 1) % (int)buffer_.size();
     if (propagator_) {
       propagator_->propagateState(buffer_[curr], buffer_[next]);
-      propagator_->propagateCovariance(buffer_[curr], buffer_[next]);
+      if (resident_) propagator_->transition(buffer_[curr], buffer_[next], f_d_[next], q_d_[next]);
+      else propagator_->propagateCovariance(buffer_[curr], buffer_[next]);
     }
     curr = next;
   }

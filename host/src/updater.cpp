@@ -15,7 +15,7 @@ static void check(xk_handle *h, int rc, const char *what) {
 
 void Updater::collaborativeUpdate(State &state) {      // updater.cpp:22-36
   if (preUpdateCI()) {
-    std::vector<std::shared_ptr<Matrix>> S_list, P_list, H_list, res_list;
+    MatrixList S_list, P_list, H_list, res_list;
     constructSlamCIUpdate(state, S_list, P_list, H_list, res_list);
     for (size_t i = 0; i < P_list.size(); i++) applyCI(state, *P_list[i], *H_list[i], *res_list[i], *S_list[i]);
   }
@@ -25,16 +25,35 @@ void Updater::update(State &state) {                   // updater.cpp:39-115
   Matrix h, res, r;
   Matrix correction = Matrix::Zero(state.nErrorStates(), 1);
   preProcess(state);
-  if (preUpdateShortMsckf()) {
-    constructShortMsckfUpdate(state, h, res, r);
-    if (h.size() > 0) applyUpdate(state, h, res, r, correction, true);
+  // before sliding the pose window with the new prior, the short MSCKF tracks are used (:50-73)
+  const bool short_update_requested = preUpdateShortMsckf();
+  if (short_update_requested) {
+    if (multi_uav_) {
+      MatrixList S_list, P_list, H_list, res_list;
+      constructShortMsckfUpdate(state, h, res, r, S_list, P_list, H_list, res_list);
+      for (size_t j = 0; j < P_list.size(); j++) applyCI(state, *P_list[j], *H_list[j], *res_list[j], *S_list[j]);
+      // (the MULTI_UAV build stops here: it does not apply the short-track rows themselves, updater.cpp:56-66)
+      compressed_on_device_ = false;
+      prior_stale_on_device_ = false;
+    } else {
+      constructShortMsckfUpdate(state, h, res, r);
+      if (h.size() > 0) applyUpdate(state, h, res, r, correction, true);
+    }
   }
-  if (preUpdate(state)) {
+  const bool update_requested = preUpdate(state);
+  if (update_requested) {
     correction = Matrix::Zero(state.nErrorStates(), 1);
-    for (int i = 0; i < iekf_iter_; i++) {
-      const bool is_last_iter = i == iekf_iter_ - 1;
-      constructUpdate(state, h, res, r);
-      if (h.size() > 0) applyUpdate(state, h, res, r, correction, is_last_iter);
+    if (multi_uav_) {                                  // :84-97: CI entries first, then the regular update, no IEKF loop
+      MatrixList S_list, P_list, H_list, res_list;
+      constructUpdate(state, h, res, r, S_list, P_list, H_list, res_list);
+      for (size_t j = 0; j < P_list.size(); j++) applyCI(state, *P_list[j], *H_list[j], *res_list[j], *S_list[j]);
+      if (h.size() > 0) applyUpdate(state, h, res, r, correction, true);
+    } else {
+      for (int i = 0; i < iekf_iter_; i++) {
+        const bool is_last_iter = i == iekf_iter_ - 1;
+        constructUpdate(state, h, res, r);
+        if (h.size() > 0) applyUpdate(state, h, res, r, correction, is_last_iter);
+      }
     }
     postUpdate(state, correction);
   }
@@ -43,15 +62,22 @@ void Updater::update(State &state) {                   // updater.cpp:39-115
 void Updater::applyUpdate(State &state, const Matrix &H, const Matrix &res, const Matrix &R, Matrix &correction_total,
                           const bool cov_update) {     // updater.cpp:117-141
   Matrix &P = state.getCovarianceRef();
-  const int n = P.rows();
+  const int n = state.nErrorStates();
   Matrix correction(n, 1);
   if (compressed_on_device_) {
-    // constructUpdate left the compressed [T_H | z] and the prior covariance resident in HBM
+    // constructUpdate left the compressed [T_H | z] resident in HBM.  The prior is the handle's covariance: what
+    // constructUpdate staged, unless an applyCI has rewritten state.cov_ since (H and res stay linearised at the
+    // staged prior, as in the reference, where constructUpdate runs before the applyCI loop).
+    if (prior_stale_on_device_) {
+      check(xk_, xk_upload_P(xk_, P.data(), n, n), "xk_upload_P");
+      prior_stale_on_device_ = false;
+    }
     check(xk_, xk_apply_update(xk_, correction_total.data(), cov_update ? 1 : 0, correction.data()), "xk_apply_update");
-    if (cov_update) check(xk_, xk_download_P(xk_, P.data(), n, n), "xk_download_P");
+    if (cov_update && !resident_) check(xk_, xk_download_P(xk_, P.data(), n, n), "xk_download_P");
     compressed_on_device_ = false;
     for (int i = 0; i < n; ++i) correction_total(i) += correction(i);                     // :140
   } else {
+    if (resident_) throw std::runtime_error("Updater::applyUpdate: dense h with a resident covariance is not supported");
     std::vector<double> rdiag(H.rows());
     for (int i = 0; i < H.rows(); ++i) rdiag[i] = R(i, i);
     check(xk_, xk_apply_update_dense(xk_, P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), rdiag.data(),
@@ -63,9 +89,16 @@ void Updater::applyUpdate(State &state, const Matrix &H, const Matrix &res, cons
 
 void Updater::applyCI(State &state, Matrix &ci_P, const Matrix &H, const Matrix &res, Matrix &S) {  // updater.cpp:144-161
   Matrix &P = state.getCovarianceRef();
-  const int n = P.rows();
+  const int n = state.nErrorStates();
   Matrix correction(n, 1);
-  check(xk_, xk_apply_ci(xk_, P.data(), n, ci_P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), S.data(),
-                         S.rows(), correction.data()), "xk_apply_ci");
+  if (resident_) {
+    // P = sym((I - K H) ci_P) becomes the handle's covariance; it does not come back to the host
+    check(xk_, xk_apply_ci_resident(xk_, ci_P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), S.data(), S.rows(),
+                                    correction.data()), "xk_apply_ci_resident");
+  } else {
+    check(xk_, xk_apply_ci(xk_, P.data(), n, ci_P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), S.data(),
+                           S.rows(), correction.data()), "xk_apply_ci");
+    prior_stale_on_device_ = compressed_on_device_;   // the staged prior no longer is state.cov_
+  }
   state.correct(correction);
 }

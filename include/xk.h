@@ -299,6 +299,16 @@ int xk_pr_copy_keyframe(xk_pr *p, int index, double *d_payload_dst, double *d_tr
  * idx / dist HOST [nq][2], ascending (distance, train index); idx = -1 where the train set is too short. */
 int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned char *train, int nt, int *idx, int *dist);
 
+/* Updater::applyCI (updater.cpp:144-161) on the RESIDENT covariance: P <- sym((I - K H) ci_P), K = ci_P H^T S^-1,
+ * replaces the handle's covariance and stays on the device; only the n-vector correction comes back.  A compressed
+ * [T_H | z] waiting for xk_apply_update is left alone, so the reference's order -- constructUpdate, the applyCI loop,
+ * then applyUpdate on the post-CI covariance (updater.cpp:84-97) -- needs no covariance transfer. */
+int xk_apply_ci_resident(xk_handle *h, const double *ci_P, int ldc, int n, const double *H, int ldh, int m,
+                         const double *res, const double *S, int lds, double *correction);
+
+/* Save (restore = 0) / bring back (restore = 1) a device-side copy of the resident covariance. */
+int xk_snapshot_P(xk_handle *h, int restore);
+
 /* ---- measurement ----------------------------------------------------- */
 
 #define XK_NSTAGE 6
@@ -321,6 +331,12 @@ int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_ti
  * posterior of the last one left in the handle's output buffer) and waits for
  * them; nothing crosses PCIe.  This is the timed region of bench.py. */
 int xk_run_steps(xk_handle *h, double sigma_img, int steps);
+
+/* Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST=1 XK_CAQR_PERSIST_DBG=1): per panel k,
+ * out[8k + 0..5] = one tile-owning workgroup (tile step start / end, after the XCD barrier, first-level merge start /
+ * end, after the second barrier), out[8k + 6..7] = one last-level workgroup; from out[256] on, the same six stamps for
+ * every tile-owning workgroup of XCD 0 ([slot][panel][8]).  n_out <= 256 + 64 * 256. */
+int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out);
 
 /* Micro-benchmark of the fp64 ceiling this path is priced against: a grid of
  * waves issuing independent v_mfma_f64_16x16x4_f64 (use_mfma=1) or v_fma_f64

@@ -576,6 +576,35 @@ def msckf_ci_track(trk, C_q_G, G_p_C, P, n_poses_max, sigma_img, matches, ci_msc
     return out
 
 
+def multi_uav_update(tracks, matches_per_track, C_q_G, G_p_C, P, n_poses_max, sigma_img, ci_msckf_w, slam=None,
+                     msckf_slam_tracks=None):
+    """The MULTI_UAV branch of Updater::update (updater.cpp:84-97) around VioUpdater::constructUpdate
+    (vio_updater.cpp:295-305, 267-423): every list entry AND the stacked h / res are built from the prior P
+    (MsckfUpdate receives cov_s = P once, msckf_update.cpp:27-63); then applyCI runs per entry -- each one
+    REPLACING the state covariance by (I - K H) P_j, with P_j a scaled copy of the prior (Q6) -- and finally
+    applyUpdate on the covariance the last applyCI left, with h / res still linearised at the prior.
+
+    matches_per_track: dict track index -> list of match dicts (see msckf_ci_track).
+    Returns dict(P, corrections [one per applyCI, then the update's], n_ci, ci [entries], visual [visual_update dict])."""
+    entries = []
+    for i, trk in enumerate(tracks):
+        m = matches_per_track.get(i)
+        if not m:
+            continue
+        o = msckf_ci_track(trk, C_q_G, G_p_C, P, n_poses_max, sigma_img, m, ci_msckf_w)
+        if o["ci"] is not None:
+            entries.append(o["ci"])
+    vis = visual_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img, slam=slam, msckf_slam_tracks=msckf_slam_tracks)
+    P_cur, corrections = np.asarray(P, float).copy(), []
+    for c in entries:                                          # updater.cpp:90-93
+        P_cur, corr = apply_ci(c["P_j"], c["H"], c["res"], c["S"])
+        corrections.append(corr)
+    if vis["h"].size > 0:                                      # :94-97
+        P_cur, corr = apply_update(P_cur, vis["h"], vis["res"], vis["r_diag"])
+        corrections.append(corr)
+    return dict(P=P_cur, corrections=corrections, n_ci=len(entries), ci=entries, visual=vis)
+
+
 # ----------------------------------------------------------------------------
 # StateManager::manage (src/x/vio/state_manager.cpp:31-149): the step that runs immediately before the
 # visual update every frame -- persistent-feature removal, anchor re-parametrisation + window slide when
@@ -734,6 +763,97 @@ def propagate_covariance_matrices(cov_0, f_d, q_d):
     cov_1[k:, :k] = cov_0[k:, :k] @ f_d.T                  # :203
     cov_1[k:, k:] = cov_0[k:, k:]                          # :204
     return cov_1
+
+
+# ----------------------------------------------------------------------------
+# IMU propagation closed forms (host side): src/x/ekf/propagator.cpp
+# ----------------------------------------------------------------------------
+def omega_matrix(w):
+    """Vector3::toOmegaMatrix (eigen_matrix_base_plugin.h:55-63): quaternion kinematic matrix, (x,y,z,w) order."""
+    x, y, z = w
+    return np.array([[0.0, z, -y, x], [-z, 0.0, x, y], [y, -x, 0.0, z], [-x, -y, -z, 0.0]])
+
+
+def quaternion_integrator(e_w_0, e_w_1, dt):
+    """Propagator::quaternionIntegrator, propagator.cpp:73-97: 4th-order Taylor series of exp(Omega(mean) dt / 2) plus
+    the first-order commutator term (Trawny & Roumeliotis eq. 130-131)."""
+    om1, om0 = omega_matrix(e_w_1), omega_matrix(e_w_0)
+    a = omega_matrix((np.asarray(e_w_1) + np.asarray(e_w_0)) / 2.0) * 0.5 * dt
+    a_k, mat_exp, fac = a.copy(), np.eye(4), 1
+    for k in range(1, 5):
+        fac *= k
+        mat_exp = mat_exp + a_k / fac
+        a_k = a_k @ a
+    return mat_exp + 1.0 / 48.0 * (om1 @ om0 - om0 @ om1) * dt * dt
+
+
+def propagate_state(s0, s1, g):
+    """Propagator::propagateState, propagator.cpp:30-51.  s0 / s1: dicts with time, p, v, q (xyzw), b_w, b_a, w_m, a_m;
+    s1 arrives with time / w_m / a_m set (State::setImu) and leaves with p, v, q, biases filled."""
+    s1["b_w"], s1["b_a"] = s0["b_w"].copy(), s0["b_a"].copy()                      # setStaticStatesFrom (window arrays too)
+    e_w_1, e_a_1 = s1["w_m"] - s1["b_w"], s1["a_m"] - s1["b_a"]
+    e_w_0, e_a_0 = s0["w_m"] - s0["b_w"], s0["a_m"] - s0["b_a"]
+    dt = s1["time"] - s0["time"]
+    q1 = quaternion_integrator(e_w_0, e_w_1, dt) @ s0["q"]
+    s1["q"] = q1 / np.linalg.norm(q1)
+    dv = (quat_to_rot(s1["q"]) @ e_a_1 + quat_to_rot(s0["q"]) @ e_a_0) / 2.0
+    s1["v"] = s0["v"] + (dv + g) * dt
+    s1["p"] = s0["p"] + (s1["v"] + s0["v"]) / 2.0 * dt
+    return s1
+
+
+def discrete_state_transition(dt, e_w, e_a, q_xyzw):
+    """Propagator::discreteStateTransition, propagator.cpp:99-164 (15 x 15, error-state order p v theta b_w b_a)."""
+    w_x, a_x, eye3 = skew(e_w), skew(e_a), np.eye(3)
+    c_q = quat_to_rot(q_xyzw)
+    dt_2_f2 = dt * dt * 0.5
+    dt_3_f3 = dt_2_f2 * dt / 3.0
+    dt_4_f4 = dt_3_f3 * dt * 0.25
+    dt_5_f5 = dt_4_f4 * dt * 0.2
+    c_q_a_x = c_q @ a_x
+    a = c_q_a_x @ (-dt_2_f2 * eye3 + dt_3_f3 * w_x - dt_4_f4 * w_x @ w_x)
+    b = c_q_a_x @ (dt_3_f3 * eye3 - dt_4_f4 * w_x + dt_5_f5 * w_x @ w_x)
+    d = -a
+    e = eye3 - dt * w_x + dt_2_f2 * w_x @ w_x
+    f = -dt * eye3 + dt_2_f2 * w_x - dt_3_f3 * (w_x @ w_x)
+    c = c_q_a_x @ f
+    F = np.eye(15)
+    F[0:3, 3:6] = dt * eye3
+    F[0:3, 6:9] = a
+    F[0:3, 9:12] = b
+    F[0:3, 12:15] = -c_q * dt_2_f2
+    F[3:6, 6:9] = c
+    F[3:6, 9:12] = d
+    F[3:6, 12:15] = -c_q * dt
+    F[6:9, 6:9] = e
+    F[6:9, 9:12] = f
+    return F
+
+
+def process_noise_model(dt, e_w, e_a, q_xyzw, n_w, n_bw, n_a, n_ba):
+    """A first-principles discrete process noise  Q_d = int_0^dt F_d(t) G Q_c G^T F_d(t)^T dt  (Weiss 2012, eq. 2.33)
+    with the reference's own F_d(t) and G = [v: -C(q) n_a, theta: -n_w, b_w: n_bw, b_a: n_ba], integrated exactly
+    (the integrand is a polynomial in t: 12-point Gauss-Legendre).
+
+    NOT the reference's q_d: Propagator::discreteProcessNoiseCov (propagator.cpp:207-840) is 630 lines of
+    machine-generated scalar code that assigns 147 of the 225 entries, is not symmetric, and carries first-order gyro-noise
+    terms in the velocity block that no derivation of this form produces (tests/test_oracle_propagator.py measures the
+    difference on the reference's own outputs, tests/golden/propagator_qd.npz).  It cannot be restated without copying
+    it, and it is host-side 15 x 15 arithmetic, so a drop-in keeps the reference's function and hands its q_d to
+    xk_cov_propagate; this model is what the mirror's own examples and the frame-loop benchmark use."""
+    G = np.zeros((15, 12))
+    G[3:6, 0:3] = -quat_to_rot(q_xyzw)
+    G[6:9, 6:9] = -np.eye(3)
+    G[9:12, 9:12] = np.eye(3)
+    G[12:15, 3:6] = np.eye(3)
+    Qc = np.diag([n_a ** 2] * 3 + [n_ba ** 2] * 3 + [n_w ** 2] * 3 + [n_bw ** 2] * 3)
+    x, wq = np.polynomial.legendre.leggauss(12)
+    Q = np.zeros((15, 15))
+    for xi, wi in zip(x, wq):
+        t = 0.5 * dt * (xi + 1.0)
+        Ft = discrete_state_transition(t, e_w, e_a, q_xyzw)
+        Q += 0.5 * dt * wi * (Ft @ G @ Qc @ G.T @ Ft.T)
+    return 0.5 * (Q + Q.T)
 
 
 # ----------------------------------------------------------------------------

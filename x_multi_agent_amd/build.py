@@ -31,19 +31,19 @@ def build_host(force=False, verbose=True):
     root = os.path.join(HERE, "..")
     lib = os.path.join(HERE, "libx_host.so")
     exe = os.path.join(HERE, "xk_host_example")
-    exe2 = os.path.join(HERE, "xk_manage_example")
-    exe3 = os.path.join(HERE, "xk_place_example")
-    srcs = [os.path.join(root, "host", "src", f) for f in ("state.cpp", "updater.cpp", "vio_updater.cpp", "ekf.cpp",
-                                                           "state_manager.cpp", "place_recognition.cpp")]
+    srcs = [os.path.join(root, "host", "src", f) for f in sorted(os.listdir(os.path.join(root, "host", "src"))) if f.endswith(".cpp")]
     inc = ["-I" + os.path.join(root, "host", "include"), "-I" + os.path.join(root, "include")]
     link = ["-L" + HERE, "-lxk", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
-    cmds = [["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + inc + srcs + ["-o", lib] + link,
-            ["g++", "-std=c++17", "-O2", "-Wall"] + inc + [os.path.join(root, "host", "examples", "visual_update_main.cpp"),
-                                                           "-o", exe, "-L" + HERE, "-lx_host"] + link[1:],
-            ["g++", "-std=c++17", "-O2", "-Wall"] + inc + [os.path.join(root, "host", "examples", "state_manage_main.cpp"),
-                                                           "-o", exe2, "-L" + HERE, "-lx_host"] + link[1:],
-            ["g++", "-std=c++17", "-O2", "-Wall"] + inc + [os.path.join(root, "host", "examples", "place_recognition_main.cpp"),
-                                                           "-o", exe3, "-L" + HERE, "-lx_host"] + link[1:]]
+    cmds = [["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + inc + srcs + ["-o", lib] + link]
+    # every host/examples/<name>_main.cpp -> x_multi_agent_amd/xk_<short>_example
+    short = {"visual_update": "host", "state_manage": "manage", "place_recognition": "place"}
+    for f in sorted(os.listdir(os.path.join(root, "host", "examples"))):
+        if not f.endswith("_main.cpp"):
+            continue
+        name = f[:-len("_main.cpp")]
+        out = os.path.join(HERE, "xk_%s_example" % short.get(name, name))
+        cmds.append(["g++", "-std=c++17", "-O2", "-Wall"] + inc + [os.path.join(root, "host", "examples", f), "-o", out,
+                                                                   "-L" + HERE, "-lx_host"] + link[1:])
     for c in cmds:
         if verbose:
             print(" ".join(c), flush=True)

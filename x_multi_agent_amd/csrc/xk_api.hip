@@ -33,6 +33,7 @@ struct xk_handle {
   double *d_q, *d_p, *d_obs, *d_feat, *d_zlast;
   int *d_trk_off, *d_anchor, *d_tsz;
   double *d_P, *d_Pout;
+  double *d_Psnap;        // xk_snapshot_P
   double *d_chi95, *d_chi90;
   double *d_A;
   int *d_tile_rows;
@@ -257,6 +258,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   free(h->h_trk2_off);
   if (h->d_csr_i) hipFree(h->d_csr_i);
   if (h->d_csr_v) hipFree(h->d_csr_v);
+  if (h->d_Psnap) hipFree(h->d_Psnap);
   for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
     if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
@@ -1047,6 +1049,50 @@ extern "C" int xk_apply_ci(xk_handle *h, double *P_out, int ldp, const double *c
   HIPCHK(h, hipMemcpy2DAsync(P_out, sizeof(double) * ldp, h->d_Pout, sizeof(double) * n, sizeof(double) * n, n,
                              hipMemcpyDeviceToHost, h->stream));
   return read_status(h);
+}
+
+// applyCI on the RESIDENT covariance: P <- sym((I - K H) ci_P) replaces the handle's covariance and stays on the
+// device (the host mirror's resident mode; the compressed [T_H | z] of a pending xk_apply_update is not touched).
+extern "C" int xk_apply_ci_resident(xk_handle *h, const double *ci_P, int ldc, int n, const double *H, int ldh, int m,
+                                    const double *res, const double *S, int lds, double *correction) {
+  if (!h || !ci_P || !H || !res || !S || !correction || n != h->n || ldc < n || ldh < m || lds < m || m <= 0) return XK_EINVAL;
+  if (m > h->CM) return fail(h, XK_ECAPACITY, "m exceeds the dense workspace");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, ci_P, sizeof(double) * ldc, sizeof(double) * n, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, H, sizeof(double) * ldh, sizeof(double) * m, n,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpy2DAsync(h->d_tmpS, sizeof(double) * m, S, sizeof(double) * lds, sizeof(double) * m, m,
+                             hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_tmpz, res, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+  UpdateSpec u;
+  memset(&u, 0, sizeof(u));
+  u.T = h->d_tmpH; u.str = 1; u.stc = m;
+  u.c = m; u.kdim = n; u.col0 = 0;
+  u.z = h->d_tmpz; u.sz = 1;
+  u.S = h->d_tmpS; u.ssr = 1; u.ssc = m;
+  u.Pin = h->d_tmpP; u.Pout = h->d_Pout; u.ct = nullptr; u.cov_update = 1;
+  int rc = launch_update(h, u);
+  if (rc != XK_OK) return rc;
+  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  rc = read_status(h);
+  if (rc != XK_OK) return rc;
+  std::swap(h->d_P, h->d_Pout);
+  return XK_OK;
+}
+
+// Keeps / brings back a copy of the resident covariance on the device (restore = 0: save, 1: restore).  Benchmarks
+// use it to replay a frame from the same prior without a PCIe upload.
+extern "C" int xk_snapshot_P(xk_handle *h, int restore) {
+  if (!h) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t bytes = sizeof(double) * (size_t)h->n * h->n;
+  if (!h->d_Psnap) {
+    if (restore) return fail(h, XK_EINVAL, "xk_snapshot_P: nothing saved");
+    HIPCHK(h, dalloc(&h->d_Psnap, (size_t)h->n * h->n));
+  }
+  HIPCHK(h, hipMemcpyAsync(restore ? h->d_P : h->d_Psnap, restore ? h->d_Psnap : h->d_P, bytes, hipMemcpyDeviceToDevice, h->stream));
+  return XK_OK;
 }
 
 // ---------------------------------------------------------------------------
