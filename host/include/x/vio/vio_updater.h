@@ -32,7 +32,8 @@ class VioUpdater : public Updater {
   ~VioUpdater() override;
   VioUpdater(const VioUpdater &) = delete;
 
-  void setMeasurement(const VioMeasurement &m) { measurement_ = m; }
+  void setMeasurement(const VioMeasurement &m) { measurement_ = m; stageMeasurementEarly(); }
+  void setMeasurement(VioMeasurement &&m) { measurement_ = std::move(m); stageMeasurementEarly(); }   // the tracker hands its lists over
   // Window occupancy and SLAM anchors live in the StateManager (state_manager.h).  manage_window = true makes
   // preUpdate call StateManager::manage (vio_updater.cpp:200-202: slide, re-anchor, augment with the current camera
   // pose); with false the window arrives ready-made in the State (a snapshot taken after manage()).
@@ -74,5 +75,8 @@ class VioUpdater : public Updater {
   double sigma_img_, sigma_landmark_, ci_slam_w_, ci_msckf_w_, rho_0_, sigma_rho_0_;
   std::vector<int> inlier_msckf_, inlier_slam_;
   int n_ci_entries_ = 0;
+  bool flags_pending_ = false;
+  bool tracks_staged_ = false;       // resident mode: measurement_.msckf_tracks already sit on the device
+  void stageMeasurementEarly();
 };
 }  // namespace x

@@ -13,13 +13,14 @@ namespace {
 void check(xk_handle *h, int rc, const char *what) {
   if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + (h ? xk_last_error(h) : "") + ")");
 }
+// c = a b, skipping the structural zeros of a (f_d is the identity plus nine 3 x 3 blocks: ~100 of 225 entries)
 CoreCovMatrix mul15(const CoreCovMatrix &a, const CoreCovMatrix &b) {
   CoreCovMatrix c = CoreCovMatrix::Zero();
-  for (int j = 0; j < 15; ++j)
-    for (int k = 0; k < 15; ++k) {
-      const double bkj = b(k, j);
-      if (bkj == 0.0) continue;
-      for (int i = 0; i < 15; ++i) c(i, j) += a(i, k) * bkj;
+  for (int k = 0; k < 15; ++k)
+    for (int i = 0; i < 15; ++i) {
+      const double aik = a(i, k);
+      if (aik == 0.0) continue;
+      for (int j = 0; j < 15; ++j) c(i, j) += aik * b(k, j);
     }
   return c;
 }
@@ -64,8 +65,12 @@ void Ekf::initializeFromState(const State &init_state) {                    // e
   buffer_[0] = init_state;
   if (resident_) {
     const int n = init_state.nErrorStates();
-    if (init_state.cov_.rows() != n) throw std::runtime_error("init_bfr_mismatch");
-    check(updater_.engine(), xk_upload_P(updater_.engine(), init_state.cov_.data(), n, n), "xk_upload_P");   // once
+    // an init state WITHOUT a covariance means the handle's covariance is already the initial one (e.g. restored with
+    // xk_snapshot_P); otherwise it is uploaded, once
+    if (init_state.cov_.size() > 0) {
+      if (init_state.cov_.rows() != n) throw std::runtime_error("init_bfr_mismatch");
+      check(updater_.engine(), xk_upload_P(updater_.engine(), init_state.cov_.data(), n, n), "xk_upload_P");
+    }
     buffer_[0].cov_ = Matrix();
     cov_idx_ = 0;
   }
@@ -138,7 +143,8 @@ bool Ekf::advanceDeviceCovariance(int idx) {
     // Q_tot = sum_j (F_k ... F_{j+1}) Q_j (.)^T; P_iv <- Phi P_iv likewise.  15 x 15 products on the host, one launch.
     CoreCovMatrix phi = CoreCovMatrix::Identity(), qt = CoreCovMatrix::Zero();
     for (int i = (cov_idx_ + 1) % sz, s = 0; s < steps; i = (i + 1) % sz, ++s) {
-      const CoreCovMatrix fq = mul15(mul15(f_d_[i], qt), transpose15(f_d_[i]));
+      // F Q F^T = (F (F Q)^T)^T: both products have the sparse f_d on the left
+      const CoreCovMatrix fq = transpose15(mul15(f_d_[i], transpose15(mul15(f_d_[i], qt))));
       for (int k = 0; k < 225; ++k) qt.m[k] = fq.m[k] + q_d_[i].m[k];
       phi = mul15(f_d_[i], phi);
     }

@@ -123,16 +123,15 @@ CoreCovMatrix Propagator::discreteProcessNoiseCov(double dt, const Quaternion &q
                                                   double n_w, double n_bw, double n_a, double n_ba) const {
   // G Q_c G^T for G = [v: -C(q), theta: -I, b_w: I, b_a: I] is block diagonal and does not depend on q:
   // diag(0, n_a^2 I, n_w^2 I, n_bw^2 I, n_ba^2 I).  The integrand F_d(t) (.) F_d(t)^T is a polynomial in t.
-  static const double gx[12] = {-0.9815606342467192, -0.9041172563704749, -0.7699026741943047, -0.5873179542866175,
-                                -0.3678314989981802, -0.1252334085114689, 0.1252334085114689,  0.3678314989981802,
-                                0.5873179542866175,  0.7699026741943047,  0.9041172563704749,  0.9815606342467192};
-  static const double gw[12] = {0.0471753363865118, 0.1069393259953184, 0.1600783285433462, 0.2031674267230659,
-                                0.2334925365383548, 0.2491470458134028, 0.2491470458134028, 0.2334925365383548,
-                                0.2031674267230659, 0.1600783285433462, 0.1069393259953184, 0.0471753363865118};
+  // (degree <= 10 in t: six Gauss-Legendre points are exact)
+  static const double gx[6] = {-0.9324695142031521, -0.6612093864662645, -0.2386191860831969,
+                               0.2386191860831969,  0.6612093864662645,  0.9324695142031521};
+  static const double gw[6] = {0.1713244923791704, 0.3607615730481386, 0.4679139345726910,
+                               0.4679139345726910, 0.3607615730481386, 0.1713244923791704};
   double dg[15];
   for (int i = 0; i < 3; ++i) { dg[i] = 0.0; dg[3 + i] = n_a * n_a; dg[6 + i] = n_w * n_w; dg[9 + i] = n_bw * n_bw; dg[12 + i] = n_ba * n_ba; }
   CoreCovMatrix Q = CoreCovMatrix::Zero();
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < 6; ++k) {
     const double t = 0.5 * dt * (gx[k] + 1.0), wk = 0.5 * dt * gw[k];
     const CoreCovMatrix F = discreteStateTransition(t, e_w, e_a, q);
     for (int i = 0; i < 15; ++i)

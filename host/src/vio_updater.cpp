@@ -14,6 +14,15 @@ static void check(xk_handle *h, int rc, const char *what) {
   if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + (h ? xk_last_error(h) : "") + ")");
 }
 
+static void toCsr(const TrackList &tr, std::vector<int> &off, std::vector<double> &obs) {
+  off.assign(tr.size() + 1, 0);
+  obs.clear();
+  for (size_t k = 0; k < tr.size(); ++k) {
+    off[k + 1] = off[k] + (int)tr[k].size();
+    for (const Feature &f : tr[k]) { obs.push_back(f.getX()); obs.push_back(f.getY()); }
+  }
+}
+
 VioUpdater::VioUpdater(int device, int n_poses_max, int n_feat_max, int k_max, double sigma_img, double sigma_landmark,
                        double ci_slam_w, int iekf_iter, double ci_msckf_w, double rho_0, double sigma_rho_0)
     : n_poses_max_(n_poses_max), n_feat_max_(n_feat_max), k_max_(k_max), state_manager_(n_poses_max, n_feat_max, nullptr),
@@ -34,6 +43,18 @@ void VioUpdater::setWindow(int n_poses, const std::vector<int> &anchor_idxs, boo
   state_manager_.restore(n_poses, n_features, a, filled_before);
 }
 
+// With a resident covariance the tracks of the frame go to the device as soon as they arrive (an asynchronous copy that
+// overlaps the host work before the update: covariance propagation, manage()); constructUpdate finds them staged.
+void VioUpdater::stageMeasurementEarly() {
+  tracks_staged_ = false;
+  if (!resident_ || !measurement_.msckf_short_tracks.empty()) return;   // (the short-track update stages its own tracks first)
+  std::vector<int> off;
+  std::vector<double> obs;
+  toCsr(measurement_.msckf_tracks, off, obs);
+  check(xk_, xk_stage_tracks(xk_, off.data(), obs.data(), (int)measurement_.msckf_tracks.size()), "xk_stage_tracks");
+  tracks_staged_ = true;
+}
+
 // Manage vision states to be added, removed, re-parametrised or slid (vio_updater.cpp:200-207)
 bool VioUpdater::preUpdate(State &state) {
   if (manage_window_) state_manager_.manage(state, measurement_.lost_slam_track_idxs, resident_);
@@ -50,24 +71,18 @@ void VioUpdater::windowLists(const State &state, std::vector<double> &q, std::ve
   p.assign(pa.data(), pa.data() + 3 * np);
 }
 
-static void toCsr(const TrackList &tr, std::vector<int> &off, std::vector<double> &obs) {
-  off.assign(tr.size() + 1, 0);
-  obs.clear();
-  for (size_t k = 0; k < tr.size(); ++k) {
-    off[k + 1] = off[k] + (int)tr[k].size();
-    for (const Feature &f : tr[k]) { obs.push_back(f.getX()); obs.push_back(f.getY()); }
-  }
-}
-
 void VioUpdater::buildAndCompress(const State &state, const TrackList &tr, bool with_slam, Matrix &h, Matrix &res, Matrix &r) {
   const int n = state.nErrorStates();
   std::vector<double> q, p;
   windowLists(state, q, p);
   check(xk_, xk_stage_window(xk_, q.data(), p.data(), state_manager_.getNPoses()), "xk_stage_window");
-  std::vector<int> off;
-  std::vector<double> obs;
-  toCsr(tr, off, obs);
-  check(xk_, xk_stage_tracks(xk_, off.data(), obs.data(), (int)tr.size()), "xk_stage_tracks");
+  if (!(tracks_staged_ && &tr == &measurement_.msckf_tracks)) {
+    std::vector<int> off;
+    std::vector<double> obs;
+    toCsr(tr, off, obs);
+    check(xk_, xk_stage_tracks(xk_, off.data(), obs.data(), (int)tr.size()), "xk_stage_tracks");
+  }
+  tracks_staged_ = false;
   const TrackList &st = measurement_.slam_tracks;
   const int M = with_slam ? (int)st.size() : 0;
   std::vector<double> z(2 * (size_t)M);
@@ -90,14 +105,18 @@ void VioUpdater::buildAndCompress(const State &state, const TrackList &tr, bool 
   if (!resident_) check(xk_, xk_upload_P(xk_, state.getCovariance().data(), n, n), "xk_upload_P");   // Matrix P = state.getCovariance()
   inlier_msckf_.assign(tr.size(), 0);
   inlier_slam_.assign(M, 0);
-  check(xk_, xk_msckf_build(xk_, sigma_img_, inlier_msckf_.data(), nullptr, inlier_slam_.data(), nullptr), "xk_msckf_build");
   if (resident_) {
-    // [T_H | z] stays in HBM and xk_apply_update consumes it there; h only has to be non-empty for Updater::update
-    check(xk_, xk_qr_compress(xk_, nullptr, 0, nullptr), "xk_qr_compress");
+    // Nothing waits for the device here: the per-feature build and the compression are queued behind the staging copies
+    // (and behind the covariance propagation / manage() of this frame); [T_H | z] stays in HBM, xk_apply_update consumes
+    // it there and its synchronisation also brings the gate flags (fetched in postUpdate).  h only has to be non-empty
+    // for Updater::update.
+    check(xk_, xk_build_compress_async(xk_, sigma_img_), "xk_build_compress_async");
+    flags_pending_ = true;
     h = Matrix::Zero(1, 1);
     res = Matrix::Zero(1, 1);
     r = Matrix::Zero(1, 1);
   } else {
+    check(xk_, xk_msckf_build(xk_, sigma_img_, inlier_msckf_.data(), nullptr, inlier_slam_.data(), nullptr), "xk_msckf_build");
     h = Matrix::Zero(n, n);
     res = Matrix::Zero(n, 1);
     check(xk_, xk_qr_compress(xk_, h.data(), n, res.data()), "xk_qr_compress");       // applyQRDecomposition
@@ -226,6 +245,10 @@ void VioUpdater::constructSlamCIUpdate(const State &state, MatrixList &S_list, M
 
 // Feature initialisation after the update (vio_updater.cpp:425-446)
 void VioUpdater::postUpdate(State &state, const Matrix &correction) {
+  if (flags_pending_) {   // resident mode: the gate results arrived with applyUpdate's synchronisation
+    check(xk_, xk_fetch_flags(xk_, inlier_msckf_.data(), nullptr, inlier_slam_.data(), nullptr), "xk_fetch_flags");
+    flags_pending_ = false;
+  }
   const int n_new = (int)measurement_.new_msckf_slam_tracks.size();
   if (n_new > 0) state_manager_.initMsckfSlamFeatures(state, n_new, correction, sigma_img_, resident_);   // :428-434
   if (!measurement_.new_slam_std_tracks.empty()) {                                                        // :437-446

@@ -299,6 +299,14 @@ int xk_pr_copy_keyframe(xk_pr *p, int index, double *d_payload_dst, double *d_tr
  * idx / dist HOST [nq][2], ascending (distance, train index); idx = -1 where the train set is too short. */
 int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned char *train, int nt, int *idx, int *dist);
 
+/* xk_msckf_build + xk_qr_compress queued on the handle's stream with NO host synchronisation and no host outputs:
+ * together with the non-blocking staging calls and xk_cov_congruence / xk_cov_propagate, a whole frame -- covariance
+ * propagation, StateManager::manage, per-feature build, QR compression, Kalman update -- is queued back to back and
+ * xk_apply_update's single synchronisation brings the correction, the status and the gate results back. */
+int xk_build_compress_async(xk_handle *h, double sigma_img);
+/* The gate results of the last build (any pointer may be NULL); synchronises the stream if it is still busy. */
+int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam);
+
 /* Updater::applyCI (updater.cpp:144-161) on the RESIDENT covariance: P <- sym((I - K H) ci_P), K = ci_P H^T S^-1,
  * replaces the handle's covariance and stays on the device; only the n-vector correction comes back.  A compressed
  * [T_H | z] waiting for xk_apply_update is left alone, so the reference's order -- constructUpdate, the applyCI loop,

@@ -6,7 +6,7 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 VISUAL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith(("ci_", "manage_", "msckf_slam_", "vocab_")))
+                      if not os.path.basename(p).startswith(("ci_", "manage_", "msckf_slam_", "vocab_", "multi_uav_", "propagator_")))
 
 # north_star tolerance: <= 1e-6 relative Frobenius on P (BASELINE.json).  The two
 # restatements and the GPU path agree far tighter than that; the tests assert the

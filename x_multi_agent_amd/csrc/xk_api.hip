@@ -19,11 +19,14 @@
 #include "xk_caqr_persist.hip.h"
 #include "xk_ci.hip.h"
 
-#define XK_VERSION_NUM 100
+#define XK_VERSION_NUM 200
+#define XK_STAGE_SLOTS 8
 
 struct xk_handle {
   int device;
   hipStream_t stream;
+  hipStream_t copy_stream;   // gate flags travel to the host beside the QR kernels, not between them
+  hipEvent_t ev_flags;
   hipEvent_t ev[16];
   // capacities
   int N, Mmax, Kmax, n, na, C1, C1P, DB, ntiles_max;
@@ -34,6 +37,7 @@ struct xk_handle {
   int *d_trk_off, *d_anchor, *d_tsz;
   double *d_P, *d_Pout;
   double *d_Psnap;        // xk_snapshot_P
+  double *d_fq;           // f_d, q_d of xk_cov_propagate
   double *d_chi95, *d_chi90;
   double *d_A;
   int *d_tile_rows;
@@ -74,6 +78,15 @@ struct xk_handle {
   int *d_csr_i;            // sparse congruence operand: row pointers then column indices
   double *d_csr_v;         //   and values
   size_t csr_cap;          //   capacity in non-zeros
+  // pinned staging ring for inputs copied to the device WITHOUT a host synchronisation (window, tracks, sparse operands):
+  // a slot is reused XK_STAGE_SLOTS calls later, by which time an update's final synchronisation has long passed
+  char *h_stage[XK_STAGE_SLOTS];
+  size_t stage_bytes;
+  int stage_next;
+  bool flags_cached;       // h_flag_* hold the gate results of the last build (fetched with the update's status)
+  int *h_flag_i;
+  double *h_flag_d;
+  bool async_pending;      // xk_build_compress_async ran: xk_apply_update owns the retry if the single-launch CAQR gave up
   // host pinned staging
   double *h_pin;
   size_t h_pin_doubles;
@@ -155,19 +168,24 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   h->LDA = h->CM + round_up(h->n + 1, 16);
   HIPCHK(h, hipSetDevice(device));
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_flags, hipEventDisableTiming));
   for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
   const size_t nn = (size_t)h->n * h->n;
   h->obs_cap = (size_t)k_max * n_poses_max;
-  HIPCHK(h, dalloc(&h->d_q, 4 * (size_t)n_poses_max));
-  HIPCHK(h, dalloc(&h->d_p, 3 * (size_t)n_poses_max));
-  HIPCHK(h, dalloc(&h->d_obs, 2 * h->obs_cap));
-  HIPCHK(h, dalloc(&h->d_trk_off, (size_t)k_max + 1));
+  // window lists in one allocation, observations + track offsets in another: a staging call is ONE host-to-device copy
+  // (small copies run as copy kernels of ~5 us each on the update's critical path)
+  HIPCHK(h, dalloc(&h->d_q, 7 * (size_t)n_poses_max));
+  h->d_p = h->d_q + 4 * (size_t)n_poses_max;
+  HIPCHK(h, dalloc(&h->d_obs, 2 * h->obs_cap + ((size_t)k_max + 2) / 2 + 1));
+  h->d_trk_off = (int *)(h->d_obs + 2 * h->obs_cap);
   HIPCHK(h, dalloc(&h->d_feat, 3 * (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_zlast, 2 * (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_anchor, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_tsz, (size_t)n_feat_max));
   HIPCHK(h, dalloc(&h->d_P, nn));
   HIPCHK(h, dalloc(&h->d_Pout, nn));
+  HIPCHK(h, dalloc(&h->d_fq, (size_t)450));
   HIPCHK(h, dalloc(&h->d_chi95, (size_t)XK_CHI2_LEN));
   HIPCHK(h, dalloc(&h->d_chi90, (size_t)XK_CHI2_LEN));
   HIPCHK(h, hipMemcpy(h->d_chi95, XK_CHI2_095, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
@@ -200,14 +218,14 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   }
   HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
   HIPCHK(h, dalloc(&h->d_X, (size_t)h->CM * h->LDA));
-  HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n));
+  HIPCHK(h, dalloc(&h->d_corr, (size_t)h->n + 4));   // + the status words right behind it: one copy brings both back
   HIPCHK(h, dalloc(&h->d_ct, (size_t)h->n));
   HIPCHK(h, dalloc(&h->d_tmpH, (size_t)h->CM * h->n));
   HIPCHK(h, dalloc(&h->d_tmpS, (size_t)h->CM * h->CM));
   HIPCHK(h, dalloc(&h->d_tmpP, nn));
   HIPCHK(h, dalloc(&h->d_rdiag, (size_t)h->CM));
   HIPCHK(h, dalloc(&h->d_tmpz, (size_t)h->CM));
-  HIPCHK(h, dalloc(&h->d_status, (size_t)4));
+  h->d_status = (int *)(h->d_corr + h->n);
   HIPCHK(h, dalloc(&h->d_payload, (size_t)xk_payload_doubles(n_poses_max, n_feat_max)));
   HIPCHK(h, dalloc(&h->d_ci, (size_t)4 * nn + 64 * (size_t)h->n + 1024));
   h->h_pin_doubles = nn + 8 * (size_t)h->n + 4 * (size_t)k_max + 4 * (size_t)n_feat_max + 1024;
@@ -229,11 +247,17 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     h->h_trk2_off = (int *)calloc(m + 1, sizeof(int));
     if (!h->h_trk2_off) return fail(h, XK_ENOMEM, "host track offsets");
   }
-  HIPCHK(h, dalloc(&h->d_csr_i, (size_t)h->n + 1 + h->csr_cap));
-  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max));
+  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max + ((size_t)h->n + 2 + h->csr_cap) / 2 + 1));
+  h->d_csr_i = nullptr;   // (the integer part follows the values of each operand)
   h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 512)));
+  h->stage_bytes = std::max({sizeof(double) * 2 * h->obs_cap + sizeof(int) * ((size_t)k_max + 1), sizeof(double) * 7 * (size_t)n_poses_max,
+                             (sizeof(int) + sizeof(double)) * h->csr_cap + sizeof(int) * ((size_t)h->n + 1) + sizeof(double) * (XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max),
+                             sizeof(double) * 8 * (size_t)std::max(n_feat_max, 1)}) + 256;
+  for (auto &sp : h->h_stage) HIPCHK(h, hipHostMalloc((void **)&sp, h->stage_bytes));
+  HIPCHK(h, hipHostMalloc((void **)&h->h_flag_i, sizeof(int) * ((size_t)k_max + n_feat_max + 8)));
+  HIPCHK(h, hipHostMalloc((void **)&h->h_flag_d, sizeof(double) * ((size_t)k_max + n_feat_max + 8)));
   HIPCHK(h, hipMemset(h->d_status, 0, sizeof(int) * 4));
   HIPCHK(h, hipMemset(h->d_tile_rows, 0, sizeof(int) * (size_t)h->ntiles_max));
   h->sigma_img = 0.0;
@@ -245,10 +269,10 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (!h) return XK_OK;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
-  void *ptrs[] = {h->d_q, h->d_p, h->d_obs, h->d_trk_off, h->d_feat, h->d_zlast, h->d_anchor, h->d_tsz,
+  void *ptrs[] = {h->d_q, h->d_obs, h->d_feat, h->d_zlast, h->d_anchor, h->d_tsz,
                   h->d_P, h->d_Pout, h->d_chi95, h->d_chi90, h->d_A, h->d_tile_rows, h->d_panel[0], h->d_panel[1], h->d_inl, h->d_inl_s,
                   h->d_gn, h->d_gam, h->d_gam_s, h->d_gpf, h->d_R, h->d_Maug, h->d_X, h->d_corr,
-                  h->d_ct, h->d_tmpH, h->d_tmpS, h->d_tmpP, h->d_rdiag, h->d_tmpz, h->d_status, h->d_payload,
+                  h->d_ct, h->d_tmpH, h->d_tmpS, h->d_tmpP, h->d_rdiag, h->d_tmpz, h->d_payload,
                   h->d_ci};
   for (void *p : ptrs)
     if (p) hipFree(p);
@@ -256,9 +280,9 @@ extern "C" int xk_destroy(xk_handle *h) {
                    (void *)h->d_gam2, (void *)h->d_H1, (void *)h->d_H2, (void *)h->d_r1, (void *)h->d_feat2})
     if (p2) hipFree(p2);
   free(h->h_trk2_off);
-  if (h->d_csr_i) hipFree(h->d_csr_i);
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
+  if (h->d_fq) hipFree(h->d_fq);
   for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
     if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
@@ -269,8 +293,14 @@ extern "C" int xk_destroy(xk_handle *h) {
   free(h->h_trk_off);
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
+  for (auto &sp : h->h_stage)
+    if (sp) hipHostFree(sp);
+  if (h->h_flag_i) hipHostFree(h->h_flag_i);
+  if (h->h_flag_d) hipHostFree(h->h_flag_d);
   for (auto &e : h->ev)
     if (e) hipEventDestroy(e);
+  if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+  if (h->ev_flags) hipEventDestroy(h->ev_flags);
   if (h->stream) hipStreamDestroy(h->stream);
   free(h);
   return XK_OK;
@@ -279,13 +309,25 @@ extern "C" int xk_destroy(xk_handle *h) {
 // ---------------------------------------------------------------------------
 // staging
 // ---------------------------------------------------------------------------
+// next slot of the pinned ring: host inputs are copied there and go to the device with an asynchronous copy, so that
+// staging never waits for the device (the caller's buffers are free on return, as before)
+static char *stage_slot(xk_handle *h, size_t bytes) {
+  if (bytes > h->stage_bytes) return nullptr;
+  char *p = h->h_stage[h->stage_next];
+  h->stage_next = (h->stage_next + 1) % XK_STAGE_SLOTS;
+  return p;
+}
+
 extern "C" int xk_stage_window(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses) {
   if (!h || !C_q_G || !G_p_C) return XK_EINVAL;
   if (n_poses < 2 || n_poses > h->N) return fail(h, XK_ECAPACITY, "n_poses outside [2, n_poses_max]");
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->d_q, C_q_G, sizeof(double) * 4 * n_poses, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_p, G_p_C, sizeof(double) * 3 * n_poses, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double *st = (double *)stage_slot(h, sizeof(double) * 7 * n_poses);
+  if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+  memcpy(st, C_q_G, sizeof(double) * 4 * n_poses);
+  memcpy(st + 4 * n_poses, G_p_C, sizeof(double) * 3 * n_poses);
+  h->d_p = h->d_q + 4 * (size_t)n_poses;                               // positions right behind the attitudes in use
+  HIPCHK(h, hipMemcpyAsync(h->d_q, st, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice, h->stream));
   h->n_poses = n_poses;
   h->have_rows = h->have_R = false;
   h->ms_built = false;
@@ -303,9 +345,13 @@ extern "C" int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *o
     }
     if ((size_t)trk_off[K] > h->obs_cap) return fail(h, XK_ECAPACITY, "too many observations");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->d_trk_off, trk_off, sizeof(int) * (K + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_obs, obs_xy, sizeof(double) * 2 * trk_off[K], hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t ob = sizeof(double) * 2 * (size_t)trk_off[K];
+    char *st = stage_slot(h, ob + sizeof(int) * (K + 1));
+    if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+    memcpy(st, obs_xy, ob);
+    memcpy(st + ob, trk_off, sizeof(int) * (K + 1));
+    h->d_trk_off = (int *)(h->d_obs + 2 * (size_t)trk_off[K]);         // offsets right behind the observations in use
+    HIPCHK(h, hipMemcpyAsync(h->d_obs, st, ob + sizeof(int) * (K + 1), hipMemcpyHostToDevice, h->stream));
   }
   if (K > 0) memcpy(h->h_trk_off, trk_off, sizeof(int) * (K + 1));
   h->K = K;
@@ -329,11 +375,18 @@ extern "C" int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor
   }
   if (M > 0) {
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(h->d_feat, feat, sizeof(double) * 3 * M, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_anchor, anchor_idxs, sizeof(int) * M, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_tsz, track_sizes, sizeof(int) * M, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_zlast, z_last, sizeof(double) * 2 * M, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    char *st = stage_slot(h, sizeof(double) * 6 * M);
+    if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+    double *sd = (double *)st;
+    int *si = (int *)(sd + 5 * M);
+    memcpy(sd, feat, sizeof(double) * 3 * M);
+    memcpy(sd + 3 * M, z_last, sizeof(double) * 2 * M);
+    memcpy(si, anchor_idxs, sizeof(int) * M);
+    memcpy(si + M, track_sizes, sizeof(int) * M);
+    HIPCHK(h, hipMemcpyAsync(h->d_feat, sd, sizeof(double) * 3 * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_zlast, sd + 3 * M, sizeof(double) * 2 * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_anchor, si, sizeof(int) * M, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_tsz, si + M, sizeof(int) * M, hipMemcpyHostToDevice, h->stream));
   }
   h->M = M;
   h->have_rows = h->have_R = false;
@@ -846,10 +899,7 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
 }
 
 #define XK_RETRY_CLASSIC 1000   // internal: the single-launch CAQR gave up, the multi-launch schedule must redo the update
-static int read_status(xk_handle *h, bool allow_retry = false) {
-  HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[4], h->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  const int st = h->h_pin_i[4], pst = h->h_pin_i[5];
+static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
   if (st != 0 || pst != 0) {
     hipMemsetAsync(h->d_status, 0, 2 * sizeof(int), h->stream);
     hipStreamSynchronize(h->stream);
@@ -863,6 +913,11 @@ static int read_status(xk_handle *h, bool allow_retry = false) {
   }
   if (st != 0) return fail(h, st, "innovation covariance not positive definite");
   return XK_OK;
+}
+static int read_status(xk_handle *h, bool allow_retry = false) {
+  HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[4], h->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return eval_status(h, h->h_pin_i[4], h->h_pin_i[5], allow_retry);
 }
 
 static int fetch_flags(xk_handle *h, int *inl, double *gam, int *inls, double *gams) {
@@ -917,21 +972,84 @@ extern "C" int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z) {
   return XK_OK;
 }
 
+// gate results of the last build -> the handle's pinned cache (asynchronous; valid after the next synchronisation)
+static int cache_flags(xk_handle *h) {
+  HIPCHK(h, hipEventRecord(h->ev_flags, h->stream));                 // the per-feature kernels have been queued
+  HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_flags, 0));
+  if (h->K > 0) {
+    HIPCHK(h, hipMemcpyAsync(h->h_flag_i, h->d_inl, sizeof(int) * h->K, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_flag_d, h->d_gam, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->copy_stream));
+  }
+  if (h->M > 0) {
+    HIPCHK(h, hipMemcpyAsync(h->h_flag_i + h->Kmax, h->d_inl_s, sizeof(int) * h->M, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_flag_d + h->Kmax, h->d_gam_s, sizeof(double) * h->M, hipMemcpyDeviceToHost, h->copy_stream));
+  }
+  h->flags_cached = true;
+  return XK_OK;
+}
+
+// xk_msckf_build + xk_qr_compress without a host synchronisation and without host outputs: the launches are queued behind
+// whatever is already on the handle's stream (staging copies, covariance propagation, manage()) and xk_apply_update's
+// one synchronisation covers them all.  The gate results come back with that synchronisation (xk_fetch_flags).
+extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
+  if (!h || !(sigma_img > 0.0)) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = launch_build(h, sigma_img);
+  if (rc != XK_OK) return rc;
+  if ((rc = cache_flags(h)) != XK_OK) return rc;
+  if ((rc = launch_compress(h)) != XK_OK) return rc;
+  h->async_pending = true;
+  return XK_OK;
+}
+
+extern "C" int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
+  if (!h) return XK_EINVAL;
+  if (!h->flags_cached) return fail(h, XK_EINVAL, "xk_fetch_flags: no build since the inputs were staged");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+  if (inlier_msckf && h->K > 0) memcpy(inlier_msckf, h->h_flag_i, sizeof(int) * h->K);
+  if (gamma_msckf && h->K > 0) memcpy(gamma_msckf, h->h_flag_d, sizeof(double) * h->K);
+  if (inlier_slam && h->M > 0) memcpy(inlier_slam, h->h_flag_i + h->Kmax, sizeof(int) * h->M);
+  if (gamma_slam && h->M > 0) memcpy(gamma_slam, h->h_flag_d + h->Kmax, sizeof(double) * h->M);
+  return XK_OK;
+}
+
 extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_update, double *correction) {
   if (!h || !correction) return XK_EINVAL;
   if (!h->have_R) return fail(h, XK_EINVAL, "xk_qr_compress has not run on the staged inputs");
   HIPCHK(h, hipSetDevice(h->device));
   const double *dct = nullptr;
-  if (corr_total) {
-    HIPCHK(h, hipMemcpyAsync(h->d_ct, corr_total, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+  bool ct_zero = true;                                 // Updater::update starts every update from a zero correction_total
+  if (corr_total)
+    for (int i = 0; i < h->n && ct_zero; ++i) ct_zero = corr_total[i] == 0.0;
+  if (corr_total && !ct_zero) {
+    double *st = (double *)stage_slot(h, sizeof(double) * h->n);
+    if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+    memcpy(st, corr_total, sizeof(double) * h->n);
+    HIPCHK(h, hipMemcpyAsync(h->d_ct, st, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
     dct = h->d_ct;
   }
-  UpdateSpec u = compressed_spec(h, dct, cov_update);
-  int rc = launch_update(h, u);
+  const bool async = h->async_pending;
+  h->async_pending = false;
+  int rc = XK_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (attempt == 1) {   // the single-launch CAQR of xk_build_compress_async gave up: rows, compression and update again
+      if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
+      if ((rc = cache_flags(h)) != XK_OK) return rc;
+      if ((rc = launch_compress(h)) != XK_OK) return rc;
+    }
+    UpdateSpec u = compressed_spec(h, dct, cov_update);
+    rc = launch_update(h, u);
+    if (rc != XK_OK) return rc;
+    // correction and status words in ONE copy (they are adjacent), one synchronisation
+    HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_corr, sizeof(double) * (h->n + 1), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int *stw = (const int *)(h->h_pin + h->n);
+    rc = eval_status(h, stw[0], stw[1], async && attempt == 0);
+    if (rc != XK_RETRY_CLASSIC) break;
+  }
   if (rc != XK_OK) return rc;
-  HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
-  rc = read_status(h);
-  if (rc != XK_OK) return rc;
+  memcpy(correction, h->h_pin, sizeof(double) * h->n);
   std::swap(h->d_P, h->d_Pout);  // posterior becomes the resident covariance
   h->have_rows = h->have_R = false;
   return XK_OK;
@@ -1457,21 +1575,25 @@ static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, cons
                       int qdim, int qoff) {
   const int n = h->n;
   HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpyAsync(h->d_csr_i, row_ptr, sizeof(int) * (n + 1), hipMemcpyHostToDevice, h->stream));
-  if (nnz) {
-    HIPCHK(h, hipMemcpyAsync(h->d_csr_i + n + 1, col_idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_csr_v, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
-  }
-  double *dq = nullptr;
-  if (q) {   // additive block, stored behind the values
-    dq = h->d_csr_v + h->csr_cap;
-    HIPCHK(h, hipMemcpyAsync(dq, q, sizeof(double) * (size_t)qdim * qdim, hipMemcpyHostToDevice, h->stream));
-  }
-  XkCongArgs a{h->d_P, h->d_Pout, n, h->d_csr_i, h->d_csr_i + n + 1, h->d_csr_v, dq, qdim, qoff};
+  // the operand goes through the pinned ring: nothing here waits for the device (a frame applies two or three of these
+  // back to back -- IMU steps, manage() -- before the update's one synchronisation)
+  const size_t vb = sizeof(double) * ((size_t)nnz + (q ? (size_t)qdim * qdim : 0)), ib = sizeof(int) * ((size_t)n + 1 + nnz);
+  char *st = stage_slot(h, vb + ib);
+  if (!st) return fail(h, XK_ECAPACITY, "sparse operand exceeds the staging slot");
+  double *sv = (double *)st;
+  int *si = (int *)(st + vb);
+  if (nnz) memcpy(sv, val, sizeof(double) * nnz);
+  if (q) memcpy(sv + nnz, q, sizeof(double) * (size_t)qdim * qdim);
+  memcpy(si, row_ptr, sizeof(int) * (n + 1));
+  if (nnz) memcpy(si + n + 1, col_idx, sizeof(int) * nnz);
+  // [values | additive block | row pointers | column indices] in one copy
+  HIPCHK(h, hipMemcpyAsync(h->d_csr_v, st, vb + ib, hipMemcpyHostToDevice, h->stream));
+  double *dq = q ? h->d_csr_v + nnz : nullptr;
+  const int *d_rp = (const int *)((const char *)h->d_csr_v + vb);
+  XkCongArgs a{h->d_P, h->d_Pout, n, d_rp, d_rp + n + 1, h->d_csr_v, dq, qdim, qoff};
   hipLaunchKernelGGL(xk_congruence, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "congruence launch", e);
-  HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller's buffers are free again
   std::swap(h->d_P, h->d_Pout);
   h->have_rows = h->have_R = false;
   return XK_OK;
@@ -1494,23 +1616,21 @@ extern "C" int xk_cov_congruence(xk_handle *h, const int *row_ptr, const int *co
 extern "C" int xk_cov_propagate(xk_handle *h, const double *f_d, int ldf, const double *q_d, int ldq) {
   if (!h || !f_d || !q_d || ldf < XK_CORE || ldq < XK_CORE) return XK_EINVAL;
   const int n = h->n;
-  std::vector<int> rp(n + 1), ci;
-  std::vector<double> v, q(XK_CORE * XK_CORE);
-  ci.reserve(XK_CORE * XK_CORE + n);
-  v.reserve(XK_CORE * XK_CORE + n);
-  for (int r = 0; r < n; ++r) {
-    rp[r] = (int)ci.size();
-    if (r < XK_CORE) {
-      for (int c = 0; c < XK_CORE; ++c) { ci.push_back(c); v.push_back(f_d[r + (size_t)c * ldf]); }
-    } else {
-      ci.push_back(r);
-      v.push_back(1.0);
-    }
-  }
-  rp[n] = (int)ci.size();
+  HIPCHK(h, hipSetDevice(h->device));
+  double *st = (double *)stage_slot(h, sizeof(double) * 450);
+  if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
   for (int c = 0; c < XK_CORE; ++c)
-    for (int r = 0; r < XK_CORE; ++r) q[r + XK_CORE * c] = q_d[r + (size_t)c * ldq];
-  return congruence(h, rp.data(), ci.data(), v.data(), (int)ci.size(), q.data(), XK_CORE, 0);
+    for (int r = 0; r < XK_CORE; ++r) {
+      st[r + XK_CORE * c] = f_d[r + (size_t)c * ldf];
+      st[225 + r + XK_CORE * c] = q_d[r + (size_t)c * ldq];
+    }
+  HIPCHK(h, hipMemcpyAsync(h->d_fq, st, sizeof(double) * 450, hipMemcpyHostToDevice, h->stream));
+  XkPropArgs a{h->d_P, n, h->d_fq};
+  hipLaunchKernelGGL(xk_cov_propagate_k, dim3(1 + (2 * (n - XK_CORE) + 255) / 256), dim3(256), 0, h->stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "propagate launch", e);
+  h->have_rows = h->have_R = false;
+  return XK_OK;
 }
 
 // ---------------------------------------------------------------------------

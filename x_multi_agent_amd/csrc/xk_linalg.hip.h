@@ -515,6 +515,60 @@ __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
   a.Pout[idx] = acc;
 }
 
+// Propagator::propagateCovarianceMatrices (propagator.cpp:166-205), IN PLACE on the resident covariance:
+//   P_ii <- F P_ii F^T + Q   (workgroup 0, through LDS)      P_iv <- F P_iv   (one thread per column)
+//   P_vi <- P_vi F^T, from the stored P_vi as the reference insists (one thread per row)      P_vv untouched.
+// Every output strip depends only on the same strip of the input, so nothing is read after it was overwritten.
+// (As a sparse congruence with J = blkdiag(F, I) the 225 core entries each walked 225 dependent loads: 39 us.)
+struct XkPropArgs {
+  double *P;
+  int n;
+  const double *FQ;   // f_d then q_d, 15 x 15 column-major each
+};
+__global__ __launch_bounds__(256) void xk_cov_propagate_k(XkPropArgs a) {
+  __shared__ double Fs[225], Ts[225];
+  const int t = threadIdx.x, n = a.n;
+  if (t < 225) Fs[t] = a.FQ[t];
+  if (blockIdx.x == 0) {
+    const int r = t % 15, c = t / 15;
+    __syncthreads();
+    if (t < 225) {
+      double acc = 0.0;
+      for (int k = 0; k < 15; ++k) acc = fma(Fs[r + 15 * k], a.P[k + (size_t)c * n], acc);     // (F P_ii)[r][c]
+      Ts[t] = acc;
+    }
+    __syncthreads();
+    if (t < 225) {
+      double acc = 0.0;
+      for (int k = 0; k < 15; ++k) acc = fma(Ts[r + 15 * k], Fs[c + 15 * k], acc);             // ((F P_ii) F^T)[r][c]
+      a.P[r + (size_t)c * n] = acc + a.FQ[225 + t];
+    }
+    return;
+  }
+  __syncthreads();
+  const int nv = n - 15, g = ((int)blockIdx.x - 1) * 256 + t;
+  if (g >= 2 * nv) return;
+  const int j = 15 + g % nv;
+  double in[15], out[15];
+  if (g < nv) {                                            // column j of P_iv
+    for (int k = 0; k < 15; ++k) in[k] = a.P[k + (size_t)j * n];
+    for (int r = 0; r < 15; ++r) {
+      double acc = 0.0;
+      for (int k = 0; k < 15; ++k) acc = fma(Fs[r + 15 * k], in[k], acc);
+      out[r] = acc;
+    }
+    for (int r = 0; r < 15; ++r) a.P[r + (size_t)j * n] = out[r];
+  } else {                                                 // row j of P_vi
+    for (int k = 0; k < 15; ++k) in[k] = a.P[j + (size_t)k * n];
+    for (int c = 0; c < 15; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 15; ++k) acc = fma(in[k], Fs[c + 15 * k], acc);
+      out[c] = acc;
+    }
+    for (int c = 0; c < 15; ++c) a.P[j + (size_t)c * n] = out[c];
+  }
+}
+
 // strided copy / scale helpers
 struct XkCopyArgs {
   const double *src;
