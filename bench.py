@@ -15,12 +15,19 @@ every 6 updates: binary-VLAD request, the responder's best keyframe back.
 value = (N * K updates) / max-over-ranks wall time.
 
 The JSON line also carries
-  roofline      fp64 compute roofline of the dominant stage (CAQR kernels),
-                timed with HIP events on the engine's stream
+  roofline      fp64 roofline of the dominant stage (CAQR kernels), timed with
+                HIP events on the engine's stream: achieved TFLOP/s from the rows
+                actually stacked, against the spec peak AND the ceiling measured
+                in this run; per-kernel fabric GB/s, MFMA-busy %, L2 hit % from
+                the PMC file of this round (refused if taken from other kernels)
+  frame_loop    whole filter frames through the C++ mirror of the reference API
+                (7 IMU steps, manage(), update, State::correct) with the
+                covariance resident on the device -- the drop-in's own rate
   cpu_baseline  the C restatement of the reference path (oracle/xk_oracle.c),
                 single thread, timed on this box's host cores (rank 0, N=1)
 """
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -33,6 +40,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
+ROUND_TAG = "r02"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
 CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
 CI_TRACKS = 2             # shared MSCKF tracks fused per CI round
 PR_SCORE_THR = 0.6        # pr_score_thr (vio.cpp:670): minimum VLAD similarity for a keyframe to be sent back
@@ -50,6 +58,62 @@ def alg_flops(N, K, M, rows=None):
     qr = 2.0 * r * c * c - (2.0 / 3.0) * c ** 3
     upd = 7.0 * n ** 3
     return feat, qr, upd
+
+
+def csrc_sha16():
+    """Hash of the kernel sources (the same one tools/summarize_prof.py stores next to the PMC numbers)."""
+    hh = hashlib.sha256()
+    d = os.path.join(HERE, "x_multi_agent_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            hh.update(open(os.path.join(d, f), "rb").read())
+    return hh.hexdigest()[:16]
+
+
+def pmc_of_this_round(config):
+    """Per-kernel counters of profiles/<round>[_cfgN]_pmc_traffic.json -- only if they were taken from THESE kernels."""
+    suf = "" if config in (4, 5) else f"_cfg{config}"
+    path = os.path.join(HERE, "profiles", f"{ROUND_TAG}{suf}_pmc_traffic.json")
+    if not os.path.exists(path):
+        print(f"bench.py: WARNING no {os.path.relpath(path, HERE)}: roofline.traffic / per_kernel are null", file=sys.stderr)
+        return None, "missing"
+    d = json.load(open(path))
+    if d.get("csrc_sha16") != csrc_sha16():
+        print(f"bench.py: WARNING {os.path.relpath(path, HERE)} was taken from other kernel sources "
+              f"({d.get('csrc_sha16')} != {csrc_sha16()}): STALE, not quoted; rerun tools/profile_round.sh", file=sys.stderr)
+        return None, "stale"
+    return d, "fresh"
+
+
+def frame_loop(sc, frames=200, imu_per_frame=7):
+    """Whole frames through the C++ mirror (host/examples/frame_loop_main.cpp), covariance resident on the device."""
+    import subprocess
+    import tempfile
+    pkg = os.path.join(HERE, "x_multi_agent_amd")
+    exe = os.path.join(pkg, "xk_frame_loop_example")
+    if not os.path.exists(exe) or len(sc.get("slam_anchor_idxs", [])):
+        return None
+    N = sc["n_poses_max"]
+    off = sc["trk_off"]
+    K = len(off) - 1
+    parts = [np.array([N, K, frames, imu_per_frame, 1, sc["sigma_img"]], float), sc["C_q_G"].ravel(), sc["G_p_C"].ravel(),
+             np.diff(off).astype(float), sc["obs_xy"].ravel(), np.asfortranarray(sc["P"]).ravel(order="F")]
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        np.concatenate(parts).astype("<f8").tofile(fin)
+        env = dict(os.environ, LD_LIBRARY_PATH=pkg + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, env=env, timeout=600)
+        if r.returncode != 0:
+            return {"error": (r.stdout + r.stderr)[-300:]}
+        out = np.fromfile(fout, dtype="<f8")
+    n = 15 + 6 * N
+    ms = out[n * n + 7 * N + 16:][min(20, frames // 4):]
+    return {"ms_per_frame": float(np.median(ms)), "frames_per_s": float(1e3 / np.median(ms)), "ms_mean": float(ms.mean()),
+            "ms_p95": float(np.percentile(ms, 95)), "frames": int(len(ms)), "imu_steps_per_frame": imu_per_frame,
+            "what": "Ekf::processImu x7 -> VioUpdater::setMeasurement -> Ekf::processUpdateMeasurement (covariance propagation, "
+                    "StateManager::manage, constructUpdate, applyUpdate, State::correct, postUpdate) through the C++ mirror of the "
+                    "reference API, covariance resident in HBM, wall clock per frame; the prior is restored by a device-side copy",
+            "log": r.stdout.strip()[-400:]}
 
 
 def cpu_baseline(sc, budget_s=20.0):
@@ -130,10 +194,11 @@ def cpu_baseline(sc, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)     # ~0.65 s of timed work at the headline size
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-frame-loop", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -266,24 +331,36 @@ def main():
     if rank == 0:
         # per-stage HIP-event timing of the same staged update (untimed region)
         tm = eng.bench_staged(sigma, 2, min(20, max(5, args.steps)))
-        f_feat, f_qr, f_upd = alg_flops(N, K, M)
+        rows = tm["rows_stacked"]                          # gated-out tracks leave zero rows: they do no algorithmic work
+        f_feat, f_qr, f_upd = alg_flops(N, K, M, rows=rows)
         f_alg = f_feat + f_qr + f_upd
         st = tm["stages"]
         qr_keys = [k for k in st if k.startswith("xk_caqr")]
         qr_ms = sum(st[k]["ms"] for k in qr_keys)
         dom = max(st.items(), key=lambda kv: kv[1]["ms"])
-        traffic = None
-        pmc = os.path.join(HERE, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("qr_bytes_per_update")
-            except Exception:
-                traffic = None
+        pmc, pmc_state = pmc_of_this_round(args.config)
+        try:
+            ceil_fma, ceil_mfma = eng.probe_fp64_peak(False), eng.probe_fp64_peak(True)
+        except Exception:
+            ceil_fma = ceil_mfma = None
         ach = f_qr / (qr_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_PEAK_TFLOPS, "traffic": traffic,
+        per_kernel = None
+        if pmc:
+            per_kernel = {k: {a: v for a, v in e.items() if a in ("avg_us", "l2_fabric_GBps", "mfma_util_pct", "wait_any_pct_of_wave_cycles", "l2_hit_pct")}
+                          for k, e in pmc["per_kernel"].items()}
+        roof = {"bound": "fp64-valu/latency",
+                "bound_note": "compute-side roofline (the compulsory HBM traffic of an update is < 1 MB); the QR kernels are Householder "
+                              "steps on the vector pipe -- fp64 vector and matrix peaks are the same 78.6 TFLOP/s on MI355X -- and what "
+                              "binds them is the dependent chain of reflector steps and launch boundaries, not flops or bytes",
+                "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+                "measured_ceiling": {"v_fma_f64": ceil_fma, "v_mfma_f64_16x16x4": ceil_mfma,
+                                     "frac_of_fma_ceiling": (ach / ceil_fma) if ceil_fma else None},
+                "traffic": pmc["qr_bytes_per_update"] if pmc else None,
+                "traffic_note": "bytes between the L2s and the fabric per update, QR kernels, PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE from "
+                                f"profiles/{ROUND_TAG}_pmc_traffic.json; Infinity-Cache hits are included (no counter separates them)",
+                "pmc_file": pmc_state, "per_kernel": per_kernel,
                 "kernel": "+".join(qr_keys) + " (Householder QR compression of the stacked [H|res])",
-                "alg_flops_per_update": f_qr, "stage_ms": qr_ms,
+                "alg_flops_per_update": f_qr, "rows_stacked": rows, "stage_ms": qr_ms,
                 "launches_per_update": sum(st[k]["launches"] for k in qr_keys),
                 "dominant_kernel_by_time": dom[0], "dominant_kernel_ms": dom[1]["ms"],
                 "dominant_kernel_launches": dom[1]["launches"],
@@ -292,6 +369,12 @@ def main():
                                  "frac": f_alg / (tm["total_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                 "stages_ms": {k: v["ms"] for k, v in st.items() if v["launches"]},
                 "dtype_peak_note": "fp64 dense peak, vector = matrix = 78.6 TFLOP/s (AMD public MI355X spec)"}
+        fl = None
+        if world == 1 and not args.no_frame_loop and args.config in (1, 3, 4):
+            eng.close()                       # the mirror creates its own handle
+            fl = frame_loop(sc)
+            if fl and "ms_per_frame" in fl:
+                fl["ratio_to_replay"] = fl["ms_per_frame"] / (1e3 * dt / args.steps)
         cpu = None
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(sc)
@@ -309,10 +392,13 @@ def main():
                           "ci_every": ci_every, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
                           "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"],
                           **({"keyframes_received_rank0": ci_stats.get("keyframes_received", 0)} if args.config == 5 else {})},
-               "roofline": roof, "cpu_baseline": cpu,
+               "roofline": roof, "frame_loop": fl, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
         print(json.dumps(out), flush=True)
-    eng.close()
+    try:
+        eng.close()
+    except Exception:
+        pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

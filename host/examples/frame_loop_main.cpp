@@ -87,7 +87,7 @@ int main(int argc, char **argv) {
     if (xk_upload_P(xk, P0.data(), n, n) != XK_OK || xk_snapshot_P(xk, 0) != XK_OK) { fprintf(stderr, "%s\n", xk_last_error(xk)); return 3; }
   }
   std::vector<double> ms(frames);
-  double t_imu = 0, t_set = 0, t_upd = 0;
+  double t_imu = 0, t_set = 0, t_upd = 0, prof[4] = {0, 0, 0, 0};
   std::optional<State> post;
   unsigned int seq = 0;
   for (int f = 0; f < frames; ++f) {
@@ -112,6 +112,7 @@ int main(int argc, char **argv) {
     t_imu += std::chrono::duration<double, std::milli>(ca - c0).count();
     t_set += std::chrono::duration<double, std::milli>(cb - ca).count();
     t_upd += std::chrono::duration<double, std::milli>(c1 - cb).count();
+    for (int i = 0; i < 4; ++i) prof[i] += updater.profileUs()[i];
     if (!post) { fprintf(stderr, "frame %d: no update applied\n", f); return 3; }
     ms[f] = std::chrono::duration<double, std::milli>(c1 - c0).count();
   }
@@ -127,7 +128,8 @@ int main(int argc, char **argv) {
   fclose(fo);
   int inl = 0;
   for (int v : updater.getMsckfInlierFlags()) inl += v;
-  printf("ok n=%d K=%d frames=%d imu_per_frame=%d mode=%d inliers=%d | per frame: imu %.4f ms, setMeasurement %.4f ms, update %.4f ms\n", n, K, frames,
-         imu_per_frame, mode, inl, t_imu / frames, t_set / frames, t_upd / frames);
+  printf("ok n=%d K=%d frames=%d imu_per_frame=%d mode=%d inliers=%d | per frame: imu %.4f ms, setMeasurement %.4f ms, update %.4f ms (host sections, us: manage %.1f construct %.1f apply %.1f post %.1f)\n",
+         n, K, frames, imu_per_frame, mode, inl, t_imu / frames, t_set / frames, t_upd / frames, prof[0] / frames, prof[1] / frames,
+         prof[2] / frames, prof[3] / frames);
   return 0;
 }

@@ -32,12 +32,16 @@ class Updater {
   void setResident(bool on) { resident_ = on; }
   bool resident() const { return resident_; }
   xk_handle *engine() const { return xk_; }
+  // host-side wall time of the last update() by section, microseconds (0 preUpdate/manage, 1 constructUpdate, 2 applyUpdate,
+  // 3 postUpdate); the device works asynchronously underneath, so the waiting lands in applyUpdate
+  const double *profileUs() const { return prof_us_; }
 
  protected:
   int iekf_iter_{1};
   bool multi_uav_{false};
   bool resident_{false};
   xk_handle *xk_{nullptr};                   // device engine (include/xk.h), owned by the concrete updater
+  double prof_us_[4] = {0, 0, 0, 0};
   bool compressed_on_device_{false};         // constructUpdate left [T_H|z] (and, unless CI ran, the prior) resident
 
   void applyUpdate(State &state, const Matrix &H, const Matrix &res, const Matrix &R, Matrix &correction_total,

@@ -2,6 +2,7 @@
 // through the C ABI (include/xk.h) into the HIP kernels.
 #include "x/ekf/updater.h"
 
+#include <chrono>
 #include <stdexcept>
 #include <string>
 
@@ -9,6 +10,9 @@
 
 using namespace x;
 
+static double usSince(std::chrono::steady_clock::time_point t0) {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
 static void check(xk_handle *h, int rc, const char *what) {
   if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + xk_last_error(h) + ")");
 }
@@ -40,7 +44,10 @@ void Updater::update(State &state) {                   // updater.cpp:39-115
       if (h.size() > 0) applyUpdate(state, h, res, r, correction, true);
     }
   }
+  auto t0 = std::chrono::steady_clock::now();
   const bool update_requested = preUpdate(state);
+  prof_us_[0] = usSince(t0);
+  prof_us_[1] = prof_us_[2] = prof_us_[3] = 0;
   if (update_requested) {
     correction = Matrix::Zero(state.nErrorStates(), 1);
     if (multi_uav_) {                                  // :84-97: CI entries first, then the regular update, no IEKF loop
@@ -51,11 +58,17 @@ void Updater::update(State &state) {                   // updater.cpp:39-115
     } else {
       for (int i = 0; i < iekf_iter_; i++) {
         const bool is_last_iter = i == iekf_iter_ - 1;
+        t0 = std::chrono::steady_clock::now();
         constructUpdate(state, h, res, r);
+        prof_us_[1] += usSince(t0);
+        t0 = std::chrono::steady_clock::now();
         if (h.size() > 0) applyUpdate(state, h, res, r, correction, is_last_iter);
+        prof_us_[2] += usSince(t0);
       }
     }
+    t0 = std::chrono::steady_clock::now();
     postUpdate(state, correction);
+    prof_us_[3] = usSince(t0);
   }
 }
 

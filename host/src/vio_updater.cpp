@@ -16,11 +16,11 @@ static void check(xk_handle *h, int rc, const char *what) {
 
 static void toCsr(const TrackList &tr, std::vector<int> &off, std::vector<double> &obs) {
   off.assign(tr.size() + 1, 0);
-  obs.clear();
-  for (size_t k = 0; k < tr.size(); ++k) {
-    off[k + 1] = off[k] + (int)tr[k].size();
-    for (const Feature &f : tr[k]) { obs.push_back(f.getX()); obs.push_back(f.getY()); }
-  }
+  for (size_t k = 0; k < tr.size(); ++k) off[k + 1] = off[k] + (int)tr[k].size();
+  obs.resize(2 * (size_t)off[tr.size()]);
+  double *o = obs.data();
+  for (const Track &t : tr)
+    for (const Feature &f : t) { *o++ = f.getX(); *o++ = f.getY(); }
 }
 
 VioUpdater::VioUpdater(int device, int n_poses_max, int n_feat_max, int k_max, double sigma_img, double sigma_landmark,

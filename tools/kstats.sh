@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/kstats.sh  -> per-kernel average durations of one bench run (rocprofv3 --kernel-trace --stats)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/ks; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -o k -- python bench.py --steps 20 --warmup 3 --no-cpu > gpurun_out/ks.log 2>&1
+rm -rf gpurun_out/ks; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -o k -- python bench.py --steps 20 --warmup 3 --no-cpu --no-frame-loop > gpurun_out/ks.log 2>&1
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("gpurun_out/ks/k_kernel_stats.csv")))

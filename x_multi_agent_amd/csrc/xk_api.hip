@@ -26,7 +26,7 @@ struct xk_handle {
   int device;
   hipStream_t stream;
   hipStream_t copy_stream;   // gate flags travel to the host beside the QR kernels, not between them
-  hipEvent_t ev_flags;
+  hipEvent_t ev_flags, ev_flags_done;
   hipEvent_t ev[16];
   // capacities
   int N, Mmax, Kmax, n, na, C1, C1P, DB, ntiles_max;
@@ -170,6 +170,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   HIPCHK(h, hipEventCreateWithFlags(&h->ev_flags, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_flags_done, hipEventDisableTiming));
   for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
   const size_t nn = (size_t)h->n * h->n;
   h->obs_cap = (size_t)k_max * n_poses_max;
@@ -301,6 +302,7 @@ extern "C" int xk_destroy(xk_handle *h) {
     if (e) hipEventDestroy(e);
   if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
   if (h->ev_flags) hipEventDestroy(h->ev_flags);
+  if (h->ev_flags_done) hipEventDestroy(h->ev_flags_done);
   if (h->stream) hipStreamDestroy(h->stream);
   free(h);
   return XK_OK;
@@ -984,6 +986,7 @@ static int cache_flags(xk_handle *h) {
     HIPCHK(h, hipMemcpyAsync(h->h_flag_i + h->Kmax, h->d_inl_s, sizeof(int) * h->M, hipMemcpyDeviceToHost, h->copy_stream));
     HIPCHK(h, hipMemcpyAsync(h->h_flag_d + h->Kmax, h->d_gam_s, sizeof(double) * h->M, hipMemcpyDeviceToHost, h->copy_stream));
   }
+  HIPCHK(h, hipEventRecord(h->ev_flags_done, h->copy_stream));
   h->flags_cached = true;
   return XK_OK;
 }
@@ -1005,8 +1008,10 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
 extern "C" int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
   if (!h) return XK_EINVAL;
   if (!h->flags_cached) return fail(h, XK_EINVAL, "xk_fetch_flags: no build since the inputs were staged");
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+  if (hipEventQuery(h->ev_flags_done) != hipSuccess) {   // (normally long done: the copies ran beside the QR kernels)
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventSynchronize(h->ev_flags_done));
+  }
   if (inlier_msckf && h->K > 0) memcpy(inlier_msckf, h->h_flag_i, sizeof(int) * h->K);
   if (gamma_msckf && h->K > 0) memcpy(gamma_msckf, h->h_flag_d, sizeof(double) * h->K);
   if (inlier_slam && h->M > 0) memcpy(inlier_slam, h->h_flag_i + h->Kmax, sizeof(int) * h->M);
