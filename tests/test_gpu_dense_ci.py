@@ -297,3 +297,53 @@ def test_device_ci_round_matches_host_abi_round(xk, world):
     assert fused_d == fused_h and fused_h >= 1
     assert corr.shape == (fused_d, 15 + 6 * N) and np.isfinite(corr).all()
     assert rel(P_d, P_h) <= 1e-9, rel(P_d, P_h)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_device_ci_round_full_size_against_the_oracle(xk, oracle_c, world):
+    """BASELINE configs 4 / 5 at their own size: xk_ci_round_device on n = 195 payloads (N = 30, K = 400) of 4 and 8
+    agents against the C oracle's msckf_ci_track + apply_ci (NOT against another product route): four shared tracks -- the
+    first one an outlier track of the scenario, the third corrupted on the own side, so both fail the single-agent gate
+    and give no entry -- entries applied in track order with every applyCI overwriting the covariance (Q6), corrections
+    compared entry by entry."""
+    import torch
+    from x_multi_agent_amd import fleet
+    cfg, n_tracks, w = 4, 4, 0.05
+    N, K, M = synth.CONFIGS[cfg]
+    scs = [fleet.shared_scenario(synth, cfg, r) for r in range(world)]
+    rank = 1
+    sc = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scs[rank].items()}
+    off = sc["trk_off"]
+    rng = np.random.default_rng(5)
+    sc["obs_xy"][off[2]:off[3]] += 0.05 * rng.standard_normal((off[3] - off[2], 2))      # track 2: own gate fails
+    scs[rank] = sc
+    dyn = np.zeros(16); dyn[9] = 1.0
+    pays = np.stack([fleet.pack_payload_host(r, 0.0, dyn, scs[r]["C_q_G"], scs[r]["G_p_C"], None, None, scs[r]["P"], N, M)
+                     for r in range(world)])
+    trks = np.stack([fleet.pack_tracks(scs[r], n_tracks, N).ravel() for r in range(world)])
+    eng = xk.Engine(N, M, K)
+    eng.stage(sc)
+    dp, dt = torch.from_numpy(pays).cuda(), torch.from_numpy(trks).cuda()
+    torch.cuda.synchronize()
+    fused, corr = fleet.ci_round_device(eng, sc, rank, world, dp, dt, n_tracks, w, want_corrections=True)
+    P_d = eng.download_P()
+    eng.close()
+    # oracle: the reference's loop
+    tr = [synth.tracks_as_list(s) for s in scs]
+    P_o, corr_o, gated = None, [], []
+    for j in range(n_tracks):
+        matches = [dict(obs=tr[r][j], q_list=scs[r]["C_q_G"], p_list=scs[r]["G_p_C"], P=scs[r]["P"], n_poses_max=N)
+                   for r in range(world) if r != rank]
+        o = oracle_c.msckf_ci_track(tr[rank][j], sc["C_q_G"], sc["G_p_C"], sc["P"], N, sc["sigma_img"], matches, w)
+        gated.append(o["ci"] is None)
+        if o["ci"] is not None:
+            c = o["ci"]
+            P_o, co = oracle_c.apply_ci(c["P_j"], c["H"], c["res"], c["S"])
+            corr_o.append(co)
+    assert gated == [True, False, True, False]             # outlier track, fused, corrupted track, fused
+    assert fused == len(corr_o) >= 2
+    assert rel(P_d, P_o) <= 1e-8, rel(P_d, P_o)
+    for a, b in zip(corr, corr_o):
+        assert rel(a, b) <= 1e-6
+    # Q6: the round's posterior is what the LAST entry alone gives from the prior, not a chain of updates
+    assert rel(P_d, sc["P"]) > 1e-3
