@@ -64,3 +64,18 @@ def test_splitmix_reference_values():
     # splitmix64 with seed 0: first outputs of the canonical generator
     r = synth.SplitMix(0)
     assert [hex(int(x)) for x in r.u64(3)] == ["0xe220a8397b1dcdaf", "0x6e789e6aa1b965f4", "0x6c45d188009454f"]
+
+
+def test_fleet_library_exports_its_header():
+    """libxk_fleet.so (RCCL exchange of the CI step) loads next to libxk.so and exports everything xk_fleet.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "xk_fleet.h")).read()
+    declared = sorted(set(re.findall(r"^\s*(?:const\s+)?(?:int|long|void|char)\s*\*?\s*(xk_fleet_[a-z_A-Z0-9]+)\s*\(", hdr, flags=re.M)))
+    assert len(declared) == 9
+    engine.lib()
+    path = os.path.join(ROOT, "x_multi_agent_amd", "libxk_fleet.so")
+    if not os.path.exists(path):
+        from x_multi_agent_amd import build
+        build.build_fleet(verbose=False)
+    F = C.CDLL(path)
+    assert not [s for s in declared if not hasattr(F, s)]
+    assert F.xk_fleet_create(None, None, 1, 0, None) == 1 and F.xk_fleet_all_gather(None, None, None, 0) == 1    # XK_EINVAL

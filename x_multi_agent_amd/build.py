@@ -11,7 +11,7 @@ SRC = os.path.join(HERE, "csrc", "xk_api.hip")
 OUT = os.path.join(HERE, "libxk.so")
 # every file xk_api.hip includes: a stale libxk.so after editing any of them would silently test old kernels
 DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))
-              if f.endswith((".hip", ".h"))) + [os.path.join(HERE, "..", "include", "xk.h")]
+              if f.endswith((".hip", ".h"))) + [os.path.join(HERE, "..", "include", "xk.h")]   # (xk_fleet.cpp: build_fleet)
 
 
 def build(force=False, verbose=True):
@@ -24,6 +24,18 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return OUT
+
+
+def build_fleet(verbose=True):
+    """libxk_fleet.so: the RCCL exchange of the CI step (include/xk_fleet.h), host code over libxk.so + librccl.so."""
+    out = os.path.join(HERE, "libxk_fleet.so")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-o", out, os.path.join(HERE, "csrc", "xk_fleet.cpp"),
+           "-L" + HERE, "-lxk", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
 
 
 def build_host(force=False, verbose=True):
@@ -53,4 +65,5 @@ def build_host(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_fleet()
     build_host()
