@@ -39,8 +39,9 @@ def test_apply_update_dense_matches_reference_form(xk, oracle_c, sc):
 
 
 def test_kalman_stage_across_measurement_counts(xk):
-    """The Cholesky of S runs in one launch up to 192 rows (xk_chol_whole) and one launch per 32-row block step
-    above; both against the closed form, at block boundaries and at ragged sizes, plus the not-positive-definite exit."""
+    """The Cholesky of S runs in one launch up to 192 rows (xk_chol_whole) and in 192-row slabs with a Schur-complement
+    GEMM between them above (test_kalman_stage_wide_systems); against the closed form, at block boundaries and at ragged
+    sizes, plus the not-positive-definite exit."""
     rng = np.random.default_rng(17)
     eng = xk.Engine(30, 0, 4)
     n = eng.n                                               # 195
@@ -71,6 +72,37 @@ def test_kalman_stage_across_measurement_counts(xk):
         # the handle stays usable afterwards
         Pg, _, _ = eng.apply_update_dense(P, H, np.zeros(m), np.full(m, 1e-3))
         assert np.isfinite(Pg).all()
+    eng.close()
+
+
+def test_kalman_stage_wide_systems(xk):
+    """More than 192 measurement rows (BASELINE configs 2 and 3: c = 331 / 301): two and three slabs, slab boundaries,
+    ragged tails; and the indefinite exit when the bad pivot sits in the second slab."""
+    rng = np.random.default_rng(23)
+    eng = xk.Engine(64, 10, 4)
+    n = eng.n                                               # 429
+    B = rng.standard_normal((n, n)) * 0.2
+    P = B @ B.T + 1e-3 * np.eye(n)
+    for m in (193, 208, 301, 331, 384, 385, 400, 430):
+        H = rng.standard_normal((m, n)) * 0.3
+        r = rng.standard_normal(m) * 1e-2
+        R = 10.0 ** rng.uniform(-5, -1, size=m)
+        Pg, cg, _ = eng.apply_update_dense(P, H, r, R)
+        S = H @ P @ H.T + np.diag(R)
+        K = np.linalg.solve(S, H @ P).T
+        Po = P - K @ H @ P
+        Po = 0.5 * (Po + Po.T)
+        assert rel(Pg, Po) <= 1e-9, m
+        assert rel(cg, K @ r) <= 1e-8, m
+    # S = H P H^T + R with P negative along e_250 only: indefinite, but its leading 192 x 192 block (first slab) is fine
+    Pd = np.eye(n)
+    Pd[250, 250] = -5.0
+    H = np.eye(300, n)
+    with pytest.raises(xk.XkError) as e:
+        eng.apply_update_dense(Pd, H, np.zeros(300), np.full(300, 1e-3))
+    assert e.value.status == 2
+    Pg, _, _ = eng.apply_update_dense(np.eye(n), H, np.zeros(300), np.full(300, 1e-3))
+    assert np.isfinite(Pg).all()
     eng.close()
 
 

@@ -855,12 +855,34 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
   // blocked Cholesky with the right-hand sides carried along: one launch per 32-column block step
   const int ncols = c + n + 1;
   static const int whole_env = env_int("XK_CHOL_WHOLE", 1);
-  if (whole_env && c <= 16 * XK_CHOLW_MAXB) {
-    // small systems: every block step inside one launch, one workgroup per 16 right-hand-side columns
-    XkCholWholeArgs d;
-    d.Maug = h->d_Maug; d.ld = LDA; d.c = c; d.ncols = ncols; d.X = h->d_X; d.status = h->d_status;
-    xk_cholw_table((c + 15) / 16, d.tab);
-    hipLaunchKernelGGL(xk_chol_whole, dim3((n + 1 + 15) / 16), dim3(64 * XK_CHOLW_WAVES), 0, h->stream, d);
+  static const int split_env = env_int("XK_CHOL_SPLIT", 1);
+  if (whole_env && (c <= 16 * XK_CHOLW_MAXB || split_env)) {
+    // Every block step inside one launch (xk_chol_whole), one workgroup per 16 right-hand-side columns.  Systems with
+    // more than 192 rows (BASELINE configs 2 and 3: c = 331 / 301) are cut into 192-row slabs:
+    //   X[0:b, b:]  = L_11^-1 [S_12 | W_1 | z_1]        xk_chol_whole on the slab, the rest of ITS ROWS as right-hand sides
+    //   M[b:, b:]  -= X[0:b, b:c]^T X[0:b, b:]           one fp64-MFMA GEMM (Schur complement of S and of the right-hand sides)
+    // and the remainder is the same problem again: 2 slabs = 3 launches instead of 11 block-step launches.
+    const int B = 16 * XK_CHOLW_MAXB;
+    for (int off = 0; off < c;) {
+      const int cb = std::min(B, c - off);
+      XkCholWholeArgs d;
+      d.Maug = h->d_Maug + (size_t)off * LDA + off; d.ld = LDA; d.c = cb; d.ncols = ncols - off;
+      d.X = h->d_X + (size_t)off * LDA + off; d.status = h->d_status;
+      xk_cholw_table((cb + 15) / 16, d.tab);
+      hipLaunchKernelGGL(xk_chol_whole, dim3((ncols - off - cb + 15) / 16), dim3(64 * XK_CHOLW_WAVES), 0, h->stream, d);
+      off += cb;
+      if (off < c) {
+        XkGemmArgs s;
+        memset(&s, 0, sizeof(s));
+        const double *Xs = h->d_X + (size_t)(off - cb) * LDA + off;       // X[slab rows, off:]
+        s.A = Xs; s.sar = 1; s.sac = LDA;                                   // A[i][k] = X[k][off + i]
+        s.B = Xs; s.sbr = LDA; s.sbc = 1;                                   // B[k][j] = X[k][off + j]
+        s.C = h->d_Maug + (size_t)off * LDA + off; s.scr = LDA; s.scc = 1;
+        s.D = s.C; s.sdr = LDA; s.sdc = 1;
+        s.M = c - off; s.N = ncols - off; s.K = cb; s.alpha = -1.0; s.beta = 1.0; s.mode = 0;
+        gemm(h, s);
+      }
+    }
   } else
   for (int kb = 0; kb < c; kb += XK_CHOL_NB) {
     const int nb = std::min(XK_CHOL_NB, c - kb);
