@@ -1,0 +1,67 @@
+"""The register-resident single-launch QR compression (csrc/xk_caqr_resident.hip.h, the default whenever the stack is
+MSCKF rows only and fits 248 fat tiles of 96 rows) against the multi-launch CAQR schedule on the same inputs -- same R up
+to rounding, hence the same posterior -- over shapes that stress its bookkeeping: ragged tracks (fat tiles cut tracks at
+arbitrary rows), many rejected tracks (zero rows inside fat tiles), few rows (most fat tiles short or empty), the
+headline size (tiles full), a partially filled window; and against the C oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import rel
+from x_multi_agent_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(xk, sc, resident):
+    os.environ["XK_CAQR_RESIDENT"] = "1" if resident else "0"
+    try:
+        N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+        eng = xk.Engine(N, 0, K)
+        eng.stage(sc)
+        r = eng.visual_update_staged(sc["sigma_img"])
+        P = eng.download_P()
+        eng.stage(sc)
+        t = eng.bench_staged(sc["sigma_img"], 0, 1)
+        eng.close()
+        return r, P, t
+    finally:
+        os.environ.pop("XK_CAQR_RESIDENT", None)
+
+
+CASES = {
+    "headline": lambda: synth.make_config(4),
+    "cfg1": lambda: synth.make_config(1),
+    "ragged": lambda: synth.make_scenario(30, 300, 0, seed=901, track_len=(2, 30)),
+    "mostly_rejected": lambda: synth.make_scenario(20, 200, 0, seed=902, outlier_frac=0.7),
+    "partial_window": lambda: synth.make_scenario(30, 120, 0, seed=903, n_poses=17),
+    "just_enough_rows": lambda: synth.make_scenario(12, 26, 0, seed=904),       # 546 rows: 3 rows per fat tile
+    "stress_prior": lambda: synth.make_scenario(24, 350, 0, seed=905, prior_kind="stress", prior_scale=0.01),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_resident_equals_multi_launch(xk, oracle_c, name):
+    sc = CASES[name]()
+    ra, Pa, ta = _run(xk, sc, True)
+    rb, Pb, tb = _run(xk, sc, False)
+    assert ta["n_levels"] == 1 and ta["n_leaf"] == 248, "the resident path did not run"
+    assert tb["n_levels"] > 1
+    assert np.array_equal(ra["inlier"], rb["inlier"])
+    assert rel(Pa, Pb) <= 1e-11 and rel(ra["correction"], rb["correction"]) <= 1e-9
+    ref = oracle_c.visual_update(sc)
+    assert np.array_equal(ra["inlier"], ref["inlier"])
+    assert rel(Pa, ref["P"]) <= 1e-8
+
+
+def test_resident_path_steps_aside_when_it_does_not_apply(xk):
+    """SLAM rows, too many rows for 248 x 96, or too few rows: the multi-launch schedule runs (and nothing breaks)."""
+    for sc in (synth.make_config(2), synth.make_scenario(40, 420, 0, seed=906), synth.make_scenario(8, 10, 0, seed=907)):
+        N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+        M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+        eng = xk.Engine(N, M, K)
+        eng.stage(sc)
+        t = eng.bench_staged(sc["sigma_img"], 0, 1)
+        assert t["n_leaf"] != 248
+        eng.close()

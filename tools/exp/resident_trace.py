@@ -1,0 +1,36 @@
+"""The register-resident single-launch CAQR (XK_CAQR_RESIDENT=1) at a given config: parity against the multi-launch
+schedule, stage times, per-panel phase spans of one tile workgroup (XK_CAQR_PERSIST_DBG=1)."""
+import ctypes as C, os, sys, subprocess
+sys.path.insert(0, '.')
+os.environ.setdefault("XK_CAQR_PERSIST_DBG", "1")
+import numpy as np
+from x_multi_agent_amd import engine, synth
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+sc = synth.make_config(cfg)
+N = sc["n_poses_max"]; K = len(sc["trk_off"]) - 1
+eng = engine.Engine(N, 0, K)
+got = eng.visual_update(sc)
+t = eng.bench_staged(sc["sigma_img"], 3, 20)
+mode = "resident" if os.environ.get("XK_CAQR_RESIDENT") == "1" else "multi-launch"
+print(mode + ":", {k: round(v["ms"], 4) for k, v in t["stages"].items() if v["ms"] > 0}, "total", round(t["total_ms"], 4), "launches", t["n_levels"])
+if mode == "resident":
+    NW = 512
+    out = (C.c_longlong * NW)()
+    eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
+    allw = np.array(list(out), dtype=np.int64)
+    w = allw[:256].reshape(32, 8)
+    w2 = allw[256:512].reshape(32, 8)
+    npan = (6 * N + 1 + 15) // 16
+    t0 = w[0, 0]
+    print("panel: tile  bar1  wait  merge bar2+reload | cum us | last-level: start(after tile start) span")
+    for k in range(npan):
+        r = w[k]
+        print(f"{k:3d}  {(r[1]-r[0])/100:5.2f} {(r[2]-r[1])/100:5.2f} {(r[3]-r[2])/100:5.2f} {(r[4]-r[3])/100:5.2f} {(r[5]-r[4])/100:5.2f} | {(r[5]-t0)/100:7.2f} | {(r[6]-r[0])/100:6.2f} {(r[7]-r[6])/100:6.2f} | steps only {(w2[k,1]-w2[k,0])/100:5.2f} | merge: load {(w2[k,2]-r[3])/100:5.2f} steps {(w2[k,3]-w2[k,2])/100:5.2f} ({(w2[k,5]-w2[k,4])/max(1,(w2[k,3]-w2[k,2]))/10:.2f} GHz) rest {(r[4]-w2[k,3])/100:5.2f}")
+    np.save("/tmp/res_P.npy", got["P"]); np.save("/tmp/res_c.npy", got["correction"])
+    eng.close()
+    env = dict(os.environ, XK_CAQR_RESIDENT="0")
+    print(subprocess.run([sys.executable, __file__, str(cfg)], env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+else:
+    P = np.load("/tmp/res_P.npy"); c = np.load("/tmp/res_c.npy")
+    print(f"resident vs multi-launch: rel dP {np.linalg.norm(P-got['P'])/np.linalg.norm(got['P']):.2e} rel dcorr {np.linalg.norm(c-got['correction'])/np.linalg.norm(got['correction']):.2e}")

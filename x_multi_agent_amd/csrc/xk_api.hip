@@ -17,6 +17,7 @@
 #include "xk_slaminit.hip.h"
 #include "xk_linalg.hip.h"
 #include "xk_caqr_persist.hip.h"
+#include "xk_caqr_resident.hip.h"
 #include "xk_ci.hip.h"
 
 #define XK_VERSION_NUM 200
@@ -48,6 +49,11 @@ struct xk_handle {
   int nleaf, nlevels;   // of the last compression
   // single-launch CAQR (xk_caqr_persist.hip.h): cross-XCD exchange slabs and the sync words
   double *d_x1, *d_x1p, *d_x2;
+  // register-resident single-launch CAQR (xk_caqr_resident.hip.h)
+  double *d_rs, *d_rpb, *d_rhq;
+  int *d_rowmap;
+  int rowmap_R;            // valid rows the device row map describes (-1: stale)
+  std::vector<int> *h_rowlens;   // track lengths the row map was built for
   unsigned *d_psync;
   long long *d_pdbg;
   long long *feat_dbg;  // probe builds only: per-workgroup phase stamps of xk_msckf_feature
@@ -213,6 +219,12 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
       HIPCHK(h, dalloc(&h->d_psync, (size_t)XK_PS_WORDS * 16));
+      HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_RES_NT * 16 * h->C1P));
+      HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_RES_NT * 256));
+      HIPCHK(h, dalloc(&h->d_rhq, (size_t)XK_PERSIST_MAXG * 16 * h->C1P));
+      HIPCHK(h, dalloc(&h->d_rowmap, (size_t)8 * XK_RES_NT * 4 * XK_RES_RPL));
+      h->rowmap_R = -1;
+      h->h_rowlens = new std::vector<int>();
       HIPCHK(h, dalloc(&h->d_pdbg, (size_t)256 + 64 * 256));
       HIPCHK(h, hipMemset(h->d_pdbg, 0, sizeof(long long) * (256 + 64 * 256)));
     }
@@ -284,6 +296,9 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_fq) hipFree(h->d_fq);
+  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rhq, (void *)h->d_rowmap})
+    if (p4) hipFree(p4);
+  delete h->h_rowlens;
   for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
     if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
@@ -659,6 +674,44 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   const bool overlap = overlap_env && (arity1 == 20 || arity1 == 40) && groups1 >= 2 && groups1 <= 20;
   a.hole_stride = 0; a.lead_off = 0; a.lead_all = 0; a.pend = 0;
   int launches = 0;
+  // register-resident single launch (xk_caqr_resident.hip.h): MSCKF tracks only, valid rows <= 248 fat tiles of 96
+  const int resident_env = env_int("XK_CAQR_RESIDENT", 1);   // (read per call: tests switch it inside one process)
+  if (resident_env && h->persist_ok && h->M == 0 && h->K2 == 0 && h->K > 0) {
+    // row map: valid row g -> physical row of the 64-row slots (depends on the track lengths only)
+    bool same = h->rowmap_R >= 0 && (int)h->h_rowlens->size() == h->K;
+    for (int k = 0; same && k < h->K; ++k) same = (*h->h_rowlens)[k] == h->h_trk_off[k + 1] - h->h_trk_off[k];
+    int R = h->rowmap_R;
+    if (!same) {
+      h->h_rowlens->resize(h->K);
+      R = 0;
+      for (int k = 0; k < h->K; ++k) { (*h->h_rowlens)[k] = h->h_trk_off[k + 1] - h->h_trk_off[k]; R += 2 * (*h->h_rowlens)[k] - 3; }
+      h->rowmap_R = -1;
+      if (R <= 8 * XK_RES_NT * 4 * XK_RES_RPL && (size_t)R * sizeof(int) <= h->stage_bytes) {
+        int *st = (int *)stage_slot(h, sizeof(int) * (size_t)R);
+        int g = 0;
+        for (int k = 0; k < h->K; ++k)
+          for (int i = 0; i < 2 * (*h->h_rowlens)[k] - 3; ++i) st[g++] = k * 64 + i;
+        if (hipMemcpyAsync(h->d_rowmap, st, sizeof(int) * (size_t)R, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "row map");
+        h->rowmap_R = R;
+      }
+    }
+    const int NTL = 8 * XK_RES_NT;
+    if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTL - 1) / NTL <= 4 * XK_RES_RPL) {
+      XkCaqrResidentArgs ra;
+      ra.A = h->d_A; ra.tile_rows = h->d_tile_rows; ra.rowmap = h->d_rowmap; ra.R = h->rowmap_R; ra.TR = (h->rowmap_R + NTL - 1) / NTL;
+      ra.C1P = h->C1P; ra.C1 = h->C1; ra.Rout = h->d_R; ra.S = h->d_rs; ra.PB1 = h->d_rpb; ra.Hq = h->d_rhq;
+      ra.X1 = h->d_x1; ra.X1P = h->d_x1p; ra.X2 = h->d_x2; ra.sync = h->d_psync; ra.status = h->d_status;
+      static const int rdbg = env_int("XK_CAQR_PERSIST_DBG", 0);
+      ra.dbg = rdbg ? h->d_pdbg : nullptr;
+      if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * XK_PS_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
+      hipLaunchKernelGGL(xk_caqr_resident, dim3(h->n_cu), dim3(XK_RES_THREADS), 0, h->stream, ra);
+      if (mid) hipEventRecord(mid, h->stream);
+      h->nleaf = NTL; h->nlevels = 1; h->have_R = true;
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
+      return XK_OK;
+    }
+  }
   // single-launch schedule (xk_caqr_persist.hip.h): every workgroup of the grid must be resident at once (2 per CU)
   static const int persist_env = env_int("XK_CAQR_PERSIST", 0);
   static const int persist_min = env_int("XK_CAQR_PERSIST_MIN", 64);
