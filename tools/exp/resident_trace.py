@@ -12,21 +12,22 @@ N = sc["n_poses_max"]; K = len(sc["trk_off"]) - 1
 eng = engine.Engine(N, 0, K)
 got = eng.visual_update(sc)
 t = eng.bench_staged(sc["sigma_img"], 3, 20)
-mode = "resident" if os.environ.get("XK_CAQR_RESIDENT") == "1" else "multi-launch"
+mode = "multi-launch" if os.environ.get("XK_CAQR_RESIDENT") == "0" else ("resident+blocked" if os.environ.get("XK_CAQR_BLOCKED") == "1" else "resident")
 print(mode + ":", {k: round(v["ms"], 4) for k, v in t["stages"].items() if v["ms"] > 0}, "total", round(t["total_ms"], 4), "launches", t["n_levels"])
-if mode == "resident":
-    NW = 512
+if mode != "multi-launch":
+    NW = 768
     out = (C.c_longlong * NW)()
     eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
     allw = np.array(list(out), dtype=np.int64)
     w = allw[:256].reshape(32, 8)
     w2 = allw[256:512].reshape(32, 8)
+    w3 = allw[512:768].reshape(32, 8)
     npan = (6 * N + 1 + 15) // 16
     t0 = w[0, 0]
     print("panel: tile  bar1  wait  merge bar2+reload | cum us | last-level: start(after tile start) span")
     for k in range(npan):
         r = w[k]
-        print(f"{k:3d}  {(r[1]-r[0])/100:5.2f} {(r[2]-r[1])/100:5.2f} {(r[3]-r[2])/100:5.2f} {(r[4]-r[3])/100:5.2f} {(r[5]-r[4])/100:5.2f} | {(r[5]-t0)/100:7.2f} | {(r[6]-r[0])/100:6.2f} {(r[7]-r[6])/100:6.2f} | steps only {(w2[k,1]-w2[k,0])/100:5.2f} | merge: load {(w2[k,2]-r[3])/100:5.2f} steps {(w2[k,3]-w2[k,2])/100:5.2f} ({(w2[k,5]-w2[k,4])/max(1,(w2[k,3]-w2[k,2]))/10:.2f} GHz) rest {(r[4]-w2[k,3])/100:5.2f}")
+        print(f"{k:3d}  {(r[1]-r[0])/100:5.2f} {(r[2]-r[1])/100:5.2f} {(r[3]-r[2])/100:5.2f} {(r[4]-r[3])/100:5.2f} {(r[5]-r[4])/100:5.2f} | {(r[5]-t0)/100:7.2f} | {(r[6]-r[0])/100:6.2f} {(r[7]-r[6])/100:6.2f} | steps only {(w2[k,1]-w2[k,0])/100:5.2f} | merge: load {(w2[k,2]-r[3])/100:5.2f} steps {(w2[k,3]-w2[k,2])/100:5.2f} ({(w2[k,5]-w2[k,4])/max(1,(w2[k,3]-w2[k,2]))/10:.2f} GHz) rest {(r[4]-w2[k,3])/100:5.2f}" + (f" | panel wave: steps {(w3[k,0]-w2[k,0])/100:5.2f} V+G {(w3[k,1]-w3[k,0])/100:5.2f} Tinv {(w3[k,2]-w3[k,1])/100:5.2f}" if w3[k,0] else ""))
     np.save("/tmp/res_P.npy", got["P"]); np.save("/tmp/res_c.npy", got["correction"])
     eng.close()
     env = dict(os.environ, XK_CAQR_RESIDENT="0")

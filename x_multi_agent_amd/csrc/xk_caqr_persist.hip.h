@@ -41,7 +41,9 @@ enum {
   XK_PS_L2CNT = 32 + XK_PERSIST_MAXP,   // [MAXP] last-level items of panel k that have published
   XK_PS_X1FLAG = 32 + 2 * XK_PERSIST_MAXP,   // [MAXP] set by the item that completes X1CNT[k]: the word the last level polls
   XK_PS_L2FLAG = 32 + 3 * XK_PERSIST_MAXP,   // [MAXP] likewise for L2CNT[k]: the word the next first-level merges poll
-  XK_PS_WORDS = 32 + 4 * XK_PERSIST_MAXP
+  XK_PS_GBARCNT = 32 + 4 * XK_PERSIST_MAXP,          // [MAXG] per first-level group: barrier arrivals / generation (xk_caqr_resident)
+  XK_PS_GBARGEN = 32 + 4 * XK_PERSIST_MAXP + XK_PERSIST_MAXG,
+  XK_PS_WORDS = 32 + 4 * XK_PERSIST_MAXP + 2 * XK_PERSIST_MAXG
 };
 
 // count `add` items in; whoever completes the count raises the flag the consumers poll (a counter that is polled by a
@@ -99,11 +101,12 @@ __device__ __forceinline__ bool xk_spin_ge(unsigned *p, unsigned target, unsigne
 // XCD's L2 once vmcnt reaches 0); the last arriver publishes the generation, the others poll THAT word, so the
 // arrival counter is not hammered by readers (1.4 us against 5.7 us with 64 workgroups polling the counter itself
 // while data moves, xcd_sync_probe).
-__device__ __forceinline__ bool xk_xcd_barrier(unsigned *sync, unsigned xcc, unsigned n, unsigned epoch, unsigned *s_ok) {
+// (cnt_base / gen_base: XK_PS_BARCNT / XK_PS_BARGEN with idx = XCD, or XK_PS_GBARCNT / XK_PS_GBARGEN with idx = group)
+__device__ __forceinline__ bool xk_flag_barrier(unsigned *sync, int cnt_base, int gen_base, unsigned idx, unsigned n, unsigned epoch, unsigned *s_ok) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned *cnt = sync + (XK_PS_BARCNT + xcc) * 16, *gen = sync + (XK_PS_BARGEN + xcc) * 16, *ab = sync + XK_PS_ABORT * 16;
+    unsigned *cnt = sync + (cnt_base + idx) * 16, *gen = sync + (gen_base + idx) * 16, *ab = sync + XK_PS_ABORT * 16;
     const unsigned old = __hip_atomic_fetch_add(cnt, 1u, XK_RLX_AGENT);
     bool ok = true;
     if (old == n * epoch - 1) __hip_atomic_store(gen, epoch, XK_RLX_AGENT);
@@ -112,6 +115,9 @@ __device__ __forceinline__ bool xk_xcd_barrier(unsigned *sync, unsigned xcc, uns
   }
   __syncthreads();
   return *s_ok != 0u;
+}
+__device__ __forceinline__ bool xk_xcd_barrier(unsigned *sync, unsigned xcc, unsigned n, unsigned epoch, unsigned *s_ok) {
+  return xk_flag_barrier(sync, XK_PS_BARCNT, XK_PS_BARGEN, xcc, n, epoch, s_ok);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

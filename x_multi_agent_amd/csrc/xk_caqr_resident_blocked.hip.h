@@ -1,3 +1,10 @@
+// xk_caqr_resident_blocked.hip.h -- EXPERIMENT (not part of libxk.so unless built with -DXK_CAQR_BLOCKED_EXPERIMENT):
+// the register-resident kernel with the blocked tile step of xk_caqr_blocked.hip.h selected by a template flag.
+// Measured on MI355X (tools/exp/qr_variants.sh, same box): QR 0.504 ms blocked vs 0.476 ms reflector-by-reflector --
+// the single panel wave's 16-step DPP chain (7.7 us) plus Gram matrix and T (1.4 + 6 us with a back substitution that
+// waits for one LDS read per term) is longer than the 16 LDS-broadcast steps it replaces, and merely having both variants
+// in one templated kernel made the plain one 18 % slower (0.566 ms).  Kept for the record and for the next attempt
+// (block forward substitution on the matrix cores instead of T^-1).
 // xk_caqr_resident.hip.h -- QR compression (VioUpdater::applyQRDecomposition, src/x/vio/vio_updater.cpp:487-512) in ONE
 // launch with the row stack RESIDENT IN REGISTERS for the whole factorisation.
 //
@@ -22,8 +29,15 @@
 //     "away" half until the returned rows are loaded into it.
 // Synchronisation, placement census, bounded spins and the cross-XCD slabs are those of xk_caqr_persist.hip.h.
 #pragma once
+#define xk_caqr_resident xk_caqr_resident_blk
+#define xk_resident_merge1 xk_resident_merge1_blk
+#define xk_resident_last xk_resident_last_blk
+#define XkCaqrResidentArgs XkCaqrResidentBlkArgs
+#define XkResidentArgsPtr XkResidentBlkArgsPtr
+#define xk_resident_args xk_resident_blk_args
 #include <hip/hip_runtime.h>
 
+#include "xk_caqr_blocked.hip.h"
 #include "xk_caqr_persist.hip.h"
 
 #define XK_RES_THREADS 768          // 12 waves, one workgroup per CU: up to 168 VGPRs (a 1024-thread version spilled 271)
@@ -135,12 +149,16 @@ __device__ __noinline__ void xk_resident_last(XkResidentArgsPtr ap, int k, int s
   }
 }
 
+// BLK = false: the reflector-by-reflector tile step of xk_linalg.hip.h (rows blocked over the 4 lanes of a column);
+// BLK = true:  the blocked step of xk_caqr_blocked.hip.h (rows interleaved, lane = part * 16 + column within the wave).
+template <bool BLK>
 __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResidentArgs a) {
   constexpr int RPL = XK_RES_RPL, NT = XK_RES_NT, RM1 = 18, A1 = 16, G = 2;
   constexpr int LDS_T = 2 * 4 * (RPL + 2), LDS_M = 2 * 16 * (RM1 + 2), LDS_L = 2 * 16 * 18;
   constexpr int LDS_MAX = LDS_T > LDS_M ? (LDS_T > LDS_L ? LDS_T : LDS_L) : (LDS_M > LDS_L ? LDS_M : LDS_L);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  __shared__ __attribute__((aligned(16))) double blds[BLK ? XK_BLK_LDS : 2];
   __shared__ unsigned s_slot, s_nx, s_ok;
   unsigned *sync = a.sync, *ab = sync + XK_PS_ABORT * 16;
   const XkResidentArgsPtr ap = (XkResidentArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -167,8 +185,11 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
   if (slot < NT) {
     // ---- role T: one fat tile in registers + a share of the XCD's first-level merges
     const int j = (int)xcc * NT + slot;                      // my fat tile: valid rows [j TR, (j + 1) TR)
-    const int cidx = tid >> 2, part = tid & 3;               // tile layout: 4 lanes per column (threads < 768)
-    const bool tlane = true;                                 // (768 threads = 192 columns x 4 lanes)
+    // tile layout: 4 lanes per column, 768 threads = 192 columns; wave w holds columns 16 w .. 16 w + 15 either way
+    const int wv = tid >> 6, lane = tid & 63;
+    const int part = BLK ? lane >> 4 : tid & 3;
+    const int cidx = BLK ? 16 * wv + (lane & 15) : tid >> 2;
+    const bool tlane = true;
     const int cabs = cidx;                                   // ABSOLUTE column of this thread, all panels
     const bool mine = tlane && cabs < a.C1;
     const bool leader = (slot % A1) == 0;
@@ -177,10 +198,10 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
     const bool stamp = a.dbg && xcc == 0 && slot == 1 && tid == 0;
     double b[RPL];
     {   // the one pass over the stack: gather my rows through the row map
-      const int g0 = j * a.TR + part * RPL, gend = min((j + 1) * a.TR, a.R);
+      const int g0 = j * a.TR + (BLK ? part : part * RPL), gend = min((j + 1) * a.TR, a.R);
 #pragma unroll
       for (int r = 0; r < RPL; ++r) {
-        const int g = g0 + r;
+        const int g = g0 + (BLK ? 4 * r : r);                // register r = row 4 r + part (blocked) / 24 part + r
         double v = 0.0;
         if (mine && g < gend) {
           const int pr = a.rowmap[g];
@@ -194,6 +215,27 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       const int c0 = 16 * k, trail = max(0, a.C1 - c0 - 16);
       const int rel = tlane ? cabs - c0 : -1;
       if (stamp) a.dbg[8 * k + 0] = wall_clock64();
+      const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
+      if (BLK) {
+        if (leader && k > 0) {
+          // the strip that was my pivot strip (rows 0..15 = registers 0..3) is away at the last level: rows 16..31 take over
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { b[q] = b[q + 4]; b[q + 4] = 0.0; }
+        }
+        if (stamp) a.dbg[256 + 8 * k + 0] = wall_clock64();
+        if (wv == k) xk_blk_panel_wave(b, lane, nsteps, blds, (a.dbg && xcc == 0 && slot == 1) ? a.dbg + 512 + 8 * k : nullptr);
+        else if (wv > k) xk_blk_trailing_wave(b, lane, blds);
+        else { __syncthreads(); __syncthreads(); }
+        if (stamp) a.dbg[256 + 8 * k + 1] = wall_clock64();
+        if (mine && rel >= 0) {                              // hand the pivot strip over: rows 0..15 = registers 0..3
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = 4 * q + part;
+            if (rel < 16) a.PB1[((size_t)j * 16 + row) * 16 + rel] = (row > rel) ? 0.0 : b[q];
+            else myS[(size_t)row * a.C1P + cabs] = b[q];
+          }
+        }
+      } else {
       if (leader && k > 0 && tlane) {
         // the strip that was my pivot strip is away at the last level: the rows part 1 kept become the new pivot strip
 #pragma unroll
@@ -202,13 +244,11 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
           b[r] = (part == 0) ? sw : (part == 1) ? 0.0 : b[r];
         }
       }
-      const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
       if (stamp) a.dbg[256 + 8 * k + 0] = wall_clock64();
       xk_caqr_steps<4, RPL>(b, rel, mine, part, nsteps, ubuf, sc);
-      if (stamp) a.dbg[256 + 8 * k + 1] = wall_clock64();
-      // hand the pivot strip over: rows 0..15 of the part-0 lanes.  (Storing row K right after step K -- it is final by then --
-      // so that the stores drain behind the remaining steps was measured: tile phase 15.4 -> 21.5 us; the stores' data keeps
-      // registers live across the steps and the compiler's waits land inside the chain.)
+      // hand the pivot strip over: rows 0..15 of the part-0 lanes.  (Storing row K right after step K -- it is final by
+      // then -- so that the stores drain behind the remaining steps was measured: the tile phase goes from 15.4 to 21.5 us,
+      // the store data keeps the steps' registers live and the compiler's waits land inside the chain.)
       if (mine && part == 0 && rel >= 0) {
         if (rel < 16) {
 #pragma unroll
@@ -218,15 +258,17 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
           for (int r = 0; r < 16; ++r) myS[(size_t)r * a.C1P + cabs] = b[r];
         }
       }
+      if (stamp) a.dbg[256 + 8 * k + 1] = wall_clock64();
+      }
       if (stamp) a.dbg[8 * k + 1] = wall_clock64();
-      // the two first-level groups of an XCD are independent of each other until the last level: each has its own barrier
-      // and runs its own merge items (a smaller barrier waits for fewer stragglers)
+      // the two first-level groups of an XCD are independent of each other: each has its own barrier and runs its own
+      // merge items (a smaller barrier waits for fewer stragglers)
       ok = xk_flag_barrier(sync, XK_PS_GBARCNT, XK_PS_GBARGEN, (unsigned)mygid, (unsigned)gsize, ++epoch, &s_ok);
       if (!ok) break;
       if (stamp) a.dbg[8 * k + 2] = wall_clock64();
       // trailing columns per first-level item: as few as keeps G x msplit items within the XCD's 31 workgroups (a step of a
       // 48-column item takes 0.83 us, of a 28-column one 0.5: fewer waves share the LDS and the vector pipe)
-      const int mch = min(32, max(8, 4 * ((trail + 4 * 15 - 1) / (4 * 15))));
+      const int mch = min(32, max(8, 4 * ((trail + 4 * 15 - 1) / (4 * 15))));   // <= 15 items per group of 15 / 16 workgroups
       const int msplit = max(1, (trail + mch - 1) / mch);
       for (int split = slot - grp * A1; split < msplit; split += gsize) {
         const int jg = grp;
@@ -241,7 +283,7 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
         xk_resident_merge1<RM1>(ap, k, (int)xcc * G + jg, base, nstrips, split, mch, ubuf, sc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) xk_count_in(sync + (XK_PS_X1CNT + k) * 16, sync + (XK_PS_X1FLAG + k) * 16, 1u, 8u * (unsigned)(G * msplit));
+        if (tid == 0) xk_count_in(sync + (XK_PS_X1CNT + k) * 16, sync + (XK_PS_X1FLAG + k) * 16, 1u, 8u * (unsigned)(G * msplit));   // all 16 groups
       }
       if (!ok) break;
       if (stamp) a.dbg[8 * k + 4] = wall_clock64();
@@ -250,13 +292,21 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
         if (!ok) break;
         // my strip comes back (trailing columns of the NEXT panels only: everything up to c0 + 15 is finished)
         if (mine && rel >= 16) {
-          if (!leader) {
+          const double *hq = a.Hq + (size_t)((int)xcc * G + grp) * 16 * a.C1P;
+          if (BLK) {
+            if (!leader) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) b[q] = xk_ld_sc1(myS + (size_t)(4 * q + part) * a.C1P + cabs);
+            } else if (k > 0) {                              // what the first level left of the rows that were away
+#pragma unroll
+              for (int q = 0; q < 4; ++q) b[4 + q] = xk_ld_sc1(hq + (size_t)(4 * q + part) * a.C1P + cabs);
+            }
+          } else if (!leader) {
             if (part == 0) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(myS + (size_t)r * a.C1P + cabs);
             }
           } else if (k > 0 && part == 1) {                   // what the first level left of the rows that were away
-            const double *hq = a.Hq + (size_t)((int)xcc * G + grp) * 16 * a.C1P;
 #pragma unroll
             for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(hq + (size_t)r * a.C1P + cabs);
           }
