@@ -296,7 +296,7 @@ __global__ __launch_bounds__(XK_PERSIST_THREADS) __attribute__((amdgpu_waves_per
     if (threadIdx.x == 0 && blockIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
     return;
   }
-  const int slot = (int)s_slot, nx = (int)s_nx;
+  const int slot = __builtin_amdgcn_readfirstlane((int)s_slot), nx = __builtin_amdgcn_readfirstlane((int)s_nx);
   const int npanels = (a.C1 + 15) / 16;
   const int TPX = a.TPX, G = a.G, A1 = a.A1, NT = a.NT;
   const int NL = 8 * (nx - NT);                        // last-level workgroups

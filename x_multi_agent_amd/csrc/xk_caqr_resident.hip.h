@@ -55,6 +55,13 @@ __device__ __forceinline__ XkCaqrResidentArgs xk_resident_args(XkResidentArgsPtr
 // first merge level of one group, 16 lanes per column (lane p = row p of every strip, register s = strip s, register
 // NS = the pending strip): 16 panel + 32 trailing columns per workgroup.  Strips come from S / PB1, the root goes to
 // X1 / X1P, the other strips back to S, the pending strip's rest to Hq.
+// Hides a pointer from loop-invariant code motion: the sixteen per-row addresses of a strip are then formed where they
+// are used (one 64-bit add each) instead of being hoisted out of the panel loop, 96 registers' worth, and spilled.
+template <typename T> __device__ __forceinline__ T *xk_opaque(T *p) {
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
 template <int RPL>
 __device__ __noinline__ void xk_resident_merge1(XkResidentArgsPtr ap, int k, int gid, int base, int nstrips, int split, int MCH,
                                                 double *ubuf, double *sc) {
@@ -159,7 +166,9 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
     if (threadIdx.x == 0 && blockIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
     return;
   }
-  const int slot = (int)s_slot;
+  // (read from LDS, so the compiler takes it for a per-lane value: every pointer derived from it became 64-bit VGPR
+  //  arithmetic, hoisted out of the panel loop and spilled -- ~100 dwords per lane, 0.39 GB of scratch traffic per update)
+  const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
   const int npanels = (a.C1 + 15) / 16;
   unsigned epoch = 0;
   bool ok = true;
@@ -211,11 +220,13 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       // registers live across the steps and the compiler's waits land inside the chain.)
       if (mine && part == 0 && rel >= 0) {
         if (rel < 16) {
+          double *pb = xk_opaque(a.PB1 + (size_t)j * 256 + rel);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a.PB1[((size_t)j * 16 + r) * 16 + rel] = (r > rel) ? 0.0 : b[r];
+          for (int r = 0; r < 16; ++r) pb[r * 16] = (r > rel) ? 0.0 : b[r];
         } else {
+          double *ps = xk_opaque(myS + cabs);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) myS[(size_t)r * a.C1P + cabs] = b[r];
+          for (int r = 0; r < 16; ++r) ps[(size_t)r * a.C1P] = b[r];
         }
       }
       if (stamp) a.dbg[8 * k + 1] = wall_clock64();
@@ -252,13 +263,14 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
         if (mine && rel >= 16) {
           if (!leader) {
             if (part == 0) {
+              const double *ps = xk_opaque(myS + cabs);
 #pragma unroll
-              for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(myS + (size_t)r * a.C1P + cabs);
+              for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(ps + (size_t)r * a.C1P);
             }
           } else if (k > 0 && part == 1) {                   // what the first level left of the rows that were away
-            const double *hq = a.Hq + (size_t)((int)xcc * G + grp) * 16 * a.C1P;
+            const double *hq = xk_opaque(a.Hq + (size_t)((int)xcc * G + grp) * 16 * a.C1P + cabs);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(hq + (size_t)r * a.C1P + cabs);
+            for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(hq + (size_t)r * a.C1P);
           }
         }
       }

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
     if (threadIdx.x == 0 && blockIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
     return;
   }
-  const int slot = (int)s_slot;
+  // (read from LDS, so the compiler takes it for a per-lane value: every pointer derived from it became 64-bit VGPR
+  //  arithmetic, hoisted out of the panel loop and spilled -- ~100 dwords per lane, 0.39 GB of scratch traffic per update)
+  const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
   const int npanels = (a.C1 + 15) / 16;
   unsigned epoch = 0;
   bool ok = true;
