@@ -15,7 +15,7 @@ t = eng.bench_staged(sc["sigma_img"], 3, 20)
 mode = "multi-launch" if os.environ.get("XK_CAQR_RESIDENT") == "0" else ("resident+blocked" if os.environ.get("XK_CAQR_BLOCKED") == "1" else "resident")
 print(mode + ":", {k: round(v["ms"], 4) for k, v in t["stages"].items() if v["ms"] > 0}, "total", round(t["total_ms"], 4), "launches", t["n_levels"])
 if mode != "multi-launch":
-    NW = 768
+    NW = 1024
     out = (C.c_longlong * NW)()
     eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
     allw = np.array(list(out), dtype=np.int64)
@@ -27,7 +27,13 @@ if mode != "multi-launch":
     print("panel: tile  bar1  wait  merge bar2+reload | cum us | last-level: start(after tile start) span")
     for k in range(npan):
         r = w[k]
-        print(f"{k:3d}  {(r[1]-r[0])/100:5.2f} {(r[2]-r[1])/100:5.2f} {(r[3]-r[2])/100:5.2f} {(r[4]-r[3])/100:5.2f} {(r[5]-r[4])/100:5.2f} | {(r[5]-t0)/100:7.2f} | {(r[6]-r[0])/100:6.2f} {(r[7]-r[6])/100:6.2f} | steps only {(w2[k,1]-w2[k,0])/100:5.2f} | merge: load {(w2[k,2]-r[3])/100:5.2f} steps {(w2[k,3]-w2[k,2])/100:5.2f} ({(w2[k,5]-w2[k,4])/max(1,(w2[k,3]-w2[k,2]))/10:.2f} GHz) rest {(r[4]-w2[k,3])/100:5.2f}" + (f" | panel wave: steps {(w3[k,0]-w2[k,0])/100:5.2f} V+G {(w3[k,1]-w3[k,0])/100:5.2f} Tinv {(w3[k,2]-w3[k,1])/100:5.2f}" if w3[k,0] else ""))
+        print(f"{k:3d}  {(r[1]-r[0])/100:5.2f} {(r[2]-r[1])/100:5.2f} {(r[3]-r[2])/100:5.2f} {(r[4]-r[3])/100:5.2f} {(r[5]-r[4])/100:5.2f} | {(r[5]-t0)/100:7.2f} | {(r[6]-r[0])/100:6.2f} {(r[7]-r[6])/100:6.2f} | steps only {(w2[k,1]-w2[k,0])/100:5.2f} | merge: load {(w2[k,2]-r[3])/100:5.2f} steps {(w2[k,3]-w2[k,2])/100:5.2f} ({(w2[k,5]-w2[k,4])/max(1,(w2[k,3]-w2[k,2]))/10:.2f} GHz) rest {(r[4]-w2[k,3])/100:5.2f}")
+    w4 = allw[768:1024].reshape(32, 8)
+    print("last level (workgroup 0), us after the tile step of the same panel started: rows 0..7 flagged | steps 0..7 done | rows 8..15 flagged | steps 8..15 done | strips published")
+    for k in range(npan):
+        print(f"{k:3d}  " + "  ".join(f"{(w4[k,i]-w[k,0])/100:6.2f}" for i in range(4)) + f"  {(w[k,7]-w[k,0])/100:6.2f}")
+    print(f"start-up: entry -> census done {(allw[513]-allw[512])/100:.2f} us, -> rows gathered (panel 0 starts) {(w[0,0]-allw[513])/100:.2f} us; "
+          f"tile workgroup leaves {(allw[514]-allw[512])/100:.2f} us after its entry, last-level workgroup {(allw[515]-allw[512])/100:.2f} us")
     np.save("/tmp/res_P.npy", got["P"]); np.save("/tmp/res_c.npy", got["correction"])
     eng.close()
     env = dict(os.environ, XK_CAQR_RESIDENT="0")

@@ -43,7 +43,10 @@ enum {
   XK_PS_L2FLAG = 32 + 3 * XK_PERSIST_MAXP,   // [MAXP] likewise for L2CNT[k]: the word the next first-level merges poll
   XK_PS_GBARCNT = 32 + 4 * XK_PERSIST_MAXP,          // [MAXG] per first-level group: barrier arrivals / generation (xk_caqr_resident)
   XK_PS_GBARGEN = 32 + 4 * XK_PERSIST_MAXP + XK_PERSIST_MAXG,
-  XK_PS_WORDS = 32 + 4 * XK_PERSIST_MAXP + 2 * XK_PERSIST_MAXG
+  // xk_caqr_resident publishes the root strips in two halves (rows 0..7 after step 7): X1CNT / X1FLAG count the SECOND half
+  XK_PS_X1CNTA = 32 + 4 * XK_PERSIST_MAXP + 2 * XK_PERSIST_MAXG,          // [MAXP] items of panel k whose rows 0..7 are out
+  XK_PS_X1FLAGA = 32 + 5 * XK_PERSIST_MAXP + 2 * XK_PERSIST_MAXG,         // [MAXP] the word the last level polls first
+  XK_PS_WORDS = 32 + 6 * XK_PERSIST_MAXP + 2 * XK_PERSIST_MAXG
 };
 
 // count `add` items in; whoever completes the count raises the flag the consumers poll (a counter that is polled by a

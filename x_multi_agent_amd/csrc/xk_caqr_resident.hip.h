@@ -28,6 +28,12 @@
 
 #define XK_RES_THREADS 768          // 12 waves, one workgroup per CU: up to 168 VGPRs (a 1024-thread version spilled 271)
 #define XK_RES_RPL 24               // rows per lane: fat tiles of 4 x 24 = 96 rows
+#ifndef XK_RES_NPARK
+#define XK_RES_NPARK 6              // tile registers parked in LDS across a merge call (see the kernel)
+#endif
+#ifndef XK_RES_LOOKAHEAD
+#define XK_RES_LOOKAHEAD 1          // one-reflector look-ahead steps (xk_caqr_steps_la); 0 = the plain steps, for A/B builds
+#endif
 #define XK_RES_NT 31                // tile workgroups per XCD (the 32nd runs the last merge level)
 
 struct XkCaqrResidentArgs {
@@ -52,9 +58,6 @@ __device__ __forceinline__ XkCaqrResidentArgs xk_resident_args(XkResidentArgsPtr
   return a;
 }
 
-// first merge level of one group, 16 lanes per column (lane p = row p of every strip, register s = strip s, register
-// NS = the pending strip): 16 panel + 32 trailing columns per workgroup.  Strips come from S / PB1, the root goes to
-// X1 / X1P, the other strips back to S, the pending strip's rest to Hq.
 // Hides a pointer from loop-invariant code motion: the sixteen per-row addresses of a strip are then formed where they
 // are used (one 64-bit add each) instead of being hoisted out of the panel loop, 96 registers' worth, and spilled.
 template <typename T> __device__ __forceinline__ T *xk_opaque(T *p) {
@@ -62,9 +65,39 @@ template <typename T> __device__ __forceinline__ T *xk_opaque(T *p) {
   return p;
 }
 
+// The 16 steps of a merge in two halves (one-reflector look-ahead inside each, xk_caqr_msteps_la): reflectors 0..7, all
+// applied on return, and reflectors 8..15.  Between the halves the caller may publish rows 0..7 of the root strip -- they
+// are final -- and the first barrier of the second half, which every wave reaches with its stores drained, is where
+// workgroup thread 0 counts the item in (cnt / flag / need).  The strips of a merge are upper triangular in the panel
+// columns, so reflector j is zero in rows > j of every strip: the level above can run ITS steps 0..7 on rows 0..7 alone.
 template <int RPL>
-__device__ __noinline__ void xk_resident_merge1(XkResidentArgsPtr ap, int k, int gid, int base, int nstrips, int split, int MCH,
-                                                double *ubuf, double *sc) {
+__device__ __forceinline__ void xk_res_msteps_a(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc) {
+  xk_caqr_mform<0, RPL>(b, rel, part, ubuf, sc);
+  __syncthreads();
+#define XK_IT(K)                                                                                  \
+  if (K < nsteps) { xk_caqr_apply<K - 1, 16, RPL>(b, rel, live, part, ubuf, sc); xk_caqr_mform<K, RPL>(b, rel, part, ubuf, sc); __syncthreads(); } \
+  else if (K == nsteps) xk_caqr_apply<K - 1, 16, RPL>(b, rel, live, part, ubuf, sc);
+  XK_IT(1) XK_IT(2) XK_IT(3) XK_IT(4) XK_IT(5) XK_IT(6) XK_IT(7)
+  if (nsteps >= 8) xk_caqr_apply<7, 16, RPL>(b, rel, live, part, ubuf, sc);
+}
+template <int RPL>
+__device__ __forceinline__ void xk_res_msteps_b(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc,
+                                                unsigned *cnt, unsigned *flag, unsigned need) {
+  if (8 < nsteps) xk_caqr_mform<8, RPL>(b, rel, part, ubuf, sc);
+  if (cnt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (cnt && threadIdx.x == 0) xk_count_in(cnt, flag, 1u, need);
+  XK_IT(9) XK_IT(10) XK_IT(11) XK_IT(12) XK_IT(13) XK_IT(14) XK_IT(15)
+#undef XK_IT
+  if (nsteps == 16) xk_caqr_apply<15, 16, RPL>(b, rel, live, part, ubuf, sc);
+}
+
+// first merge level of one group, 16 lanes per column (lane p = row p of every strip, register s = strip s, register
+// NS = the pending strip): 16 panel + 32 trailing columns per workgroup.  Strips come from S / PB1, the root goes to
+// X1 / X1P, the other strips back to S, the pending strip's rest to Hq.
+template <int RPL>
+__device__ __noinline__ bool xk_resident_merge1(XkResidentArgsPtr ap, int k, int gid, int base, int nstrips, int split, int MCH,
+                                                double *ubuf, double *sc, unsigned *s_ok, unsigned need) {
   constexpr int NP = 16, NS = RPL - 2;
   const XkCaqrResidentArgs a = xk_resident_args(ap);
   const int c0 = 16 * k;
@@ -81,6 +114,14 @@ __device__ __noinline__ void xk_resident_merge1(XkResidentArgsPtr ap, int k, int
   double b[RPL];
 #pragma unroll
   for (int s = 0; s < NS; ++s) b[s] = (mine && s < nstrips) ? xk_ld_sc1(g0 + (size_t)s * strip_step) : 0.0;
+  // the pending strip is the one input that comes from the last level of panel k - 1: wait for it with the other sixteen
+  // loads already in flight
+  if (k > 0) {
+    if (threadIdx.x == 0)
+      *s_ok = xk_spin_ge(a.sync + (XK_PS_L2FLAG + k - 1) * 16, 1u, a.sync + XK_PS_ABORT * 16, 4u) ? 1u : 0u;
+    __syncthreads();
+    if (!*s_ok) return false;
+  }
   b[NS] = (mine && pend_ok) ? xk_ld_sc1(pend_src) : 0.0;
   b[NS + 1] = 0.0;
   const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
@@ -91,25 +132,46 @@ __device__ __noinline__ void xk_resident_merge1(XkResidentArgsPtr ap, int k, int
     asm volatile("" ::"v"(sink));
     a.dbg[256 + 8 * k + 2] = wall_clock64(); a.dbg[256 + 8 * k + 4] = clock64();
   }
+  unsigned *cnt_a = a.sync + (XK_PS_X1CNTA + k) * 16, *flag_a = a.sync + (XK_PS_X1FLAGA + k) * 16;
+#if XK_RES_LOOKAHEAD
+  if (panel) __builtin_amdgcn_s_setprio(3);
+  xk_res_msteps_a<RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
+  // rows 0..7 of the root strip are final: out they go while steps 8..15 run (the last level starts on them)
+  if (mine && part < 8) {
+    if (panel) {
+      if (split == 0) xk_st_sc1(a.X1P + ((size_t)k * XK_PERSIST_MAXG + gid) * 256 + part * 16 + cidx, (part > cidx) ? 0.0 : b[0]);
+    } else {
+      xk_st_sc1(a.X1 + (((size_t)k * XK_PERSIST_MAXG + gid) * 16 + part) * a.C1P + col, b[0]);
+    }
+  }
+  xk_res_msteps_b<RPL>(b, cidx, mine, part, nsteps, ubuf, sc, cnt_a, flag_a, need);
+  if (panel) __builtin_amdgcn_s_setprio(0);
+  const int first_row = 8;
+#else
 #define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL>(b, cidx, mine, part, ubuf, sc);
   XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
   XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
 #undef XK_STEP
+  const int first_row = 0;
+  (void)cnt_a; (void)flag_a;
+#endif
   if (mstamp) { a.dbg[256 + 8 * k + 3] = wall_clock64(); a.dbg[256 + 8 * k + 5] = clock64(); }
-  if (!mine) return;
+  if (!mine) return true;
   if (panel) {
-    if (split == 0) xk_st_sc1(a.X1P + ((size_t)k * XK_PERSIST_MAXG + gid) * 256 + part * 16 + cidx, (part > cidx) ? 0.0 : b[0]);
+    if (split == 0 && part >= first_row)
+      xk_st_sc1(a.X1P + ((size_t)k * XK_PERSIST_MAXG + gid) * 256 + part * 16 + cidx, (part > cidx) ? 0.0 : b[0]);
   } else {
-    xk_st_sc1(a.X1 + (((size_t)k * XK_PERSIST_MAXG + gid) * 16 + part) * a.C1P + col, b[0]);
+    if (part >= first_row) xk_st_sc1(a.X1 + (((size_t)k * XK_PERSIST_MAXG + gid) * 16 + part) * a.C1P + col, b[0]);
 #pragma unroll
     for (int s = 1; s < NS; ++s)
       if (s < nstrips) g0[(size_t)s * strip_step] = b[s];
     if (pend_ok) pend_dst[0] = b[NS];
   }
+  return true;
 }
 
 // last merge level, 16 lanes per column (lane p = row p of every root strip): 16 roots -> 16 rows of R, the rest -> X2
-__device__ __noinline__ void xk_resident_last(XkResidentArgsPtr ap, int k, int split, int lchalf, double *ubuf, double *sc) {
+__device__ __noinline__ bool xk_resident_last(XkResidentArgsPtr ap, int k, int split, int lchalf, double *ubuf, double *sc, unsigned *s_ok) {
   constexpr int NP = 16, RPL = 16;
   const XkCaqrResidentArgs a = xk_resident_args(ap);
   const int c0 = 16 * k;
@@ -119,16 +181,37 @@ __device__ __noinline__ void xk_resident_last(XkResidentArgsPtr ap, int k, int s
   const bool mine = col < a.C1 && (panel || cidx - 16 < lchalf);
   const size_t slab = (size_t)k * XK_PERSIST_MAXG;
   double b[RPL];
+  // rows 0..7 of the roots first (published after step 7 of the first level), rows 8..15 when the first level is through:
+  // steps 0..7 here overlap steps 8..15 there
+  unsigned *ab = a.sync + XK_PS_ABORT * 16;
+  long long *lst = (a.dbg && split == 0 && threadIdx.x == 0) ? a.dbg + 768 + 8 * k : nullptr;
+  if (threadIdx.x == 0) *s_ok = xk_spin_ge(a.sync + (XK_PS_X1FLAGA + k) * 16, 1u, ab, 5u) ? 1u : 0u;
+  __syncthreads();
+  if (!*s_ok) return false;
+  if (lst) lst[0] = wall_clock64();
 #pragma unroll
   for (int s = 0; s < RPL; ++s)
-    b[s] = !mine ? 0.0 : panel ? xk_ld_sc1(a.X1P + (slab + s) * 256 + part * 16 + cidx)
-                               : xk_ld_sc1(a.X1 + ((slab + s) * 16 + part) * a.C1P + col);
+    b[s] = (!mine || part >= 8) ? 0.0 : panel ? xk_ld_sc1(a.X1P + (slab + s) * 256 + part * 16 + cidx)
+                                              : xk_ld_sc1(a.X1 + ((slab + s) * 16 + part) * a.C1P + col);
   const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
-#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep<K, RPL>(b, cidx, mine, part, ubuf, sc);
-  XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
-  XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
-#undef XK_STEP
-  if (!mine) return;
+  if (panel) __builtin_amdgcn_s_setprio(3);
+  xk_res_msteps_a<RPL>(b, cidx, mine, part, nsteps, ubuf, sc);
+  if (lst) lst[1] = wall_clock64();
+  // (Looking for the second flag two steps early and starting these loads into spare registers behind steps 6 and 7 was
+  //  measured: the first half went from 8.8 to 10.5 us, the second from 9.0 to 4.5, the kernel from 0.414 to 0.428 ms.)
+  if (threadIdx.x == 0) *s_ok = xk_spin_ge(a.sync + (XK_PS_X1FLAG + k) * 16, 1u, ab, 5u) ? 1u : 0u;
+  __syncthreads();
+  if (!*s_ok) return false;
+  if (lst) lst[2] = wall_clock64();
+  if (mine && part >= 8) {
+#pragma unroll
+    for (int s = 0; s < RPL; ++s)
+      b[s] = panel ? xk_ld_sc1(a.X1P + (slab + s) * 256 + part * 16 + cidx) : xk_ld_sc1(a.X1 + ((slab + s) * 16 + part) * a.C1P + col);
+  }
+  xk_res_msteps_b<RPL>(b, cidx, mine, part, nsteps, ubuf, sc, nullptr, nullptr, 0u);
+  if (panel) __builtin_amdgcn_s_setprio(0);
+  if (lst) lst[3] = wall_clock64();
+  if (!mine) return true;
   if (panel) {
     if (split == 0) {
       const double v = (part > cidx) ? 0.0 : b[0];
@@ -140,6 +223,7 @@ __device__ __noinline__ void xk_resident_last(XkResidentArgsPtr ap, int k, int s
 #pragma unroll
     for (int s = 0; s < RPL; ++s) xk_st_sc1(a.X2 + ((slab + s) * 16 + part) * a.C1P + col, b[s]);
   }
+  return true;
 }
 
 __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResidentArgs a) {
@@ -148,10 +232,13 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
   constexpr int LDS_MAX = LDS_T > LDS_M ? (LDS_T > LDS_L ? LDS_T : LDS_L) : (LDS_M > LDS_L ? LDS_M : LDS_L);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  constexpr int NPARK = XK_RES_NPARK;
+  __shared__ double park[(NPARK > 0 ? NPARK : 1) * XK_RES_THREADS];
   __shared__ unsigned s_slot, s_nx, s_ok;
   unsigned *sync = a.sync, *ab = sync + XK_PS_ABORT * 16;
   const XkResidentArgsPtr ap = (XkResidentArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned xcc = xk_xcc_id();
+  const long long t_entry = a.dbg ? wall_clock64() : 0;
   if (threadIdx.x == 0) {
     s_slot = __hip_atomic_fetch_add(sync + (XK_PS_CENSUS + xcc) * 16, 1u, XK_RLX_AGENT);
     __hip_atomic_fetch_add(sync + XK_PS_TOTAL * 16, 1u, XK_RLX_AGENT);
@@ -166,9 +253,8 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
     if (threadIdx.x == 0 && blockIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
     return;
   }
-  // (read from LDS, so the compiler takes it for a per-lane value: every pointer derived from it became 64-bit VGPR
-  //  arithmetic, hoisted out of the panel loop and spilled -- ~100 dwords per lane, 0.39 GB of scratch traffic per update)
   const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
+  const long long t_census = a.dbg ? wall_clock64() : 0;
   const int npanels = (a.C1 + 15) / 16;
   unsigned epoch = 0;
   bool ok = true;
@@ -199,6 +285,7 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       }
     }
     double *myS = a.S + (size_t)j * 16 * a.C1P;
+    if (stamp) { a.dbg[512] = t_entry; a.dbg[513] = t_census; }
     for (int k = 0; k < npanels && ok; ++k) {
       const int c0 = 16 * k, trail = max(0, a.C1 - c0 - 16);
       const int rel = tlane ? cabs - c0 : -1;
@@ -213,7 +300,11 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       }
       const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
       if (stamp) a.dbg[256 + 8 * k + 0] = wall_clock64();
+#if XK_RES_LOOKAHEAD
+      xk_caqr_steps_la<4, RPL>(b, rel, mine, part, nsteps, (rel >> 4) == 0, ubuf, sc);
+#else
       xk_caqr_steps<4, RPL>(b, rel, mine, part, nsteps, ubuf, sc);
+#endif
       if (stamp) a.dbg[256 + 8 * k + 1] = wall_clock64();
       // hand the pivot strip over: rows 0..15 of the part-0 lanes.  (Storing row K right after step K -- it is final by then --
       // so that the stores drain behind the remaining steps was measured: tile phase 15.4 -> 21.5 us; the stores' data keeps
@@ -239,22 +330,33 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       // 48-column item takes 0.83 us, of a 28-column one 0.5: fewer waves share the LDS and the vector pipe)
       const int mch = min(32, max(8, 4 * ((trail + 4 * 15 - 1) / (4 * 15))));
       const int msplit = max(1, (trail + mch - 1) / mch);
+      // The merge bodies are calls (inlined, they spill three times as much), so whatever of the fat tile stays live across
+      // them must sit in the 64 callee-saved VGPRs of the 168: forty-eight tile registers plus the lane's indices do not
+      // fit, and the register that lost was reloaded and stored back in every one of the 32 steps of a panel.  NPARK tile
+      // registers wait in LDS instead while this workgroup runs a merge item.
+      const bool has_item = slot - grp * A1 < msplit;
+      if (has_item) {
+#pragma unroll
+        for (int q = 0; q < NPARK; ++q) park[q * XK_RES_THREADS + tid] = b[RPL - NPARK + q];
+      }
       for (int split = slot - grp * A1; split < msplit; split += gsize) {
         const int jg = grp;
         const int base = (int)xcc * NT + jg * A1;
         const int nstrips = gsize;
-        if (k > 0) {
-          if (tid == 0) s_ok = xk_spin_ge(sync + (XK_PS_L2FLAG + k - 1) * 16, 1u, ab, 4u) ? 1u : 0u;
-          __syncthreads();
-          if (!s_ok) { ok = false; break; }
-        }
         if (stamp) a.dbg[8 * k + 3] = wall_clock64();
-        xk_resident_merge1<RM1>(ap, k, (int)xcc * G + jg, base, nstrips, split, mch, ubuf, sc);
+        if (!xk_resident_merge1<RM1>(ap, k, (int)xcc * G + jg, base, nstrips, split, mch, ubuf, sc, &s_ok, 8u * (unsigned)(G * msplit))) { ok = false; break; }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if !XK_RES_LOOKAHEAD
+        if (tid == 0) xk_count_in(sync + (XK_PS_X1CNTA + k) * 16, sync + (XK_PS_X1FLAGA + k) * 16, 1u, 8u * (unsigned)(G * msplit));
+#endif
         if (tid == 0) xk_count_in(sync + (XK_PS_X1CNT + k) * 16, sync + (XK_PS_X1FLAG + k) * 16, 1u, 8u * (unsigned)(G * msplit));
       }
       if (!ok) break;
+      if (has_item) {
+#pragma unroll
+        for (int q = 0; q < NPARK; ++q) b[RPL - NPARK + q] = park[q * XK_RES_THREADS + tid];
+      }
       if (stamp) a.dbg[8 * k + 4] = wall_clock64();
       if (k + 1 < npanels) {
         ok = xk_flag_barrier(sync, XK_PS_GBARCNT, XK_PS_GBARGEN, (unsigned)mygid, (unsigned)gsize, ++epoch, &s_ok);
@@ -276,6 +378,7 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       }
       if (stamp) a.dbg[8 * k + 5] = wall_clock64();
     }
+    if (stamp) a.dbg[514] = wall_clock64();
   } else {
     // ---- role L: the last merge level of every panel, on a CU of its own
     const int lidx = (int)xcc;                               // 8 of them
@@ -285,16 +388,14 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       const int lchalf = max(4, 4 * ((trail + 31) / 32));    // trailing columns per workgroup: all 8 share the range
       const int lsplit = max(1, (trail + lchalf - 1) / lchalf);
       if (lidx >= lsplit) continue;
-      if (tid == 0) s_ok = xk_spin_ge(sync + (XK_PS_X1FLAG + k) * 16, 1u, ab, 5u) ? 1u : 0u;
-      __syncthreads();
-      if (!s_ok) { ok = false; break; }
       if (stamp) a.dbg[8 * k + 6] = wall_clock64();
-      xk_resident_last(ap, k, lidx, lchalf, ubuf, sc);
+      if (!xk_resident_last(ap, k, lidx, lchalf, ubuf, sc, &s_ok)) { ok = false; break; }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) xk_count_in(sync + (XK_PS_L2CNT + k) * 16, sync + (XK_PS_L2FLAG + k) * 16, 1u, (unsigned)lsplit);
       if (stamp) a.dbg[8 * k + 7] = wall_clock64();
     }
+    if (stamp) a.dbg[515] = wall_clock64();
   }
   if (!ok && tid == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
 }

@@ -891,6 +891,169 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
   }
 }
 
+// ----------------------------------------------------------------------------
+// The same steps with a ONE-REFLECTOR LOOK-AHEAD (register-resident kernel): iteration K of a panel is
+//     every lane: apply reflector K - 1;   the owner of column K: form reflector K and publish it;   barrier
+// instead of  owner: form K; barrier; everyone: apply K.  The arithmetic and its order are identical; what changes is
+// the critical path of a step: the owner's wave no longer waits for the slowest of the three waves that share its SIMD
+// to finish applying the previous reflector before it starts the next scalar chain -- with the waves that hold panel
+// columns raised in priority (s_setprio), their apply runs first and the chain overlaps the other waves' apply.
+// Double-buffered like xk_caqr_step: reflector K lives in buffer K & 1, rewritten two iterations later, a barrier after
+// its last reader.
+template <int KK, int NP, int RPL>
+__device__ __forceinline__ void xk_caqr_form(double (&b)[RPL], int rel, int part, double *ubuf, double *sc) {
+  constexpr int RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
+  double *scp = sc + pb * 4;
+  if (rel != KK) return;
+  // rows 0..KK of the part-0 lane (R entries and the pivot) are no part of the reflector: the 0/1 lane mask that keeps
+  // them out of the norm also makes the published column clean, so that only the pivot entry is patched after the chain
+  const double below = (part != 0) ? 1.0 : 0.0;
+  double vm[RPL];
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) vm[r] = (r > KK) ? b[r] : b[r] * below;
+#pragma unroll
+  for (int r = 0; r < RPL; r += 2) {
+    xk_d2 tt = {vm[r], vm[r + 1]};
+    useg[r >> 1] = tt;
+  }
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) {
+    if ((r & 3) == 0) s0 = fma(vm[r], b[r], s0); else if ((r & 3) == 1) s1 = fma(vm[r], b[r], s1);
+    else if ((r & 3) == 2) s2 = fma(vm[r], b[r], s2); else s3 = fma(vm[r], b[r], s3);
+  }
+  const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
+  if (part == 0) {
+    const double c0v = b[KK];
+    double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+    if (tail > 2.2250738585072014e-308) {
+      const double n2 = fma(c0v, c0v, tail);
+      double y = __builtin_amdgcn_rsq(n2);
+      y = y * fma(-0.5 * n2 * y, y, 1.5);
+      y = y * fma(-0.5 * n2 * y, y, 1.5);
+      const double ab = n2 * y;
+      beta = (c0v >= 0) ? -ab : ab;
+      vp = c0v - beta;
+      y2 = y * y;
+      tden = fma(fabs(c0v), y, 1.0);
+    }
+    double rt = __builtin_amdgcn_rcp(tden);
+    rt = fma(rt, fma(-tden, rt, 1.0), rt);
+    rt = fma(rt, fma(-tden, rt, 1.0), rt);
+    const double mtt = -(y2 * rt);
+    ubuf[(pb * NP + part) * RPLP + KK] = vp;             // the pivot entry of the reflector
+    scp[0] = mtt;
+    b[KK] = beta;
+  }
+}
+
+template <int KK, int NP, int RPL>
+__device__ __forceinline__ void xk_caqr_apply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
+  constexpr int RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
+  const double mtt = sc[pb * 4];
+  if (rel > KK && live && mtt != 0.0) {
+    xk_d2 u[RPL / 2];
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+      else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+    }
+    const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+    }
+  }
+}
+
+// `hot` = this wave holds panel columns (wave-uniform)
+template <int NP, int RPL>
+__device__ __forceinline__ void xk_caqr_steps_la(double (&b)[RPL], int rel, bool live, int part, int nsteps, bool hot, double *ubuf, double *sc) {
+  if (hot) __builtin_amdgcn_s_setprio(3);
+  xk_caqr_form<0, NP, RPL>(b, rel, part, ubuf, sc);
+  __syncthreads();
+#define XK_IT(K)                                                                                  \
+  if (K < nsteps) { xk_caqr_apply<K - 1, NP, RPL>(b, rel, live, part, ubuf, sc); xk_caqr_form<K, NP, RPL>(b, rel, part, ubuf, sc); __syncthreads(); } \
+  else if (K == nsteps) xk_caqr_apply<K - 1, NP, RPL>(b, rel, live, part, ubuf, sc);
+  XK_IT(1) XK_IT(2) XK_IT(3) XK_IT(4) XK_IT(5) XK_IT(6) XK_IT(7) XK_IT(8)
+  XK_IT(9) XK_IT(10) XK_IT(11) XK_IT(12) XK_IT(13) XK_IT(14) XK_IT(15)
+#undef XK_IT
+  if (nsteps == 16) xk_caqr_apply<15, NP, RPL>(b, rel, live, part, ubuf, sc);
+  if (hot) __builtin_amdgcn_s_setprio(0);
+}
+
+// the merge layout (xk_caqr_mstep): 16 lanes per column, lane p = row p of every strip
+template <int KK, int RPL>
+__device__ __forceinline__ void xk_caqr_mform(double (&b)[RPL], int rel, int part, double *ubuf, double *sc) {
+  constexpr int NP = 16, RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  xk_d2 *useg = reinterpret_cast<xk_d2 *>(ubuf + (pb * NP + part) * RPLP);
+  double *scp = sc + pb * 4;
+  if (rel != KK) return;
+  const double below = (part > KK) ? 1.0 : 0.0, at_or_below = (part >= KK) ? 1.0 : 0.0;
+  {
+    xk_d2 t0 = {b[0] * at_or_below, b[1]};
+    useg[0] = t0;
+  }
+#pragma unroll
+  for (int r = 2; r < RPL; r += 2) {
+    xk_d2 tt = {b[r], b[r + 1]};
+    useg[r >> 1] = tt;
+  }
+  double s0 = (b[0] * below) * b[0], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+  for (int r = 1; r < RPL; ++r) {
+    if ((r & 3) == 0) s0 = fma(b[r], b[r], s0); else if ((r & 3) == 1) s1 = fma(b[r], b[r], s1);
+    else if ((r & 3) == 2) s2 = fma(b[r], b[r], s2); else s3 = fma(b[r], b[r], s3);
+  }
+  const double tail = xk_group_sum<NP>((s0 + s1) + (s2 + s3));
+  if (part == KK) {
+    const double c0v = b[0];
+    double y2 = 0.0, tden = 1.0, vp = 0.0, beta = c0v;
+    if (tail > 2.2250738585072014e-308) {
+      const double n2 = fma(c0v, c0v, tail);
+      double y = __builtin_amdgcn_rsq(n2);
+      y = y * fma(-0.5 * n2 * y, y, 1.5);
+      y = y * fma(-0.5 * n2 * y, y, 1.5);
+      const double ab = n2 * y;
+      beta = (c0v >= 0) ? -ab : ab;
+      vp = c0v - beta;
+      y2 = y * y;
+      tden = fma(fabs(c0v), y, 1.0);
+    }
+    double rt = __builtin_amdgcn_rcp(tden);
+    rt = fma(rt, fma(-tden, rt, 1.0), rt);
+    rt = fma(rt, fma(-tden, rt, 1.0), rt);
+    const double mtt = -(y2 * rt);
+    ubuf[(pb * NP + part) * RPLP] = vp;
+    scp[0] = mtt;
+    b[0] = beta;
+  }
+}
+
+template <int RPL>
+__device__ __forceinline__ void xk_caqr_msteps_la(double (&b)[RPL], int rel, bool live, int part, int nsteps, bool hot, double *ubuf, double *sc) {
+  if (hot) __builtin_amdgcn_s_setprio(3);
+  xk_caqr_mform<0, RPL>(b, rel, part, ubuf, sc);
+  __syncthreads();
+#define XK_IT(K)                                                                                  \
+  if (K < nsteps) { xk_caqr_apply<K - 1, 16, RPL>(b, rel, live, part, ubuf, sc); xk_caqr_mform<K, RPL>(b, rel, part, ubuf, sc); __syncthreads(); } \
+  else if (K == nsteps) xk_caqr_apply<K - 1, 16, RPL>(b, rel, live, part, ubuf, sc);
+  XK_IT(1) XK_IT(2) XK_IT(3) XK_IT(4) XK_IT(5) XK_IT(6) XK_IT(7) XK_IT(8)
+  XK_IT(9) XK_IT(10) XK_IT(11) XK_IT(12) XK_IT(13) XK_IT(14) XK_IT(15)
+#undef XK_IT
+  if (nsteps == 16) xk_caqr_apply<15, 16, RPL>(b, rel, live, part, ubuf, sc);
+  if (hot) __builtin_amdgcn_s_setprio(0);
+}
+
 // Merge body.  RPL = ARITY (20, 40) or ARITY + 2 (22, 42: register ARITY is the pending strip of the
 // overlapped schedule).  `group` / `split` = which strips / which trailing columns this workgroup owns.
 template <int RPL>
