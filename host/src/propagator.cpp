@@ -131,15 +131,24 @@ CoreCovMatrix Propagator::discreteProcessNoiseCov(double dt, const Quaternion &q
   double dg[15];
   for (int i = 0; i < 3; ++i) { dg[i] = 0.0; dg[3 + i] = n_a * n_a; dg[6 + i] = n_w * n_w; dg[9 + i] = n_bw * n_bw; dg[12 + i] = n_ba * n_ba; }
   CoreCovMatrix Q = CoreCovMatrix::Zero();
+  // F_d(t) is the identity in the bias rows and zero left of the diagonal blocks: only the structurally non-zero terms
+  // of  sum_l F(i,l) dg[l] F(j,l)  are formed (the skipped ones are exact zeros, so the sums are the dense sums)
   for (int k = 0; k < 6; ++k) {
     const double t = 0.5 * dt * (gx[k] + 1.0), wk = 0.5 * dt * gw[k];
     const CoreCovMatrix F = discreteStateTransition(t, e_w, e_a, q);
-    for (int i = 0; i < 15; ++i)
-      for (int j = i; j < 15; ++j) {
+    double Fd[9][15];
+    for (int i = 0; i < 9; ++i)
+      for (int l = 3; l < 15; ++l) Fd[i][l] = F(i, l) * dg[l];
+    for (int i = 0; i < 9; ++i) {
+      for (int j = i; j < 9; ++j) {
+        const int lo = (j >= 6) ? 6 : 3, hi = (j >= 6) ? 12 : 15;   // attitude rows: columns theta, b_w only
         double s = 0.0;
-        for (int l = 3; l < 15; ++l) s += F(i, l) * dg[l] * F(j, l);
+        for (int l = lo; l < hi; ++l) s += Fd[i][l] * F(j, l);
         Q(i, j) += wk * s;
       }
+      for (int j = 9; j < 15; ++j) Q(i, j) += wk * Fd[i][j];          // F(j, :) = e_j for the bias rows
+    }
+    for (int i = 9; i < 15; ++i) Q(i, i) += wk * dg[i];
   }
   for (int i = 0; i < 15; ++i)
     for (int j = 0; j < i; ++j) Q(i, j) = Q(j, i);

@@ -14,6 +14,21 @@ static void check(xk_handle *h, int rc, const char *what) {
   if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + (h ? xk_last_error(h) : "") + ")");
 }
 
+// one pass over the tracker's lists, straight into the engine's pinned staging memory
+static void stageTracks(xk_handle *xk, const TrackList &tr) {
+  int n_obs = 0;
+  for (const Track &t : tr) n_obs += (int)t.size();
+  int *off = nullptr;
+  double *o = nullptr;
+  check(xk, xk_stage_tracks_begin(xk, (int)tr.size(), n_obs, &off, &o), "xk_stage_tracks_begin");
+  off[0] = 0;
+  for (size_t k = 0; k < tr.size(); ++k) {
+    off[k + 1] = off[k] + (int)tr[k].size();
+    for (const Feature &f : tr[k]) { *o++ = f.getX(); *o++ = f.getY(); }
+  }
+  check(xk, xk_stage_tracks_end(xk), "xk_stage_tracks_end");
+}
+
 static void toCsr(const TrackList &tr, std::vector<int> &off, std::vector<double> &obs) {
   off.assign(tr.size() + 1, 0);
   for (size_t k = 0; k < tr.size(); ++k) off[k + 1] = off[k] + (int)tr[k].size();
@@ -48,10 +63,7 @@ void VioUpdater::setWindow(int n_poses, const std::vector<int> &anchor_idxs, boo
 void VioUpdater::stageMeasurementEarly() {
   tracks_staged_ = false;
   if (!resident_ || !measurement_.msckf_short_tracks.empty()) return;   // (the short-track update stages its own tracks first)
-  std::vector<int> off;
-  std::vector<double> obs;
-  toCsr(measurement_.msckf_tracks, off, obs);
-  check(xk_, xk_stage_tracks(xk_, off.data(), obs.data(), (int)measurement_.msckf_tracks.size()), "xk_stage_tracks");
+  stageTracks(xk_, measurement_.msckf_tracks);
   tracks_staged_ = true;
 }
 
@@ -76,12 +88,7 @@ void VioUpdater::buildAndCompress(const State &state, const TrackList &tr, bool 
   std::vector<double> q, p;
   windowLists(state, q, p);
   check(xk_, xk_stage_window(xk_, q.data(), p.data(), state_manager_.getNPoses()), "xk_stage_window");
-  if (!(tracks_staged_ && &tr == &measurement_.msckf_tracks)) {
-    std::vector<int> off;
-    std::vector<double> obs;
-    toCsr(tr, off, obs);
-    check(xk_, xk_stage_tracks(xk_, off.data(), obs.data(), (int)tr.size()), "xk_stage_tracks");
-  }
+  if (!(tracks_staged_ && &tr == &measurement_.msckf_tracks)) stageTracks(xk_, tr);
   tracks_staged_ = false;
   const TrackList &st = measurement_.slam_tracks;
   const int M = with_slam ? (int)st.size() : 0;

@@ -76,6 +76,12 @@ void *xk_stream(xk_handle *h);
  *       slam_update.cpp:196), z_last [M x 2] newest observation. */
 int xk_stage_window(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses);
 int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *obs_xy, int K);
+/* The same in two halves for a host that builds the CSR lists anyway: *trk_off (K+1 ints) and *obs_xy (2 n_obs doubles)
+ * point INTO the handle's pinned staging memory; fill them, then call xk_stage_tracks_end (which validates like
+ * xk_stage_tracks and queues the one copy).  Replaces the list -> vector -> staging double copy of a C++ host
+ * (host/src/vio_updater.cpp, mirror of the list walk in vio_updater.cpp:267-300). */
+int xk_stage_tracks_begin(xk_handle *h, int K, int n_obs, int **trk_off, double **obs_xy);
+int xk_stage_tracks_end(xk_handle *h);
 int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor_idxs, const int *track_sizes,
                   const double *z_last, int M);
 int xk_upload_P(xk_handle *h, const double *P, int ldp, int n);

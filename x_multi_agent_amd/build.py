@@ -46,7 +46,7 @@ def build_host(force=False, verbose=True):
     srcs = [os.path.join(root, "host", "src", f) for f in sorted(os.listdir(os.path.join(root, "host", "src"))) if f.endswith(".cpp")]
     inc = ["-I" + os.path.join(root, "host", "include"), "-I" + os.path.join(root, "include")]
     link = ["-L" + HERE, "-lxk", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
-    cmds = [["g++", "-std=c++17", "-O2", "-Wall", "-fPIC", "-shared"] + inc + srcs + ["-o", lib] + link]
+    cmds = [["g++", "-std=c++17", "-O3", "-Wall", "-fPIC", "-shared"] + inc + srcs + ["-o", lib] + link]
     # every host/examples/<name>_main.cpp -> x_multi_agent_amd/xk_<short>_example
     short = {"visual_update": "host", "state_manage": "manage", "place_recognition": "place"}
     for f in sorted(os.listdir(os.path.join(root, "host", "examples"))):

@@ -54,7 +54,9 @@ struct xk_handle {
   int *d_rowmap;
   int rowmap_R;            // valid rows the device row map describes (-1: stale)
   std::vector<int> *h_rowlens;   // track lengths the row map was built for
-  unsigned *d_psync;
+  unsigned *d_psync;    // TWO sets of sync words: a resident launch uses one and zeroes the other for the next launch
+  int psync_phase;
+  bool psync_dirty;     // somebody else (the persist experiment) used set 0: clear both before the next resident launch
   long long *d_pdbg;
   long long *feat_dbg;  // probe builds only: per-workgroup phase stamps of xk_msckf_feature
   bool attr_slaminit, attr_feat_batch;   // hipFuncSetAttribute done for this handle's device
@@ -65,7 +67,8 @@ struct xk_handle {
   // update workspace
   int CM, LDA;
   double *d_Maug, *d_X, *d_corr, *d_ct, *d_tmpH, *d_tmpS, *d_tmpP, *d_rdiag, *d_tmpz;
-  int *d_status;
+  int *d_status;        // status words; they live in PINNED HOST memory (h_out + n): kernels write them only on failure
+  double *h_out;        // pinned host, device-visible: [n] correction of xk_apply_update + the status words
   // CI / payload
   double *d_payload;
   double *d_ci;  // scratch for the CI kernels
@@ -92,6 +95,8 @@ struct xk_handle {
   bool flags_cached;       // h_flag_* hold the gate results of the last build (fetched with the update's status)
   int *h_flag_i;
   double *h_flag_d;
+  char *trk_slot;          // xk_stage_tracks_begin .. _end: the staging slot being filled
+  int trk_slot_K, trk_slot_nobs;
   bool async_pending;      // xk_build_compress_async ran: xk_apply_update owns the retry if the single-launch CAQR gave up
   // host pinned staging
   double *h_pin;
@@ -218,7 +223,9 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
-      HIPCHK(h, dalloc(&h->d_psync, (size_t)XK_PS_WORDS * 16));
+      HIPCHK(h, dalloc(&h->d_psync, (size_t)2 * XK_PS_WORDS * 16));
+      HIPCHK(h, hipMemset(h->d_psync, 0, sizeof(unsigned) * 2 * XK_PS_WORDS * 16));
+      h->psync_phase = 0; h->psync_dirty = false;
       HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_RES_NT * 16 * h->C1P));
       HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_RES_NT * 256));
       HIPCHK(h, dalloc(&h->d_rhq, (size_t)XK_PERSIST_MAXG * 16 * h->C1P));
@@ -238,7 +245,12 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, dalloc(&h->d_tmpP, nn));
   HIPCHK(h, dalloc(&h->d_rdiag, (size_t)h->CM));
   HIPCHK(h, dalloc(&h->d_tmpz, (size_t)h->CM));
-  h->d_status = (int *)(h->d_corr + h->n);
+  // The status words and the correction of the resident path (xk_apply_update) are written by the kernels straight into
+  // pinned host memory through its device-visible address: after the stream synchronisation that ends an update the host
+  // reads them in place -- no device-to-host copy (a ~4 us blit kernel plus its launch gap at the end of every frame).
+  HIPCHK(h, hipHostMalloc((void **)&h->h_out, sizeof(double) * ((size_t)h->n + 4), hipHostMallocDefault));
+  memset(h->h_out, 0, sizeof(double) * ((size_t)h->n + 4));
+  h->d_status = (int *)(h->h_out + h->n);
   HIPCHK(h, dalloc(&h->d_payload, (size_t)xk_payload_doubles(n_poses_max, n_feat_max)));
   HIPCHK(h, dalloc(&h->d_ci, (size_t)4 * nn + 64 * (size_t)h->n + 1024));
   h->h_pin_doubles = nn + 8 * (size_t)h->n + 4 * (size_t)k_max + 4 * (size_t)n_feat_max + 1024;
@@ -271,7 +283,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   for (auto &sp : h->h_stage) HIPCHK(h, hipHostMalloc((void **)&sp, h->stage_bytes));
   HIPCHK(h, hipHostMalloc((void **)&h->h_flag_i, sizeof(int) * ((size_t)k_max + n_feat_max + 8)));
   HIPCHK(h, hipHostMalloc((void **)&h->h_flag_d, sizeof(double) * ((size_t)k_max + n_feat_max + 8)));
-  HIPCHK(h, hipMemset(h->d_status, 0, sizeof(int) * 4));
+  memset(h->d_status, 0, sizeof(int) * 4);
   HIPCHK(h, hipMemset(h->d_tile_rows, 0, sizeof(int) * (size_t)h->ntiles_max));
   h->sigma_img = 0.0;
   *out = h;
@@ -307,6 +319,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->h_ci_cols) hipHostFree(h->h_ci_cols);
   if (h->h_ci_w) hipHostFree(h->h_ci_w);
   free(h->h_trk_off);
+  if (h->h_out) hipHostFree(h->h_out);
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
   for (auto &sp : h->h_stage)
@@ -351,33 +364,64 @@ extern "C" int xk_stage_window(xk_handle *h, const double *C_q_G, const double *
   return XK_OK;
 }
 
-extern "C" int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *obs_xy, int K) {
-  if (!h || K < 0 || (K > 0 && (!trk_off || !obs_xy))) return XK_EINVAL;
+// Track staging in two halves, so that a host that builds its CSR lists anyway can build them IN the pinned staging
+// memory (one pass over the tracker's lists instead of list -> vector -> staging copy; 0.2 MB at the headline size):
+//   xk_stage_tracks_begin(K, n_obs, &off, &obs)  ->  fill off[0..K], obs[0..2 n_obs)  ->  xk_stage_tracks_end()
+extern "C" int xk_stage_tracks_begin(xk_handle *h, int K, int n_obs, int **trk_off, double **obs_xy) {
+  if (!h || K < 0 || n_obs < 0 || !trk_off || !obs_xy) return XK_EINVAL;
   if (K > h->Kmax) return fail(h, XK_ECAPACITY, "K > k_max");
+  if ((size_t)n_obs > h->obs_cap) return fail(h, XK_ECAPACITY, "too many observations");
+  const size_t ob = sizeof(double) * 2 * (size_t)n_obs;
+  char *st = stage_slot(h, ob + sizeof(int) * (K + 1));
+  if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+  h->trk_slot = st; h->trk_slot_K = K; h->trk_slot_nobs = n_obs;
+  *obs_xy = (double *)st;
+  *trk_off = (int *)(st + ob);
+  return XK_OK;
+}
+
+extern "C" int xk_stage_tracks_end(xk_handle *h) {
+  if (!h || !h->trk_slot) return XK_EINVAL;
+  const int K = h->trk_slot_K;
+  const size_t ob = sizeof(double) * 2 * (size_t)h->trk_slot_nobs;
+  const int *trk_off = (const int *)(h->trk_slot + ob);
+  char *st = h->trk_slot;
+  h->trk_slot = nullptr;
+  int lmax = 0;
   if (K > 0) {
     if (trk_off[0] != 0) return fail(h, XK_EINVAL, "trk_off[0] != 0");
     for (int k = 0; k < K; ++k) {
       const int L = trk_off[k + 1] - trk_off[k];
       if (L < 2 || L > h->N) return fail(h, XK_EINVAL, "track length outside [2, n_poses_max]");
+      lmax = std::max(lmax, L);
     }
-    if ((size_t)trk_off[K] > h->obs_cap) return fail(h, XK_ECAPACITY, "too many observations");
+    if (trk_off[K] != h->trk_slot_nobs) return fail(h, XK_EINVAL, "trk_off[K] != n_obs");
     HIPCHK(h, hipSetDevice(h->device));
-    const size_t ob = sizeof(double) * 2 * (size_t)trk_off[K];
-    char *st = stage_slot(h, ob + sizeof(int) * (K + 1));
-    if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
-    memcpy(st, obs_xy, ob);
-    memcpy(st + ob, trk_off, sizeof(int) * (K + 1));
     h->d_trk_off = (int *)(h->d_obs + 2 * (size_t)trk_off[K]);         // offsets right behind the observations in use
     HIPCHK(h, hipMemcpyAsync(h->d_obs, st, ob + sizeof(int) * (K + 1), hipMemcpyHostToDevice, h->stream));
+    memcpy(h->h_trk_off, trk_off, sizeof(int) * (K + 1));
   }
-  if (K > 0) memcpy(h->h_trk_off, trk_off, sizeof(int) * (K + 1));
   h->K = K;
   h->have_rows = h->have_R = false;
-  // remember the longest track for validation against n_poses at build time
-  int lmax = 0;
-  for (int k = 0; k < K; ++k) lmax = std::max(lmax, trk_off[k + 1] - trk_off[k]);
-  h->h_pin_i[0] = lmax;
+  h->h_pin_i[0] = lmax;                                                 // the longest track, validated against n_poses at build time
   return XK_OK;
+}
+
+extern "C" int xk_stage_tracks(xk_handle *h, const int *trk_off, const double *obs_xy, int K) {
+  if (!h || K < 0 || (K > 0 && (!trk_off || !obs_xy))) return XK_EINVAL;
+  if (K > 0 && trk_off[0] != 0) return fail(h, XK_EINVAL, "trk_off[0] != 0");
+  if (K > 0 && trk_off[K] < 0) return fail(h, XK_EINVAL, "negative observation count");
+  int *so = nullptr;
+  double *sx = nullptr;
+  const int rc = xk_stage_tracks_begin(h, K, K > 0 ? trk_off[K] : 0, &so, &sx);
+  if (rc != XK_OK) return rc;
+  if (K > 0) {
+    memcpy(sx, obs_xy, sizeof(double) * 2 * (size_t)trk_off[K]);
+    memcpy(so, trk_off, sizeof(int) * (K + 1));
+  } else {
+    so[0] = 0;
+  }
+  return xk_stage_tracks_end(h);
 }
 
 extern "C" int xk_stage_slam(xk_handle *h, const double *feat, const int *anchor_idxs, const int *track_sizes,
@@ -700,10 +744,18 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       XkCaqrResidentArgs ra;
       ra.A = h->d_A; ra.tile_rows = h->d_tile_rows; ra.rowmap = h->d_rowmap; ra.R = h->rowmap_R; ra.TR = (h->rowmap_R + NTL - 1) / NTL;
       ra.C1P = h->C1P; ra.C1 = h->C1; ra.Rout = h->d_R; ra.S = h->d_rs; ra.PB1 = h->d_rpb; ra.Hq = h->d_rhq;
-      ra.X1 = h->d_x1; ra.X1P = h->d_x1p; ra.X2 = h->d_x2; ra.sync = h->d_psync; ra.status = h->d_status;
+      // no memset between the per-feature kernel and this one (it cost stream time in every update): the sync words are
+      // double-buffered, every launch leaves the other set zeroed for its successor
+      if (h->psync_dirty) {
+        if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * 2 * XK_PS_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
+        h->psync_dirty = false; h->psync_phase = 0;
+      }
+      ra.X1 = h->d_x1; ra.X1P = h->d_x1p; ra.X2 = h->d_x2; ra.status = h->d_status;
+      ra.sync = h->d_psync + (size_t)h->psync_phase * XK_PS_WORDS * 16;
+      ra.sync_next = h->d_psync + (size_t)(h->psync_phase ^ 1) * XK_PS_WORDS * 16;
+      h->psync_phase ^= 1;
       static const int rdbg = env_int("XK_CAQR_PERSIST_DBG", 0);
       ra.dbg = rdbg ? h->d_pdbg : nullptr;
-      if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * XK_PS_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
       hipLaunchKernelGGL(xk_caqr_resident, dim3(h->n_cu), dim3(XK_RES_THREADS), 0, h->stream, ra);
       if (mid) hipEventRecord(mid, h->stream);
       h->nleaf = NTL; h->nlevels = 1; h->have_R = true;
@@ -732,6 +784,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
     pa.dbg = pdbg ? h->d_pdbg : nullptr;
     if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * XK_PS_WORDS * 16, h->stream) != hipSuccess)
       return fail(h, XK_EDEVICE, "sync words");
+    h->psync_dirty = true;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_persist<14>), dim3(2 * h->n_cu), dim3(XK_PERSIST_THREADS), 0, h->stream, pa);
     if (mid) hipEventRecord(mid, h->stream);
     h->nleaf = ntiles;
@@ -871,6 +924,7 @@ struct UpdateSpec {
   double *Pout;       // n x n col-major (may equal neither Pin)
   const double *ct;   // device corr_total or null
   int cov_update;
+  double *corr;       // where the correction goes: null -> h->d_corr (device); xk_apply_update passes pinned host memory
 };
 
 // Kalman algebra on the device (updater.cpp:117-141 / :144-161).  ev (optional)
@@ -952,11 +1006,11 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     g.C = u.Pout; g.scr = 1; g.scc = n;
     g.M = n; g.N = n + 1; g.K = c; g.alpha = -1.0; g.beta = 1.0; g.mode = 2;
     // extra column: corr = X^T (L^-1 z') - corr_tot   (K z' - corr_tot, updater.cpp:126)
-    g.xcol = 1; g.bx = h->d_X + c + n; g.sbx = LDA; g.ex = u.ct; g.cx = h->d_corr; g.scx = 1;
+    g.xcol = 1; g.bx = h->d_X + c + n; g.sbx = LDA; g.ex = u.ct; g.cx = u.corr ? u.corr : h->d_corr; g.scx = 1;
     gemm(h, g);
   } else {
     if (u.Pout != u.Pin) hipMemcpyAsync(u.Pout, u.Pin, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream);
-    XkCorrArgs cr{h->d_X, LDA, c, n, c, c + n, u.ct, h->d_corr};
+    XkCorrArgs cr{h->d_X, LDA, c, n, c, c + n, u.ct, u.corr ? u.corr : h->d_corr};
     hipLaunchKernelGGL(xk_corr, dim3((n + 63) / 64), dim3(64), 0, h->stream, cr);
   }
   hipError_t e = hipGetLastError();
@@ -978,8 +1032,8 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
 #define XK_RETRY_CLASSIC 1000   // internal: the single-launch CAQR gave up, the multi-launch schedule must redo the update
 static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
   if (st != 0 || pst != 0) {
-    hipMemsetAsync(h->d_status, 0, 2 * sizeof(int), h->stream);
     hipStreamSynchronize(h->stream);
+    h->d_status[0] = h->d_status[1] = 0;
   }
   if (pst != 0) {
     // reasons: 1 grid not resident, 2 XCD barrier, 3 uneven XCD placement, 4/5 waiting for the last / first level
@@ -992,9 +1046,8 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
   return XK_OK;
 }
 static int read_status(xk_handle *h, bool allow_retry = false) {
-  HIPCHK(h, hipMemcpyAsync(&h->h_pin_i[4], h->d_status, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  return eval_status(h, h->h_pin_i[4], h->h_pin_i[5], allow_retry);
+  return eval_status(h, h->d_status[0], h->d_status[1], allow_retry);
 }
 
 static int fetch_flags(xk_handle *h, int *inl, double *gam, int *inls, double *gams) {
@@ -1119,17 +1172,16 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
       if ((rc = launch_compress(h)) != XK_OK) return rc;
     }
     UpdateSpec u = compressed_spec(h, dct, cov_update);
+    u.corr = h->h_out;
     rc = launch_update(h, u);
     if (rc != XK_OK) return rc;
-    // correction and status words in ONE copy (they are adjacent), one synchronisation
-    HIPCHK(h, hipMemcpyAsync(h->h_pin, h->d_corr, sizeof(double) * (h->n + 1), hipMemcpyDeviceToHost, h->stream));
+    // the kernels wrote the correction and (on failure) the status words into pinned host memory: one synchronisation, no copy
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    const int *stw = (const int *)(h->h_pin + h->n);
-    rc = eval_status(h, stw[0], stw[1], async && attempt == 0);
+    rc = eval_status(h, h->d_status[0], h->d_status[1], async && attempt == 0);
     if (rc != XK_RETRY_CLASSIC) break;
   }
   if (rc != XK_OK) return rc;
-  memcpy(correction, h->h_pin, sizeof(double) * h->n);
+  memcpy(correction, h->h_out, sizeof(double) * h->n);
   std::swap(h->d_P, h->d_Pout);  // posterior becomes the resident covariance
   h->have_rows = h->have_R = false;
   return XK_OK;

@@ -48,6 +48,7 @@ struct XkCaqrResidentArgs {
   double *Hq;             // [16][16][C1P] what the first level leaves of a group's pending strip (for its leader)
   double *X1, *X1P, *X2;  // cross-XCD slabs, as in xk_caqr_persist
   unsigned *sync;
+  unsigned *sync_next;    // the other set of sync words: zeroed by this launch for the next one
   int *status;
   long long *dbg;
 };
@@ -382,6 +383,8 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
   } else {
     // ---- role L: the last merge level of every panel, on a CU of its own
     const int lidx = (int)xcc;                               // 8 of them
+    // nothing to do until the first roots arrive: leave the other set of sync words zeroed for the next launch
+    for (int i = lidx * XK_RES_THREADS + tid; i < XK_PS_WORDS * 16; i += 8 * XK_RES_THREADS) a.sync_next[i] = 0u;
     const bool stamp = a.dbg && lidx == 0 && tid == 0;
     for (int k = 0; k < npanels && ok; ++k) {
       const int trail = max(0, a.C1 - 16 * k - 16);

@@ -23,7 +23,7 @@ STATUS = {0: "XK_OK", 1: "XK_EINVAL", 2: "XK_ESINGULAR", 3: "XK_ENAN", 4: "XK_ED
 # every symbol include/xk.h declares (tests check the library exports them all)
 SYMBOLS = [
     "xk_create", "xk_destroy", "xk_strerror", "xk_last_error", "xk_version", "xk_stream",
-    "xk_stage_window", "xk_stage_tracks", "xk_stage_slam", "xk_upload_P", "xk_download_P",
+    "xk_stage_window", "xk_stage_tracks", "xk_stage_tracks_begin", "xk_stage_tracks_end", "xk_stage_slam", "xk_upload_P", "xk_download_P",
     "xk_msckf_build", "xk_qr_compress", "xk_apply_update", "xk_visual_update_staged", "xk_visual_update",
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
     "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
