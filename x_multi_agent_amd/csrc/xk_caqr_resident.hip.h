@@ -235,25 +235,26 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
   constexpr int NPARK = XK_RES_NPARK;
   __shared__ double park[(NPARK > 0 ? NPARK : 1) * XK_RES_THREADS];
-  __shared__ unsigned s_slot, s_nx, s_ok;
+  __shared__ unsigned s_slot, s_ok;
   unsigned *sync = a.sync, *ab = sync + XK_PS_ABORT * 16;
   const XkResidentArgsPtr ap = (XkResidentArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned xcc = xk_xcc_id();
   const long long t_entry = a.dbg ? wall_clock64() : 0;
+  // Placement census: a workgroup reads the XCD it runs on and takes the next slot there (the dispatcher deals workgroups
+  // round-robin over the XCDs, but where it starts depends on what ran before: block b -> XCD b % 8 does NOT hold).  An
+  // XCD that receives a 33rd workgroup raises the abort word -- every spin looks at it -- and the host falls back to the
+  // multi-launch schedule.  Nobody waits for the census to complete (the first version spun until all 256 had arrived:
+  // 6.4 us before the first load); nothing needs every workgroup to be resident before the first group barrier, and
+  // all spins are bounded.
   if (threadIdx.x == 0) {
-    s_slot = __hip_atomic_fetch_add(sync + (XK_PS_CENSUS + xcc) * 16, 1u, XK_RLX_AGENT);
-    __hip_atomic_fetch_add(sync + XK_PS_TOTAL * 16, 1u, XK_RLX_AGENT);
-    bool ok = xk_spin_ge(sync + XK_PS_TOTAL * 16, gridDim.x, ab, 1u);
-    const unsigned nx = __hip_atomic_load(sync + (XK_PS_CENSUS + xcc) * 16, XK_RLX_AGENT);
-    if (ok && (nx * 8u != gridDim.x || nx != NT + 1)) { __hip_atomic_store(ab, 3u, XK_RLX_AGENT); ok = false; }
-    s_nx = nx;
-    s_ok = ok ? 1u : 0u;
+    const unsigned sl = __hip_atomic_fetch_add(sync + (XK_PS_CENSUS + xcc) * 16, 1u, XK_RLX_AGENT);
+    const bool bad = sl > (unsigned)NT || gridDim.x != 8u * (NT + 1);
+    if (bad) { __hip_atomic_store(ab, 3u, XK_RLX_AGENT); a.status[1] = 3; }
+    s_slot = sl;
+    s_ok = bad ? 0u : 1u;
   }
   __syncthreads();
-  if (!s_ok) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
-    return;
-  }
+  if (!s_ok) return;
   const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
   const long long t_census = a.dbg ? wall_clock64() : 0;
   const int npanels = (a.C1 + 15) / 16;
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
         double v = 0.0;
         if (mine && g < gend) {
           const int pr = a.rowmap[g];
-          if (a.tile_rows[pr >> 6] > 0) v = a.A[(size_t)pr * a.C1P + cabs];
+          // (the row and its track's verdict are fetched side by side, not one after the other: a rejected track's slot
+          //  holds whatever the per-feature kernel left there, the select drops it)
+          const double x = a.A[(size_t)pr * a.C1P + cabs];
+          v = (a.tile_rows[pr >> 6] > 0) ? x : 0.0;
         }
         b[r] = v;
       }
