@@ -65,3 +65,30 @@ def test_resident_path_steps_aside_when_it_does_not_apply(xk):
         t = eng.bench_staged(sc["sigma_img"], 0, 1)
         assert t["n_leaf"] != 248
         eng.close()
+
+
+def test_resident_launch_that_gives_up_is_redone_by_the_multi_launch_schedule(xk, oracle_c):
+    """Every spin of the single launch is bounded and looks at an abort word; a launch that gives up (workgroups not
+    co-resident, uneven XCD placement) must cost one retry, not a wrong answer.  XK_CAQR_RESIDENT_POISON raises the abort
+    word before the launch: the update has to come back correct, through the multi-launch schedule, and the handle has to
+    keep working (with that schedule) afterwards."""
+    sc = synth.make_config(4)
+    ref = oracle_c.visual_update(sc)
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    eng = xk.Engine(N, 0, K)
+    os.environ["XK_CAQR_RESIDENT_POISON"] = "1"
+    try:
+        eng.stage(sc)
+        r = eng.visual_update_staged(sc["sigma_img"])
+    finally:
+        os.environ.pop("XK_CAQR_RESIDENT_POISON", None)
+    assert np.array_equal(r["inlier"], ref["inlier"])
+    assert rel(eng.download_P(), ref["P"]) <= 1e-8
+    assert rel(r["correction"], ref["correction"]) <= 1e-6
+    eng.stage(sc)                                   # the same handle again: multi-launch from now on
+    t = eng.bench_staged(sc["sigma_img"], 0, 1)
+    assert t["n_leaf"] != 248
+    eng.stage(sc)
+    r2 = eng.visual_update_staged(sc["sigma_img"])
+    assert rel(eng.download_P(), ref["P"]) <= 1e-8 and rel(r2["correction"], ref["correction"]) <= 1e-6
+    eng.close()

@@ -754,6 +754,14 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       ra.sync = h->d_psync + (size_t)h->psync_phase * XK_PS_WORDS * 16;
       ra.sync_next = h->d_psync + (size_t)(h->psync_phase ^ 1) * XK_PS_WORDS * 16;
       h->psync_phase ^= 1;
+      // test hook: raise the abort word before the launch -- every workgroup gives up at its first spin, exactly what an
+      // uneven placement or a missing workgroup leads to, and the host has to redo the update with the multi-launch schedule
+      if (env_int("XK_CAQR_RESIDENT_POISON", 0)) {
+        const unsigned seven = 7u;
+        if (hipMemcpyAsync(ra.sync + XK_PS_ABORT * 16, &seven, sizeof(unsigned), hipMemcpyHostToDevice, h->stream) != hipSuccess)
+          return fail(h, XK_EDEVICE, "poison");
+        hipStreamSynchronize(h->stream);
+      }
       static const int rdbg = env_int("XK_CAQR_PERSIST_DBG", 0);
       ra.dbg = rdbg ? h->d_pdbg : nullptr;
       hipLaunchKernelGGL(xk_caqr_resident, dim3(h->n_cu), dim3(XK_RES_THREADS), 0, h->stream, ra);
