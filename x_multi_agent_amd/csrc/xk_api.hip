@@ -915,7 +915,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
 static void gemm(xk_handle *h, const XkGemmArgs &g) {
   const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
   if (tiles <= 0) return;
-  hipLaunchKernelGGL(xk_gemm_f64, dim3(tiles), dim3(64), 0, h->stream, g);
+  hipLaunchKernelGGL(xk_gemm_f64, dim3(tiles), dim3(64 * XK_GEMM_WAVES), 0, h->stream, g);
 }
 
 struct UpdateSpec {
@@ -1365,6 +1365,9 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
                                   "xk_kalman_update", "(unused)"};
   for (int s = 0; s < XK_NSTAGE; ++s) snprintf(out->stage_name[s], sizeof(out->stage_name[s]), "%s", names[s]);
   double acc[XK_NSTAGE] = {0, 0, 0, 0, 0, 0}, tot = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (int s = 0; s < XK_NSTAGE; ++s) acc[s] = 0;
+  tot = 0;
   for (int it = 0; it < warmup + steps; ++it) {
     HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
     int rc = launch_build(h, sigma_img);
@@ -1387,8 +1390,11 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
       hipEventElapsedTime(&ms, h->ev[0], h->ev[4]); tot += ms;
     }
   }
-  int rc = read_status(h);
+  const int rc = read_status(h, attempt == 0);
+  if (rc == XK_RETRY_CLASSIC) continue;            // the single-launch CAQR gave up somewhere: measure the multi-launch schedule
   if (rc != XK_OK) return rc;
+  break;
+  }
   for (int s = 0; s < XK_NSTAGE; ++s) out->stage_ms[s] = (float)(acc[s] / steps);
   out->total_ms = (float)(tot / steps);
   out->stage_launches[0] = (h->K > 0) + (h->M > 0);
@@ -1998,16 +2004,22 @@ extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
     hipGraphDestroy(g);
     return rc;
   }
-  for (int it = 0; it < steps; ++it) {
-    int rc = launch_build(h, sigma_img);
-    if (rc != XK_OK) return rc;
-    rc = launch_compress(h);
-    if (rc != XK_OK) return rc;
-    UpdateSpec u = compressed_spec(h, nullptr, 1);
-    rc = launch_update(h, u);
-    if (rc != XK_OK) return rc;
+  // (every step recomputes the same update from the resident prior, so a single-launch CAQR that gave up -- e.g. two
+  //  processes sharing one GPU, each with a grid that wants every CU -- costs one more pass with the multi-launch schedule)
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int it = 0; it < steps; ++it) {
+      int rc = launch_build(h, sigma_img);
+      if (rc != XK_OK) return rc;
+      rc = launch_compress(h);
+      if (rc != XK_OK) return rc;
+      UpdateSpec u = compressed_spec(h, nullptr, 1);
+      rc = launch_update(h, u);
+      if (rc != XK_OK) return rc;
+    }
+    const int rc = read_status(h, attempt == 0);
+    if (rc != XK_RETRY_CLASSIC) return rc;
   }
-  return read_status(h);
+  return XK_EDEVICE;
 }
 
 // ---------------------------------------------------------------------------

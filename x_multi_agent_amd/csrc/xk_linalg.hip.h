@@ -60,8 +60,13 @@ struct XkGemmArgs {
   long scx;
 };
 
-__global__ __launch_bounds__(64) void xk_gemm_f64(XkGemmArgs g) {
-  const int lane = threadIdx.x;
+#define XK_GEMM_WAVES 4
+__global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) {
+  // One 16 x 16 output tile per workgroup, K split over XK_GEMM_WAVES waves (these GEMMs are a few MFLOP each and pure
+  // latency: with one wave per tile the 45 dependent MFMA steps of K = 180 and their three rounds of operand loads were
+  // most of a 8 us kernel); the partial tiles meet in LDS and wave 0 adds them in a fixed order.
+  __shared__ double red[XK_GEMM_WAVES - 1][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_n = (g.N + 15) >> 4;
   const int t = blockIdx.x;
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
@@ -72,29 +77,41 @@ __global__ __launch_bounds__(64) void xk_gemm_f64(XkGemmArgs g) {
   const double *ap = g.A + (long)arow * g.sar, *bp = xc ? g.bx : g.B + (long)bcol * g.sbc;
   const long sbr = xc ? g.sbx : g.sbr;
   xk_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  // K in chunks of 64 with the NEXT chunk's 32 loads in flight while this one feeds the matrix core: a
-  // tile is one wave with nothing else to hide the ~1 us operand latency behind (these GEMMs are a few
-  // MFLOP each; they are latency, not throughput).
+  const int kq = ((g.K + 4 * XK_GEMM_WAVES - 1) / (4 * XK_GEMM_WAVES)) * 4;   // K range of a wave, a multiple of the MFMA depth
+  const int kbeg = wave * kq, kend = min(g.K, kbeg + kq);
+  // chunks of 64 with the NEXT chunk's 32 loads in flight while this one feeds the matrix core
   constexpr int CH = 16;   // MFMA steps per chunk
   double av[2][CH], bv[2][CH];
   auto load = [&](int buf, int k0) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const int k = k0 + 4 * u + lk;
-      av[buf][u] = (aok && k < g.K) ? ap[(long)k * g.sac] : 0.0;
-      bv[buf][u] = (bok && k < g.K) ? bp[(long)k * sbr] : 0.0;
+      av[buf][u] = (aok && k < kend) ? ap[(long)k * g.sac] : 0.0;
+      bv[buf][u] = (bok && k < kend) ? bp[(long)k * sbr] : 0.0;
     }
   };
-  load(0, 0);
-  for (int k0 = 0; k0 < g.K; k0 += 8 * CH) {
-    if (k0 + 4 * CH < g.K) load(1, k0 + 4 * CH);
+  if (kbeg < kend) {
+    load(0, kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 8 * CH) {
+      if (k0 + 4 * CH < kend) load(1, k0 + 4 * CH);
 #pragma unroll
-    for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
-    if (k0 + 4 * CH >= g.K) break;
-    if (k0 + 8 * CH < g.K) load(0, k0 + 8 * CH);
+      for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0][u], bv[0][u], acc, 0, 0, 0);
+      if (k0 + 4 * CH >= kend) break;
+      if (k0 + 8 * CH < kend) load(0, k0 + 8 * CH);
 #pragma unroll
-    for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+      for (int u = 0; u < CH; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1][u], bv[1][u], acc, 0, 0, 0);
+    }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < XK_GEMM_WAVES - 1; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += red[w][r][lane];
   const int col = tn * 16 + li;
   if (col >= g.N) return;
 #pragma unroll
