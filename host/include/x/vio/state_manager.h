@@ -64,5 +64,9 @@ class StateManager {
   xk_handle *xk_;
   Csr pending_;            // product of the operations queued by the current manage() call (empty = identity)
   bool has_pending_ = false;
+  Csr scratch_;            // apply(): the product under construction, swapped with pending_
+  std::vector<double> acc_;
+  std::vector<char> used_;
+  std::vector<int> cols_;
 };
 }  // namespace x

@@ -41,10 +41,13 @@ void StateManager::clear() {
 void StateManager::apply(const Csr &J) {
   if (!has_pending_) { pending_ = J; has_pending_ = true; return; }
   const int n = (int)J.rp.size() - 1;
-  Csr out;
-  std::vector<double> acc(n, 0.0);
-  std::vector<char> used(n, 0);
-  std::vector<int> cols;
+  Csr &out = scratch_;                                   // (members: no allocation per call once they have grown)
+  out.rp.clear(); out.ci.clear(); out.v.clear(); out.rp.push_back(0);
+  std::vector<double> &acc = acc_;
+  std::vector<char> &used = used_;
+  std::vector<int> &cols = cols_;
+  acc.assign(n, 0.0);
+  used.assign(n, 0);
   for (int r = 0; r < n; ++r) {
     cols.clear();
     for (int ia = J.rp[r]; ia < J.rp[r + 1]; ++ia) {
@@ -59,7 +62,7 @@ void StateManager::apply(const Csr &J) {
     for (int b : cols) { out.entry(b, acc[b]); acc[b] = 0.0; used[b] = 0; }
     out.endRow();
   }
-  pending_ = out;
+  std::swap(pending_, scratch_);
 }
 
 void StateManager::flush() {
@@ -124,6 +127,10 @@ void StateManager::reparametrizeFeatures(const Matrix &atts_old, const Matrix &p
   rotOf(atts_old, idx1, R_new);
   transpose33(R_new, R_newT);
   mul33(R_newT, R_old, RnTRo);
+  // (nothing anchored in the oldest pose -- the usual frame: J = I, and none of the bookkeeping below is needed)
+  bool any = false;
+  for (int j = 0; j < n_features_ && !any; ++j) any = anchor_idxs_[j] == 0;
+  if (!any) return;
   // rows of J that differ from the identity: feature j -> five 3x3 blocks (:455-482)
   std::vector<std::vector<std::pair<int, double>>> special(n);
   std::vector<char> is_special(n, 0);

@@ -92,6 +92,7 @@ struct xk_handle {
   char *h_stage[XK_STAGE_SLOTS];
   size_t stage_bytes;
   int stage_next;
+  bool flags_direct;       // no SLAM rows in the last build: nothing was copied, the kernel wrote the cache
   bool flags_cached;       // h_flag_* hold the gate results of the last build (fetched with the update's status)
   int *h_flag_i;
   double *h_flag_d;
@@ -629,6 +630,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
     a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
+    a.inlier_h = h->h_flag_i; a.gamma_h = h->h_flag_d;     // gate results also straight into the pinned flag cache
     const size_t lds = xk_feature_lds_bytes(h->n_poses);
     hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
   }
@@ -1112,17 +1114,16 @@ extern "C" int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z) {
 
 // gate results of the last build -> the handle's pinned cache (asynchronous; valid after the next synchronisation)
 static int cache_flags(xk_handle *h) {
-  HIPCHK(h, hipEventRecord(h->ev_flags, h->stream));                 // the per-feature kernels have been queued
-  HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_flags, 0));
-  if (h->K > 0) {
-    HIPCHK(h, hipMemcpyAsync(h->h_flag_i, h->d_inl, sizeof(int) * h->K, hipMemcpyDeviceToHost, h->copy_stream));
-    HIPCHK(h, hipMemcpyAsync(h->h_flag_d, h->d_gam, sizeof(double) * h->K, hipMemcpyDeviceToHost, h->copy_stream));
-  }
-  if (h->M > 0) {
+  // MSCKF gate results: the per-feature kernel writes them into the pinned cache itself (XkFeatArgs::inlier_h / gamma_h);
+  // without SLAM rows there is nothing to copy and nothing to wait for but the stream (five runtime calls less per frame)
+  h->flags_direct = h->M == 0;
+  if (!h->flags_direct) {
+    HIPCHK(h, hipEventRecord(h->ev_flags, h->stream));               // the per-feature kernels have been queued
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_flags, 0));
     HIPCHK(h, hipMemcpyAsync(h->h_flag_i + h->Kmax, h->d_inl_s, sizeof(int) * h->M, hipMemcpyDeviceToHost, h->copy_stream));
     HIPCHK(h, hipMemcpyAsync(h->h_flag_d + h->Kmax, h->d_gam_s, sizeof(double) * h->M, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(h, hipEventRecord(h->ev_flags_done, h->copy_stream));
   }
-  HIPCHK(h, hipEventRecord(h->ev_flags_done, h->copy_stream));
   h->flags_cached = true;
   return XK_OK;
 }
@@ -1144,9 +1145,15 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
 extern "C" int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
   if (!h) return XK_EINVAL;
   if (!h->flags_cached) return fail(h, XK_EINVAL, "xk_fetch_flags: no build since the inputs were staged");
-  if (hipEventQuery(h->ev_flags_done) != hipSuccess) {   // (normally long done: the copies ran beside the QR kernels)
+  if (!h->flags_direct && hipEventQuery(h->ev_flags_done) != hipSuccess) {   // (normally long done: the copies ran beside the QR kernels)
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipEventSynchronize(h->ev_flags_done));
+  }
+  // the MSCKF results were written by the per-feature kernel: valid once the stream has passed it (after xk_apply_update
+  // it has; otherwise this waits)
+  if (h->K > 0 && hipStreamQuery(h->stream) != hipSuccess) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   if (inlier_msckf && h->K > 0) memcpy(inlier_msckf, h->h_flag_i, sizeof(int) * h->K);
   if (gamma_msckf && h->K > 0) memcpy(gamma_msckf, h->h_flag_d, sizeof(double) * h->K);
@@ -1634,7 +1641,7 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
     a.P = aP; a.n = n_i; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = nullptr; a.DB = 0; a.C1P = 0; a.na = n_i - XK_CORE;
     a.tile_rows = dint + 2; a.inlier = dint + 1; a.gamma = dscal + 2; a.gpf = dgpf + 4; a.gn_iters = dint + 3;
-    a.gpf_in = dgpf; a.up_out = up + i * upsz; a.batch = nullptr; a.dbg = nullptr;
+    a.gpf_in = dgpf; a.up_out = up + i * upsz; a.batch = nullptr; a.dbg = nullptr; a.inlier_h = nullptr; a.gamma_h = nullptr;
     hipLaunchKernelGGL(xk_msckf_feature, dim3(1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(np_i), h->stream, a);
     if (self) {
       int inl = 0;
@@ -1763,15 +1770,13 @@ extern "C" int xk_cov_propagate(xk_handle *h, const double *f_d, int ldf, const 
   if (!h || !f_d || !q_d || ldf < XK_CORE || ldq < XK_CORE) return XK_EINVAL;
   const int n = h->n;
   HIPCHK(h, hipSetDevice(h->device));
-  double *st = (double *)stage_slot(h, sizeof(double) * 450);
-  if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+  XkPropArgs a;
+  a.P = h->d_P; a.n = n;
   for (int c = 0; c < XK_CORE; ++c)
     for (int r = 0; r < XK_CORE; ++r) {
-      st[r + XK_CORE * c] = f_d[r + (size_t)c * ldf];
-      st[225 + r + XK_CORE * c] = q_d[r + (size_t)c * ldq];
+      a.FQ[r + XK_CORE * c] = f_d[r + (size_t)c * ldf];
+      a.FQ[225 + r + XK_CORE * c] = q_d[r + (size_t)c * ldq];
     }
-  HIPCHK(h, hipMemcpyAsync(h->d_fq, st, sizeof(double) * 450, hipMemcpyHostToDevice, h->stream));
-  XkPropArgs a{h->d_P, n, h->d_fq};
   hipLaunchKernelGGL(xk_cov_propagate_k, dim3(1 + (2 * (n - XK_CORE) + 255) / 256), dim3(256), 0, h->stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "propagate launch", e);

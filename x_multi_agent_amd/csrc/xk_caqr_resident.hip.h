@@ -34,7 +34,10 @@
 #ifndef XK_RES_LOOKAHEAD
 #define XK_RES_LOOKAHEAD 1          // one-reflector look-ahead steps (xk_caqr_steps_la); 0 = the plain steps, for A/B builds
 #endif
-#define XK_RES_NT 31                // tile workgroups per XCD (the 32nd runs the last merge level)
+#ifndef XK_RES_NL
+#define XK_RES_NL 1                 // workgroups per XCD that run the last merge level (A/B builds: 2)
+#endif
+#define XK_RES_NT (32 - XK_RES_NL)  // tile workgroups per XCD
 
 struct XkCaqrResidentArgs {
   const double *A;        // tiles [ntiles][64][C1P] row-major as the per-feature kernels wrote them (read once)
@@ -228,7 +231,7 @@ __device__ __noinline__ bool xk_resident_last(XkResidentArgsPtr ap, int k, int s
 }
 
 __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResidentArgs a) {
-  constexpr int RPL = XK_RES_RPL, NT = XK_RES_NT, RM1 = 18, A1 = 16, G = 2;
+  constexpr int RPL = XK_RES_RPL, NT = XK_RES_NT, NL = XK_RES_NL, RM1 = 18, A1 = (NT + 1) / 2, G = 2;
   constexpr int LDS_T = 2 * 4 * (RPL + 2), LDS_M = 2 * 16 * (RM1 + 2), LDS_L = 2 * 16 * 18;
   constexpr int LDS_MAX = LDS_T > LDS_M ? (LDS_T > LDS_L ? LDS_T : LDS_L) : (LDS_M > LDS_L ? LDS_M : LDS_L);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
   // all spins are bounded.
   if (threadIdx.x == 0) {
     const unsigned sl = __hip_atomic_fetch_add(sync + (XK_PS_CENSUS + xcc) * 16, 1u, XK_RLX_AGENT);
-    const bool bad = sl > (unsigned)NT || gridDim.x != 8u * (NT + 1);
+    const bool bad = sl >= (unsigned)(NT + NL) || gridDim.x != 8u * (NT + NL);
     if (bad) { __hip_atomic_store(ab, 3u, XK_RLX_AGENT); a.status[1] = 3; }
     s_slot = sl;
     s_ok = bad ? 0u : 1u;
@@ -386,13 +389,13 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
     if (stamp) a.dbg[514] = wall_clock64();
   } else {
     // ---- role L: the last merge level of every panel, on a CU of its own
-    const int lidx = (int)xcc;                               // 8 of them
+    const int lidx = (int)xcc * NL + (slot - NT);             // 8 NL of them
     // nothing to do until the first roots arrive: leave the other set of sync words zeroed for the next launch
-    for (int i = lidx * XK_RES_THREADS + tid; i < XK_PS_WORDS * 16; i += 8 * XK_RES_THREADS) a.sync_next[i] = 0u;
+    for (int i = lidx * XK_RES_THREADS + tid; i < XK_PS_WORDS * 16; i += 8 * NL * XK_RES_THREADS) a.sync_next[i] = 0u;
     const bool stamp = a.dbg && lidx == 0 && tid == 0;
     for (int k = 0; k < npanels && ok; ++k) {
       const int trail = max(0, a.C1 - 16 * k - 16);
-      const int lchalf = max(4, 4 * ((trail + 31) / 32));    // trailing columns per workgroup: all 8 share the range
+      const int lchalf = max(4, 4 * ((trail + 32 * NL - 1) / (32 * NL)));   // trailing columns per workgroup: all 8 NL share the range
       const int lsplit = max(1, (trail + lchalf - 1) / lchalf);
       if (lidx >= lsplit) continue;
       if (stamp) a.dbg[8 * k + 6] = wall_clock64();

@@ -53,6 +53,8 @@ struct XkFeatArgs {
   int *tile_rows;       // rows of tile k that hold data (0 = skip)
   int *inlier;
   double *gamma;
+  int *inlier_h;     // optional mirrors of the two in PINNED HOST memory (device-visible address): the host reads the gate
+  double *gamma_h;   // results in place after its next synchronisation instead of queueing copies behind an event
   double *gpf;       // [K][3] triangulated landmark, world frame
   int *gn_iters;     // [K]
   // multi-agent MSCKF (msckf_update.cpp:201-203,439-443): use a landmark triangulated elsewhere and
@@ -839,6 +841,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu
     a.gamma[k] = scal[13];
     a.inlier[k] = inl ? 1 : 0;
     a.tile_rows[k] = inl ? d : 0;
+    if (a.inlier_h) { a.gamma_h[k] = scal[13]; a.inlier_h[k] = inl ? 1 : 0; }
   }
   if (a.up_out) {
     // rows 0..2 of Q^T [J | Hf | res]   (msckf_update.cpp:439-443)

@@ -537,13 +537,17 @@ __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
 //   P_vi <- P_vi F^T, from the stored P_vi as the reference insists (one thread per row)      P_vv untouched.
 // Every output strip depends only on the same strip of the input, so nothing is read after it was overwritten.
 // (As a sparse congruence with J = blkdiag(F, I) the 225 core entries each walked 225 dependent loads: 39 us.)
+// f_d and q_d (3.6 KB) travel IN the kernel arguments: no staging copy, no blit kernel in front of the propagation
 struct XkPropArgs {
   double *P;
   int n;
-  const double *FQ;   // f_d then q_d, 15 x 15 column-major each
+  double FQ[450];     // f_d then q_d, 15 x 15 column-major each
 };
-__global__ __launch_bounds__(256) void xk_cov_propagate_k(XkPropArgs a) {
+__global__ __launch_bounds__(256) void xk_cov_propagate_k(XkPropArgs a_) {
   __shared__ double Fs[225], Ts[225];
+  // (indexed per lane, so read through the kernarg segment pointer: a by-value array indexed dynamically would be copied
+  //  to scratch first)
+  const XkPropArgs __attribute__((address_space(4))) &a = *(const XkPropArgs __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
   const int t = threadIdx.x, n = a.n;
   if (t < 225) Fs[t] = a.FQ[t];
   if (blockIdx.x == 0) {
