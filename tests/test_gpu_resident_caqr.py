@@ -92,3 +92,33 @@ def test_resident_launch_that_gives_up_is_redone_by_the_multi_launch_schedule(xk
     r2 = eng.visual_update_staged(sc["sigma_img"])
     assert rel(eng.download_P(), ref["P"]) <= 1e-8 and rel(r2["correction"], ref["correction"]) <= 1e-6
     eng.close()
+
+
+def test_tracks_staged_in_place_give_the_same_update(xk, oracle_c):
+    """xk_stage_tracks_begin / _end (the CSR lists are built IN the engine's pinned staging memory) against xk_stage_tracks on
+    the same scenario, and the misuse the header rules out: a last offset that disagrees with n_obs, _end without _begin."""
+    import ctypes as C
+    sc = synth.make_scenario(12, 60, 0, seed=911, track_len=(2, 12))
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    eng = xk.Engine(N, 0, K)
+    eng.stage(sc)
+    ra = eng.visual_update_staged(sc["sigma_img"])
+    Pa = eng.download_P()
+    eng.stage(sc)                                                  # window, SLAM (none) and prior again, then the tracks in place
+    off = np.asarray(sc["trk_off"], np.int32)
+    obs = np.ascontiguousarray(sc["obs_xy"], np.float64).ravel()
+    po, px = C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    assert eng.L.xk_stage_tracks_begin(eng.h, C.c_int(K), C.c_int(int(off[-1])), C.byref(po), C.byref(px)) == 0
+    C.memmove(po, off.ctypes.data, off.nbytes)
+    C.memmove(px, obs.ctypes.data, obs.nbytes)
+    assert eng.L.xk_stage_tracks_end(eng.h) == 0
+    rb = eng.visual_update_staged(sc["sigma_img"])
+    assert np.array_equal(ra["inlier"], rb["inlier"]) and np.array_equal(ra["correction"], rb["correction"])
+    assert np.array_equal(Pa, eng.download_P())
+    ref = oracle_c.visual_update(sc)
+    assert rel(Pa, ref["P"]) <= 1e-8
+    assert eng.L.xk_stage_tracks_end(eng.h) != 0                   # nothing begun
+    assert eng.L.xk_stage_tracks_begin(eng.h, C.c_int(K), C.c_int(int(off[-1]) + 1), C.byref(po), C.byref(px)) == 0
+    C.memmove(po, off.ctypes.data, off.nbytes)
+    assert eng.L.xk_stage_tracks_end(eng.h) != 0                   # trk_off[K] != n_obs
+    eng.close()
