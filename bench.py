@@ -351,7 +351,8 @@ def main():
         roof = {"bound": "fp64-valu/latency",
                 "bound_note": "compute-side roofline (the compulsory HBM traffic of an update is < 1 MB); the QR kernels are Householder "
                               "steps on the vector pipe -- fp64 vector and matrix peaks are the same 78.6 TFLOP/s on MI355X -- and what "
-                              "binds them is the dependent chain of reflector steps and launch boundaries, not flops or bytes",
+                              "binds them is the dependent chain of reflector steps and the hand-offs between merge levels (launch boundaries in "
+                              "the multi-launch schedule), not flops or bytes",
                 "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
                 "measured_ceiling": {"v_fma_f64": ceil_fma, "v_mfma_f64_16x16x4": ceil_mfma,
                                      "frac_of_fma_ceiling": (ach / ceil_fma) if ceil_fma else None},
@@ -359,7 +360,9 @@ def main():
                 "traffic_note": "bytes between the L2s and the fabric per update, QR kernels, PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE from "
                                 f"profiles/{ROUND_TAG}_pmc_traffic.json; Infinity-Cache hits are included (no counter separates them)",
                 "pmc_file": pmc_state, "per_kernel": per_kernel,
-                "kernel": "+".join(qr_keys) + " (Householder QR compression of the stacked [H|res])",
+                "kernel": ("xk_caqr_resident (Householder QR compression of the stacked [H|res]: ONE launch, the row stack resident in "
+                           "registers; stage keys " + "+".join(qr_keys) + ")") if tm.get("n_levels") == 1 else
+                          "+".join(qr_keys) + " (Householder QR compression of the stacked [H|res], multi-launch CAQR)",
                 "alg_flops_per_update": f_qr, "rows_stacked": rows, "stage_ms": qr_ms,
                 "launches_per_update": sum(st[k]["launches"] for k in qr_keys),
                 "dominant_kernel_by_time": dom[0], "dominant_kernel_ms": dom[1]["ms"],
