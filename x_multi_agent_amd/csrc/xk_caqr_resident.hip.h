@@ -31,6 +31,9 @@
 #ifndef XK_RES_NPARK
 #define XK_RES_NPARK 6              // tile registers parked in LDS across a merge call (see the kernel)
 #endif
+#ifndef XK_RES_CHAINWAVE
+#define XK_RES_CHAINWAVE 0
+#endif
 #ifndef XK_RES_LOOKAHEAD
 #define XK_RES_LOOKAHEAD 1          // one-reflector look-ahead steps (xk_caqr_steps_la); 0 = the plain steps, for A/B builds
 #endif
@@ -95,6 +98,10 @@ __device__ __forceinline__ void xk_res_msteps_b(double (&b)[RPL], int rel, bool 
 #undef XK_IT
   if (nsteps == 16) xk_caqr_apply<15, 16, RPL>(b, rel, live, part, ubuf, sc);
 }
+
+#if XK_RES_CHAINWAVE
+#include "xk_caqr_chainwave.hip.h"   // experiment, measured and rejected (see that file)
+#endif
 
 // first merge level of one group, 16 lanes per column (lane p = row p of every strip, register s = strip s, register
 // NS = the pending strip): 16 panel + 32 trailing columns per workgroup.  Strips come from S / PB1, the root goes to
@@ -308,7 +315,11 @@ __global__ __launch_bounds__(XK_RES_THREADS) void xk_caqr_resident(XkCaqrResiden
       }
       const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
       if (stamp) a.dbg[256 + 8 * k + 0] = wall_clock64();
-#if XK_RES_LOOKAHEAD
+#if XK_RES_CHAINWAVE
+      // (wave 0's columns are finished from panel 1 on: it is the chain wave; panel 0 has no idle wave)
+      if (k > 0) xk_cw_steps<RPL>(b, rel, mine, part, nsteps, (tid >> 6) == 0, tid & 63, ubuf, sc);
+      else xk_caqr_steps_la<4, RPL>(b, rel, mine, part, nsteps, (rel >> 4) == 0, ubuf, sc);
+#elif XK_RES_LOOKAHEAD
       xk_caqr_steps_la<4, RPL>(b, rel, mine, part, nsteps, (rel >> 4) == 0, ubuf, sc);
 #else
       xk_caqr_steps<4, RPL>(b, rel, mine, part, nsteps, ubuf, sc);
