@@ -25,6 +25,9 @@
 
 #include "xk_linalg.hip.h"
 
+#ifndef XK_SPIN_SLEEP
+#define XK_SPIN_SLEEP 8            // s_sleep argument between two polls of a flag (x 64 clocks)
+#endif
 #define XK_PERSIST_MAXP 32          // panels per launch (C1 <= 512)
 #define XK_PERSIST_MAXG 16          // first-level groups = strips of the last level
 #define XK_PERSIST_THREADS 768
@@ -94,7 +97,7 @@ __device__ __forceinline__ bool xk_spin_ge(unsigned *p, unsigned target, unsigne
       if (__hip_atomic_load(abort_, XK_RLX_AGENT)) return false;
       if (wall_clock64() - t0 > 20000000LL) break;      // 100 MHz ticks
     }
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(XK_SPIN_SLEEP);
   }
   __hip_atomic_store(abort_, reason, XK_RLX_AGENT);
   return false;

@@ -60,7 +60,9 @@ struct XkGemmArgs {
   long scx;
 };
 
+#ifndef XK_GEMM_WAVES
 #define XK_GEMM_WAVES 4
+#endif
 __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) {
   // One 16 x 16 output tile per workgroup, K split over XK_GEMM_WAVES waves (these GEMMs are a few MFLOP each and pure
   // latency: with one wave per tile the 45 dependent MFMA steps of K = 180 and their three rounds of operand loads were
