@@ -134,9 +134,10 @@ def cpu_baseline(sc, budget_s=20.0):
         pinned = False
     times = []
     t_start = time.perf_counter()
+    ref = None
     for i in range(3 + 20):
         t0 = time.perf_counter()
-        c_oracle.visual_update(sc, library=L)
+        ref = c_oracle.visual_update(sc, library=L)
         dt = time.perf_counter() - t0
         if i >= 3:
             times.append(dt)
@@ -188,6 +189,7 @@ def cpu_baseline(sc, budget_s=20.0):
                            "note": "independent agents, one process per core, 3 updates each, slowest worker's time"}
     except Exception as e:
         out["all_core"] = {"error": str(e)[:200]}
+    out["_ref"] = ref          # the oracle's posterior on these inputs: main() turns it into the line's `parity` block
     return out
 
 
@@ -372,6 +374,12 @@ def main():
                                  "frac": f_alg / (tm["total_ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                 "stages_ms": {k: v["ms"] for k, v in st.items() if v["launches"]},
                 "dtype_peak_note": "fp64 dense peak, vector = matrix = 78.6 TFLOP/s (AMD public MI355X spec)"}
+        # what the device path computes on these inputs (untimed; checked against the CPU baseline's result below)
+        gpu_res = None
+        if world == 1 and not args.no_cpu:
+            eng.stage(sc)
+            gpu_res = eng.visual_update_staged(sigma)
+            gpu_res["P"] = eng.download_P()
         fl = None
         if world == 1 and not args.no_frame_loop and args.config in (1, 3, 4):
             eng.close()                       # the mirror creates its own handle
@@ -379,8 +387,18 @@ def main():
             if fl and "ms_per_frame" in fl:
                 fl["ratio_to_replay"] = fl["ms_per_frame"] / (1e3 * dt / args.steps)
         cpu = None
+        parity = None
         if world == 1 and not args.no_cpu:
             cpu = cpu_baseline(sc)
+            ref = cpu.pop("_ref", None)
+            if ref is not None and gpu_res is not None:
+                def _rel(a, b):
+                    nb = float(np.linalg.norm(b))
+                    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / nb) if nb > 0 else float(np.linalg.norm(a))
+                parity = {"rel_dP_fro": _rel(gpu_res["P"], ref["P"]), "rel_dcorrection": _rel(gpu_res["correction"], ref["correction"]),
+                          "inlier_masks_identical": bool(np.array_equal(gpu_res["inlier"], ref["inlier"])),
+                          "inliers": int(np.sum(ref["inlier"])), "bar_rel_dP": 1e-6,
+                          "checker": "oracle/xk_oracle.c on the same inputs (the cpu_baseline leg's result; parity unpinned, DESIGN 5)"}
         value = world * args.steps / dt
         out = {"metric": "EKF updates/sec (window=30, 400 MSCKF feats)" if args.config in (4, 5)
                else f"EKF updates/sec (config {args.config})",
@@ -395,7 +413,7 @@ def main():
                           "ci_every": ci_every, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
                           "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"],
                           **({"keyframes_received_rank0": ci_stats.get("keyframes_received", 0)} if args.config == 5 else {})},
-               "roofline": roof, "frame_loop": fl, "cpu_baseline": cpu,
+               "roofline": roof, "frame_loop": fl, "parity": parity, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
         print(json.dumps(out), flush=True)
     try:
