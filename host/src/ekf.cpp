@@ -13,22 +13,32 @@ namespace {
 void check(xk_handle *h, int rc, const char *what) {
   if (rc != XK_OK) throw std::runtime_error(std::string(what) + ": " + xk_strerror(rc) + " (" + (h ? xk_last_error(h) : "") + ")");
 }
-// c = a b, skipping the structural zeros of a (f_d is the identity plus nine 3 x 3 blocks: ~100 of 225 entries)
-CoreCovMatrix mul15(const CoreCovMatrix &a, const CoreCovMatrix &b) {
+// 15 x 15 products for composing IMU steps, column-major with the inner loop down a column (contiguous: the compiler
+// vectorises it; the earlier version skipped the structural zeros of f_d entry by entry with a strided inner loop and
+// was three times slower).  b's zeros are skipped per entry (f_d on the right is ~55 % zeros).
+CoreCovMatrix mul15(const CoreCovMatrix &a, const CoreCovMatrix &b) {          // a b
   CoreCovMatrix c = CoreCovMatrix::Zero();
-  for (int k = 0; k < 15; ++k)
-    for (int i = 0; i < 15; ++i) {
-      const double aik = a(i, k);
-      if (aik == 0.0) continue;
-      for (int j = 0; j < 15; ++j) c(i, j) += aik * b(k, j);
+  for (int j = 0; j < 15; ++j)
+    for (int k = 0; k < 15; ++k) {
+      const double bkj = b.m[k + 15 * j];
+      if (bkj == 0.0) continue;
+      const double *ak = a.m + 15 * k;
+      double *cj = c.m + 15 * j;
+      for (int i = 0; i < 15; ++i) cj[i] += ak[i] * bkj;
     }
   return c;
 }
-CoreCovMatrix transpose15(const CoreCovMatrix &a) {
-  CoreCovMatrix t;
-  for (int i = 0; i < 15; ++i)
-    for (int j = 0; j < 15; ++j) t(i, j) = a(j, i);
-  return t;
+CoreCovMatrix mul15_nt(const CoreCovMatrix &a, const CoreCovMatrix &b) {       // a b^T
+  CoreCovMatrix c = CoreCovMatrix::Zero();
+  for (int j = 0; j < 15; ++j)
+    for (int k = 0; k < 15; ++k) {
+      const double bjk = b.m[j + 15 * k];
+      if (bjk == 0.0) continue;
+      const double *ak = a.m + 15 * k;
+      double *cj = c.m + 15 * j;
+      for (int i = 0; i < 15; ++i) cj[i] += ak[i] * bjk;
+    }
+  return c;
 }
 }  // namespace
 
@@ -143,8 +153,7 @@ bool Ekf::advanceDeviceCovariance(int idx) {
     // Q_tot = sum_j (F_k ... F_{j+1}) Q_j (.)^T; P_iv <- Phi P_iv likewise.  15 x 15 products on the host, one launch.
     CoreCovMatrix phi = CoreCovMatrix::Identity(), qt = CoreCovMatrix::Zero();
     for (int i = (cov_idx_ + 1) % sz, s = 0; s < steps; i = (i + 1) % sz, ++s) {
-      // F Q F^T = (F (F Q)^T)^T: both products have the sparse f_d on the left
-      const CoreCovMatrix fq = transpose15(mul15(f_d_[i], transpose15(mul15(f_d_[i], qt))));
+      const CoreCovMatrix fq = mul15_nt(mul15(f_d_[i], qt), f_d_[i]);                    // F Q F^T
       for (int k = 0; k < 225; ++k) qt.m[k] = fq.m[k] + q_d_[i].m[k];
       phi = mul15(f_d_[i], phi);
     }

@@ -136,14 +136,14 @@ CoreCovMatrix Propagator::discreteProcessNoiseCov(double dt, const Quaternion &q
   for (int k = 0; k < 6; ++k) {
     const double t = 0.5 * dt * (gx[k] + 1.0), wk = 0.5 * dt * gw[k];
     const CoreCovMatrix F = discreteStateTransition(t, e_w, e_a, q);
-    double Fd[9][15];
+    double Fd[9][16], Fr[9][16];                                       // rows of F, contiguous in l (F itself is column-major)
     for (int i = 0; i < 9; ++i)
-      for (int l = 3; l < 15; ++l) Fd[i][l] = F(i, l) * dg[l];
+      for (int l = 3; l < 15; ++l) { Fr[i][l] = F(i, l); Fd[i][l] = Fr[i][l] * dg[l]; }
     for (int i = 0; i < 9; ++i) {
       for (int j = i; j < 9; ++j) {
         const int lo = (j >= 6) ? 6 : 3, hi = (j >= 6) ? 12 : 15;   // attitude rows: columns theta, b_w only
         double s = 0.0;
-        for (int l = lo; l < hi; ++l) s += Fd[i][l] * F(j, l);
+        for (int l = lo; l < hi; ++l) s += Fd[i][l] * Fr[j][l];
         Q(i, j) += wk * s;
       }
       for (int j = 9; j < 15; ++j) Q(i, j) += wk * Fd[i][j];          // F(j, :) = e_j for the bias rows
