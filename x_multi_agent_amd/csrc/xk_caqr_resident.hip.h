@@ -210,16 +210,20 @@ __device__ __noinline__ bool xk_resident_last(XkResidentArgsPtr ap, int k, int s
   if (lst) lst[1] = wall_clock64();
   // (Looking for the second flag two steps early and starting these loads into spare registers behind steps 6 and 7 was
   //  measured: the first half went from 8.8 to 10.5 us, the second from 9.0 to 4.5, the kernel from 0.414 to 0.428 ms.)
-  if (threadIdx.x == 0) *s_ok = xk_spin_ge(a.sync + (XK_PS_X1FLAG + k) * 16, 1u, ab, 5u) ? 1u : 0u;
-  __syncthreads();
-  if (!*s_ok) return false;
-  if (lst) lst[2] = wall_clock64();
-  if (mine && part >= 8) {
+  // (a panel of <= 8 columns is the last one and has no trailing columns: rows 8..15 of its roots are structurally zero,
+  //  there is no second half to wait for -- 4 us of the kernel's tail)
+  if (nsteps > 8) {
+    if (threadIdx.x == 0) *s_ok = xk_spin_ge(a.sync + (XK_PS_X1FLAG + k) * 16, 1u, ab, 5u) ? 1u : 0u;
+    __syncthreads();
+    if (!*s_ok) return false;
+    if (lst) lst[2] = wall_clock64();
+    if (mine && part >= 8) {
 #pragma unroll
-    for (int s = 0; s < RPL; ++s)
-      b[s] = panel ? xk_ld_sc1(a.X1P + (slab + s) * 256 + part * 16 + cidx) : xk_ld_sc1(a.X1 + ((slab + s) * 16 + part) * a.C1P + col);
+      for (int s = 0; s < RPL; ++s)
+        b[s] = panel ? xk_ld_sc1(a.X1P + (slab + s) * 256 + part * 16 + cidx) : xk_ld_sc1(a.X1 + ((slab + s) * 16 + part) * a.C1P + col);
+    }
+    xk_res_msteps_b<RPL>(b, cidx, mine, part, nsteps, ubuf, sc, nullptr, nullptr, 0u);
   }
-  xk_res_msteps_b<RPL>(b, cidx, mine, part, nsteps, ubuf, sc, nullptr, nullptr, 0u);
   if (panel) __builtin_amdgcn_s_setprio(0);
   if (lst) lst[3] = wall_clock64();
   if (!mine) return true;
