@@ -88,16 +88,23 @@ if pmc:
             e["mfma_busy_over_sq_busy"] = (g("SQ_VALU_MFMA_BUSY_CYCLES") or 0.0) / g("SQ_BUSY_CYCLES")
         if g("SQ_WAVE_CYCLES"):
             e["wait_any_pct_of_wave_cycles"] = 100.0 * (g("SQ_WAIT_ANY") or 0.0) / g("SQ_WAVE_CYCLES")
+            # vector-pipe activity per wave cycle, normalised below by xk_probe_fma (back-to-back v_fma_f64 = 100 %)
+            e["valu_active_over_wave_cycles"] = (g("SQ_ACTIVE_INST_VALU") or 0.0) / g("SQ_WAVE_CYCLES")
         if g("TCC_HIT_sum") is not None and (g("TCC_HIT_sum") + (g("TCC_MISS_sum") or 0)) > 0:
             e["l2_hit_pct"] = 100.0 * g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
         per_kernel[k] = e
     sat = per_kernel.get("xk_probe_mfma", {}).get("mfma_busy_over_sq_busy")
+    satv = per_kernel.get("xk_probe_fma", {}).get("valu_active_over_wave_cycles")
     for k, e in per_kernel.items():
         if sat and "mfma_busy_over_sq_busy" in e:
             e["mfma_util_pct"] = 100.0 * e["mfma_busy_over_sq_busy"] / sat
+        if satv and "valu_active_over_wave_cycles" in e:
+            e["valu_util_pct_of_resident_waves"] = 100.0 * e["valu_active_over_wave_cycles"] / satv
     res = {"note": "FETCH_SIZE/WRITE_SIZE are in KiB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts 64 B per 128-B request "
                    "(MI355X_MICROARCH.md HBM section) -> fetch bytes corrected = 2x.  Both count requests from the L2 to the fabric: "
-                   "Infinity-Cache (MALL) hits are included, no counter on this stack separates them from HBM accesses.",
+                   "Infinity-Cache (MALL) hits are included, no counter on this stack separates them from HBM accesses.  "
+                   "valu_util_pct_of_resident_waves = SQ_ACTIVE_INST_VALU per SQ_WAVE_CYCLES relative to xk_probe_fma (waves that do nothing but "
+                   "dependent v_fma_f64): how busy a RESIDENT wave keeps the vector pipe, not a chip-level utilisation.",
            "csrc_sha16": csrc_sha16(), "config": int(cfg), "updates_in_run": updates, "per_kernel": per_kernel, "kernels": pmc}
     qr = [k for k in pmc if "caqr" in k]
     f = sum(pmc[k].get("FETCH_SIZE", {}).get("sum", 0.0) for k in qr) * 1024.0
