@@ -15,12 +15,17 @@
 //     chip instead of ~30 MB), XCD-local.
 //   * XCD x = 31 tile workgroups (two first-level groups of 16 / 15 strips) + ONE workgroup for the last merge level,
 //     which therefore has a CU of its own next to the tile steps.  First-level merges run on 16 lanes per column with
-//     16 panel + 32 trailing columns per workgroup (768 threads, 168 VGPRs), at most one item per CU.
+//     16 panel + 8..32 trailing columns per item (as few as keeps the items of a group within its workgroups), at most
+//     one item per CU; the last level runs in two halves, the first beside the second half of the first level (the
+//     strips of a merge are upper triangular in the panel columns: its steps 0..7 need rows 0..7 of the roots only).
+//   * Steps with a one-reflector look-ahead (xk_linalg.hip.h: xk_caqr_steps_la, xk_caqr_form / xk_caqr_apply).
 //   * Group leaders: the root strip leaves for the last level (X1) and comes back one panel later as the pending strip
 //     (X2 -> first level -> Hq).  Meanwhile the leader needs another pivot strip in the registers of its part-0 lanes:
 //     it swaps registers 0..15 of its part-0 and part-1 lanes (one quad-permute DPP move per register) and zeroes the
 //     "away" half until the returned rows are loaded into it.
-// Synchronisation, placement census, bounded spins and the cross-XCD slabs are those of xk_caqr_persist.hip.h.
+// Synchronisation primitives, bounded spins and the cross-XCD slabs are those of xk_caqr_persist.hip.h; the placement census
+// does not wait for the whole grid, and the sync words are double-buffered (a launch zeroes the set its successor uses).
+// DESIGN 3.2.1 has the anatomy, what made it fast and what was tried and rejected.
 #pragma once
 #include <hip/hip_runtime.h>
 
