@@ -46,7 +46,7 @@ def test_resident_equals_multi_launch(xk, oracle_c, name):
     sc = CASES[name]()
     ra, Pa, ta = _run(xk, sc, True)
     rb, Pb, tb = _run(xk, sc, False)
-    assert ta["n_levels"] == 1 and ta["n_leaf"] == 248, "the resident path did not run"
+    assert ta["n_levels"] == 1 and ta["n_leaf"] in (184, 248), "the resident path did not run"
     assert tb["n_levels"] > 1
     assert np.array_equal(ra["inlier"], rb["inlier"])
     assert rel(Pa, Pb) <= 1e-11 and rel(ra["correction"], rb["correction"]) <= 1e-9
@@ -63,7 +63,7 @@ def test_resident_path_steps_aside_when_it_does_not_apply(xk):
         eng = xk.Engine(N, M, K)
         eng.stage(sc)
         t = eng.bench_staged(sc["sigma_img"], 0, 1)
-        assert t["n_leaf"] != 248
+        assert t["n_leaf"] not in (184, 248)
         eng.close()
 
 
@@ -87,7 +87,7 @@ def test_resident_launch_that_gives_up_is_redone_by_the_multi_launch_schedule(xk
     assert rel(r["correction"], ref["correction"]) <= 1e-6
     eng.stage(sc)                                   # the same handle again: multi-launch from now on
     t = eng.bench_staged(sc["sigma_img"], 0, 1)
-    assert t["n_leaf"] != 248
+    assert t["n_leaf"] not in (184, 248)
     eng.stage(sc)
     r2 = eng.visual_update_staged(sc["sigma_img"])
     assert rel(eng.download_P(), ref["P"]) <= 1e-8 and rel(r2["correction"], ref["correction"]) <= 1e-6

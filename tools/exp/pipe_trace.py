@@ -1,0 +1,48 @@
+"""The pipelined register-resident CAQR (xk_caqr_pipe, XK_CAQR_PIPE=1) at a given config: parity against the multi-launch
+schedule and the round-2 resident kernel, stage times, per-panel phase spans of one tile / first-level / last-level
+workgroup (XK_CAQR_PERSIST_DBG=1)."""
+import ctypes as C, os, sys, subprocess
+sys.path.insert(0, '.')
+os.environ.setdefault("XK_CAQR_PERSIST_DBG", "1")
+import numpy as np
+from x_multi_agent_amd import engine, synth
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+mode = sys.argv[2] if len(sys.argv) > 2 else "pipe"
+if mode == "multi": os.environ["XK_CAQR_RESIDENT"] = "0"
+if mode == "resident": os.environ["XK_CAQR_PIPE"] = "0"
+sc = synth.make_config(cfg)
+N = sc["n_poses_max"]; K = len(sc["trk_off"]) - 1
+eng = engine.Engine(N, 0, K)
+got = eng.visual_update(sc)
+t = eng.bench_staged(sc["sigma_img"], 3, 20)
+print(mode + ":", {k: round(v["ms"], 4) for k, v in t["stages"].items() if v["ms"] > 0}, "total", round(t["total_ms"], 4), "launches", t["n_levels"], "leaves", t["n_leaf"], flush=True)
+if mode == "pipe":
+    NW = 2048
+    out = (C.c_longlong * NW)()
+    eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
+    w = np.array(list(out), dtype=np.int64)
+    T = w[:512].reshape(32, 16); M = w[512:1024].reshape(32, 16); L = w[1024:1536].reshape(32, 16)
+    npan = (6 * N + 1 + 15) // 16
+    t0 = T[0, 0]
+    us = lambda x: x / 100.0
+    print("tile workgroup (XCD 0, slot 1), us: steps 0..7 | rows 0..7 stored + steps 8..15 | stores + arrive | wait for the strips | reload || panel total | cumulative")
+    for k in range(npan):
+        r = T[k]
+        nxt = T[k + 1, 0] if k + 1 < npan else r[3]
+        print(f"{k:3d}  {us(r[1]-r[0]):5.2f} {us(r[2]-r[1]):5.2f} {us(r[3]-r[2]):5.2f} {us(r[4]-r[3]):5.2f} {us(r[5]-r[4]):5.2f} || {us(nxt-r[0]):6.2f} | {us(nxt-t0):7.2f}")
+    print("first level (XCD 0, item 0), us after the tile step of the panel started: rows 0..7 seen | loaded | steps 0..7 + publish | rows 8..15 seen | steps 8..15 done | stored + arrived")
+    for k in range(npan):
+        print(f"{k:3d}  " + "  ".join(f"{us(M[k,i]-T[k,0]):6.2f}" for i in range(6)))
+    print("last level (XCD 7), us after the tile step of the panel started: roots 0..7 seen | steps 0..7 | roots 8..15 seen | steps 8..15 | out")
+    for k in range(npan):
+        print(f"{k:3d}  " + "  ".join(f"{us(L[k,i]-T[k,0]):6.2f}" for i in range(5)))
+    print(f"start-up: entry -> rows gathered {us(w[1537]-w[1536]):.2f} us; tile workgroup leaves {us(w[1538]-w[1536]):.2f} us after its entry, last level {us(w[1539]-w[1536]):.2f} us")
+    np.save("/tmp/pipe_P.npy", got["P"]); np.save("/tmp/pipe_c.npy", got["correction"])
+    eng.close()
+    for m in ("resident", "multi"):
+        r = subprocess.run([sys.executable, __file__, str(cfg), m], capture_output=True, text=True)
+        print((r.stdout.strip() or r.stderr.strip()[-400:]))
+else:
+    P = np.load("/tmp/pipe_P.npy"); c = np.load("/tmp/pipe_c.npy")
+    print(f"   pipe vs {mode}: rel dP {np.linalg.norm(P-got['P'])/np.linalg.norm(got['P']):.2e} rel dcorr {np.linalg.norm(c-got['correction'])/np.linalg.norm(got['correction']):.2e}")

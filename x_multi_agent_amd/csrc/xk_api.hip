@@ -18,6 +18,7 @@
 #include "xk_linalg.hip.h"
 #include "xk_caqr_persist.hip.h"
 #include "xk_caqr_resident.hip.h"
+#include "xk_caqr_pipe.hip.h"
 #include "xk_ci.hip.h"
 
 #define XK_VERSION_NUM 200
@@ -51,12 +52,17 @@ struct xk_handle {
   double *d_x1, *d_x1p, *d_x2;
   // register-resident single-launch CAQR (xk_caqr_resident.hip.h)
   double *d_rs, *d_rpb, *d_rhq;
+  // pipelined register-resident CAQR (xk_caqr_pipe.hip.h): the last level's panel-column slab, its own sync words
+  double *d_pon;
+  unsigned *d_xsync;
+  int xsync_phase;
   int *d_rowmap;
   int rowmap_R;            // valid rows the device row map describes (-1: stale)
   std::vector<int> *h_rowlens;   // track lengths the row map was built for
   unsigned *d_psync;    // TWO sets of sync words: a resident launch uses one and zeroes the other for the next launch
   int psync_phase;
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
+  bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
   bool psync_dirty;     // somebody else (the persist experiment) used set 0: clear both before the next resident launch
   long long *d_pdbg;
   long long *feat_dbg;  // probe builds only: per-workgroup phase stamps of xk_msckf_feature
@@ -232,6 +238,11 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_RES_NT * 256));
       HIPCHK(h, dalloc(&h->d_rhq, (size_t)XK_PERSIST_MAXG * 16 * h->C1P));
       HIPCHK(h, dalloc(&h->d_rowmap, (size_t)8 * XK_RES_NT * 4 * XK_RES_RPL));
+      static_assert(XK_PIPE_NT * XK_PIPE_RPL <= XK_RES_NT * XK_RES_RPL && XK_PIPE_NT <= XK_RES_NT, "the pipelined kernel shares the resident kernel's strip and row-map buffers");
+      HIPCHK(h, dalloc(&h->d_pon, (np + 1) * 8 * 256));
+      HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
+      HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
+      h->xsync_phase = 0;
       h->rowmap_R = -1;
       h->h_rowlens = new std::vector<int>();
       HIPCHK(h, dalloc(&h->d_pdbg, (size_t)256 + 64 * 256));
@@ -310,7 +321,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_fq) hipFree(h->d_fq);
-  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rhq, (void *)h->d_rowmap})
+  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rhq, (void *)h->d_rowmap, (void *)h->d_pon, (void *)h->d_xsync})
     if (p4) hipFree(p4);
   delete h->h_rowlens;
   for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
@@ -741,6 +752,32 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
         if (hipMemcpyAsync(h->d_rowmap, st, sizeof(int) * (size_t)R, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "row map");
         h->rowmap_R = R;
       }
+    }
+    // pipelined schedule (xk_caqr_pipe.hip.h): 184 fat tiles of <= 128 rows, the merge levels on workgroups of their own
+    const int pipe_env = env_int("XK_CAQR_PIPE", 1);
+    const int NTP = 8 * XK_PIPE_NT;
+    if (pipe_env && h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTP - 1) / NTP <= 4 * XK_PIPE_RPL) {
+      XkCaqrPipeArgs pa;
+      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.rowmap = h->d_rowmap; pa.R = h->rowmap_R; pa.TR = (h->rowmap_R + NTP - 1) / NTP;
+      pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
+      pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.ON = h->d_pon; pa.status = h->d_status;
+      pa.sync = h->d_xsync + (size_t)h->xsync_phase * XP_WORDS * 16;
+      pa.sync_next = h->d_xsync + (size_t)(h->xsync_phase ^ 1) * XP_WORDS * 16;
+      h->xsync_phase ^= 1;
+      if (env_int("XK_CAQR_RESIDENT_POISON", 0)) {
+        const unsigned seven = 7u;
+        if (hipMemcpyAsync(pa.sync + XP_ABORT * 16, &seven, sizeof(unsigned), hipMemcpyHostToDevice, h->stream) != hipSuccess)
+          return fail(h, XK_EDEVICE, "poison");
+        hipStreamSynchronize(h->stream);
+      }
+      static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
+      pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
+      hipLaunchKernelGGL(xk_caqr_pipe, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      if (mid) hipEventRecord(mid, h->stream);
+      h->nleaf = NTP; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = true;
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
+      return XK_OK;
     }
     const int NTL = 8 * XK_RES_NT;
     if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTL - 1) / NTL <= 4 * XK_RES_RPL) {
