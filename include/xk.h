@@ -346,6 +346,15 @@ int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_ti
  * them; nothing crosses PCIe.  This is the timed region of bench.py. */
 int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 
+/* Which schedule compressed the last update -- 0 the multi-launch CAQR, 1 the register-resident single launch (round 2), 2 the
+ * pipelined single launch -- whether the single-launch path is armed for the next update, how many launches have given up on
+ * this handle so far (workgroups not co-resident: another process on the GPU, a CU mask) and the reason code of the last one
+ * (2 XCD-local hand-off, 3 uneven XCD placement, 4 / 5 / 6 waiting for the last level / the roots / the tiles).  A launch that
+ * gives up costs one bounded retry (<= 2 ms) and the update is redone by the multi-launch schedule with the same result; the
+ * handle tries the fast path again after XK_CAQR_REARM (64) clean updates, doubling that distance at every further give-up.
+ * xk_last_error() carries the same information as text.  Any pointer may be NULL. */
+int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason);
+
 /* Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST=1 XK_CAQR_PERSIST_DBG=1): per panel k,
  * out[8k + 0..5] = one tile-owning workgroup (tile step start / end, after the XCD barrier, first-level merge start /
  * end, after the second barrier), out[8k + 6..7] = one last-level workgroup; from out[256] on, the same six stamps for

@@ -85,12 +85,45 @@ def test_resident_launch_that_gives_up_is_redone_by_the_multi_launch_schedule(xk
     assert np.array_equal(r["inlier"], ref["inlier"])
     assert rel(eng.download_P(), ref["P"]) <= 1e-8
     assert rel(r["correction"], ref["correction"]) <= 1e-6
-    eng.stage(sc)                                   # the same handle again: multi-launch from now on
+    st = eng.caqr_status()
+    assert st["giveups"] == 1 and st["last_reason"] == 7 and not st["armed"] and st["schedule"] == 0, st
+    eng.stage(sc)                                   # the same handle again: multi-launch for the next XK_CAQR_REARM updates
     t = eng.bench_staged(sc["sigma_img"], 0, 1)
     assert t["n_leaf"] not in (184, 248)
     eng.stage(sc)
     r2 = eng.visual_update_staged(sc["sigma_img"])
     assert rel(eng.download_P(), ref["P"]) <= 1e-8 and rel(r2["correction"], ref["correction"]) <= 1e-6
+    eng.close()
+
+
+def test_fast_path_is_rearmed_after_clean_updates(xk, oracle_c):
+    """A launch that gave up must not cost the fast path for the life of the handle: after XK_CAQR_REARM clean multi-launch
+    updates the single launch is tried again (with its sync words cleared -- the launch that gave up left them mid-count) and,
+    the GPU being free again, stays; a second give-up doubles the distance."""
+    sc = synth.make_config(4)
+    ref = oracle_c.visual_update(sc)
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    os.environ["XK_CAQR_REARM"] = "3"
+    try:
+        eng = xk.Engine(N, 0, K)
+    finally:
+        os.environ.pop("XK_CAQR_REARM", None)
+    sched = []
+    for i in range(8):
+        if i in (0, 6):
+            os.environ["XK_CAQR_RESIDENT_POISON"] = "1"
+        try:
+            eng.stage(sc)
+            r = eng.visual_update_staged(sc["sigma_img"])
+        finally:
+            os.environ.pop("XK_CAQR_RESIDENT_POISON", None)
+        assert np.array_equal(r["inlier"], ref["inlier"])
+        assert rel(eng.download_P(), ref["P"]) <= 1e-8 and rel(r["correction"], ref["correction"]) <= 1e-6, i
+        sched.append(eng.caqr_status()["schedule"])
+    # update 0 gives up -> multi-launch; 1, 2, 3 multi-launch; 4 re-armed: single launch again; 5 likewise; 6 gives up again
+    assert sched[:4] == [0, 0, 0, 0] and sched[4] == 2 and sched[5] == 2 and sched[6] == 0, sched
+    st = eng.caqr_status()
+    assert st["giveups"] == 2 and not st["armed"]
     eng.close()
 
 

@@ -26,17 +26,18 @@ if mode == "pipe":
     npan = (6 * N + 1 + 15) // 16
     t0 = T[0, 0]
     us = lambda x: x / 100.0
-    print("tile workgroup (XCD 0, slot 1), us: steps 0..7 | rows 0..7 stored + steps 8..15 | stores + arrive | wait for the strips | reload || panel total | cumulative")
+    print("tile workgroup (XCD 0, slot 1), us: phase 0 | 1 | 2 | 3 (steps + rows stored) | drain + arrive | wait for the strips | reload || panel total | cumulative")
     for k in range(npan):
         r = T[k]
-        nxt = T[k + 1, 0] if k + 1 < npan else r[3]
-        print(f"{k:3d}  {us(r[1]-r[0]):5.2f} {us(r[2]-r[1]):5.2f} {us(r[3]-r[2]):5.2f} {us(r[4]-r[3]):5.2f} {us(r[5]-r[4]):5.2f} || {us(nxt-r[0]):6.2f} | {us(nxt-t0):7.2f}")
-    print("first level (XCD 0, item 0), us after the tile step of the panel started: rows 0..7 seen | loaded | steps 0..7 + publish | rows 8..15 seen | steps 8..15 done | stored + arrived")
+        nxt = T[k + 1, 0] if k + 1 < npan else r[5]
+        ph = [r[0]] + [x for x in r[1:5] if x > 0]
+        print(f"{k:3d}  " + " ".join(f"{us(ph[i+1]-ph[i]):5.2f}" for i in range(len(ph) - 1)) + f" | {us(r[5]-ph[-1]):5.2f} {us(r[6]-r[5]):5.2f} {us(r[7]-r[6]):5.2f} || {us(nxt-r[0]):6.2f} | {us(nxt-t0):7.2f} | shader clock {(r[9]-r[8])/max(1,(r[10]-r[0]))/10:.2f} GHz")
+    print("first level (XCD 0, item 0), us after the tile step of the panel started: per phase (rows seen, steps done + published) ... | strips stored + arrived")
     for k in range(npan):
-        print(f"{k:3d}  " + "  ".join(f"{us(M[k,i]-T[k,0]):6.2f}" for i in range(6)))
-    print("last level (XCD 7), us after the tile step of the panel started: roots 0..7 seen | steps 0..7 | roots 8..15 seen | steps 8..15 | out")
+        print(f"{k:3d}  " + "  ".join(f"{us(M[k,i]-T[k,0]):6.2f}" for i in range(9) if M[k, i] > 0))
+    print("last level (workgroup 0), us after the tile step of the panel started: per phase (roots seen, steps done) ... | out")
     for k in range(npan):
-        print(f"{k:3d}  " + "  ".join(f"{us(L[k,i]-T[k,0]):6.2f}" for i in range(5)))
+        print(f"{k:3d}  " + "  ".join(f"{us(L[k,i]-T[k,0]):6.2f}" for i in range(9) if L[k, i] > 0))
     print(f"start-up: entry -> rows gathered {us(w[1537]-w[1536]):.2f} us; tile workgroup leaves {us(w[1538]-w[1536]):.2f} us after its entry, last level {us(w[1539]-w[1536]):.2f} us")
     np.save("/tmp/pipe_P.npy", got["P"]); np.save("/tmp/pipe_c.npy", got["correction"])
     eng.close()

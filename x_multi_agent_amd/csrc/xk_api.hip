@@ -52,8 +52,7 @@ struct xk_handle {
   double *d_x1, *d_x1p, *d_x2;
   // register-resident single-launch CAQR (xk_caqr_resident.hip.h)
   double *d_rs, *d_rpb, *d_rhq;
-  // pipelined register-resident CAQR (xk_caqr_pipe.hip.h): the last level's panel-column slab, its own sync words
-  double *d_pon;
+  // pipelined register-resident CAQR (xk_caqr_pipe.hip.h): its own sync words (two sets, like d_psync)
   unsigned *d_xsync;
   int xsync_phase;
   int *d_rowmap;
@@ -69,6 +68,10 @@ struct xk_handle {
   bool attr_slaminit, attr_feat_batch;   // hipFuncSetAttribute done for this handle's device
   int n_cu;
   bool persist_ok;      // cleared when a launch gave up (workgroups not co-resident): the multi-launch schedule takes over
+  bool fast_capable;    // decided at xk_create: 256 CUs, one 768-thread workgroup of the single-launch kernels fits a CU
+  int fast_giveups, fast_reason;   // launches that gave up so far / why the last one did (xk_caqr_status)
+  int clean_classic, rearm_after;  // multi-launch updates since the last give-up / how many of them re-arm the fast path
+  bool xsync_dirty;     // a pipelined launch gave up: its counters are mid-count, clear both sets before the next one
   bool have_rows, have_R;
   double sigma_img;
   // update workspace
@@ -152,6 +155,11 @@ static hipError_t dalloc(T **p, size_t count) {
 static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out);
 extern "C" int xk_destroy(xk_handle *h);
 // (a failure part-way through releases everything allocated so far)
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out) {
   if (!out) return XK_EINVAL;
   *out = nullptr;
@@ -225,7 +233,20 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount;
+    // The single-launch schedules need all 256 workgroups co-resident, one per CU.  Decide what can be decided up front:
+    // the device must expose 256 CUs to this process (SPX mode, no CU mask visible in the properties) and the runtime must
+    // agree that a 768-thread workgroup of each kernel fits a CU; what cannot be known here (another process on the GPU,
+    // a CU mask set behind the runtime's back) is caught by the placement census and the bounded spins inside the launch.
     h->persist_ok = h->DB == 64 && h->C1 <= 192 && h->n_cu == 256;
+    if (h->persist_ok) {
+      int nb1 = 0, nb2 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)xk_caqr_pipe, XK_PIPE_THREADS, 0) != hipSuccess) nb1 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void *)xk_caqr_resident, XK_RES_THREADS, 0) != hipSuccess) nb2 = 0;
+      h->persist_ok = nb1 >= 1 && nb2 >= 1;
+      (void)hipGetLastError();
+    }
+    h->fast_capable = h->persist_ok;
+    h->rearm_after = env_int("XK_CAQR_REARM", 64);
     if (h->persist_ok) {
       const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * XK_PERSIST_MAXG * 16;
       HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
@@ -239,7 +260,6 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_rhq, (size_t)XK_PERSIST_MAXG * 16 * h->C1P));
       HIPCHK(h, dalloc(&h->d_rowmap, (size_t)8 * XK_RES_NT * 4 * XK_RES_RPL));
       static_assert(XK_PIPE_NT * XK_PIPE_RPL <= XK_RES_NT * XK_RES_RPL && XK_PIPE_NT <= XK_RES_NT, "the pipelined kernel shares the resident kernel's strip and row-map buffers");
-      HIPCHK(h, dalloc(&h->d_pon, (np + 1) * 8 * 256));
       HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
       HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
       h->xsync_phase = 0;
@@ -321,7 +341,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_fq) hipFree(h->d_fq);
-  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rhq, (void *)h->d_rowmap, (void *)h->d_pon, (void *)h->d_xsync})
+  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rhq, (void *)h->d_rowmap, (void *)h->d_xsync})
     if (p4) hipFree(p4);
   delete h->h_rowlens;
   for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
@@ -695,11 +715,6 @@ static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_merge<RPL>), dim3(groups, csplit), dim3(16 * (16 + a.chalf)), 0, h->stream, a);
 }
 
-static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 // QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
 static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
@@ -734,6 +749,11 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   int launches = 0;
   // register-resident single launch (xk_caqr_resident.hip.h): MSCKF tracks only, valid rows <= 248 fat tiles of 96
   const int resident_env = env_int("XK_CAQR_RESIDENT", 1);   // (read per call: tests switch it inside one process)
+  if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && h->M == 0 && h->K2 == 0 && h->K > 0 &&
+      ++h->clean_classic > h->rearm_after) {
+    h->persist_ok = true;                         // (the sync words of a launch that gave up are cleared below)
+    h->clean_classic = 0;
+  }
   if (resident_env && h->persist_ok && h->M == 0 && h->K2 == 0 && h->K > 0) {
     // row map: valid row g -> physical row of the 64-row slots (depends on the track lengths only)
     bool same = h->rowmap_R >= 0 && (int)h->h_rowlens->size() == h->K;
@@ -760,7 +780,11 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       XkCaqrPipeArgs pa;
       pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.rowmap = h->d_rowmap; pa.R = h->rowmap_R; pa.TR = (h->rowmap_R + NTP - 1) / NTP;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
-      pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.ON = h->d_pon; pa.status = h->d_status;
+      pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.status = h->d_status;
+      if (h->xsync_dirty) {
+        if (hipMemsetAsync(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
+        h->xsync_dirty = false; h->xsync_phase = 0;
+      }
       pa.sync = h->d_xsync + (size_t)h->xsync_phase * XP_WORDS * 16;
       pa.sync_next = h->d_xsync + (size_t)(h->xsync_phase ^ 1) * XP_WORDS * 16;
       h->xsync_phase ^= 1;
@@ -772,6 +796,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       }
       static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
       pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
+      pa.test_stall = env_int("XK_CAQR_TEST_STALL", 0);
       hipLaunchKernelGGL(xk_caqr_pipe, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       if (mid) hipEventRecord(mid, h->stream);
       h->nleaf = NTP; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = true;
@@ -806,7 +831,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       ra.dbg = rdbg ? h->d_pdbg : nullptr;
       hipLaunchKernelGGL(xk_caqr_resident, dim3(h->n_cu), dim3(XK_RES_THREADS), 0, h->stream, ra);
       if (mid) hipEventRecord(mid, h->stream);
-      h->nleaf = NTL; h->nlevels = 1; h->have_R = true; h->last_resident = true;
+      h->nleaf = NTL; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = false;
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
       return XK_OK;
@@ -838,7 +863,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
     h->nleaf = ntiles;
     h->nlevels = 1;
     h->have_R = true;
-    h->last_resident = true;
+    h->last_resident = true; h->last_pipe = false;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
     return XK_OK;
@@ -948,7 +973,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   h->nleaf = ntiles;
   h->nlevels = launches;
   h->have_R = true;
-  h->last_resident = false;
+  h->last_resident = false; h->last_pipe = false;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
   return XK_OK;
@@ -1087,9 +1112,15 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
   }
   if (pst != 0) {
     // reasons: 1 grid not resident, 2 XCD barrier, 3 uneven XCD placement, 4/5 waiting for the last / first level
+    // The fast path steps aside, but not for the life of the handle: after `rearm_after` clean multi-launch updates it is
+    // tried again (the other tenant of the GPU may be gone); every further give-up doubles that distance, so a permanently
+    // shared GPU costs one bounded retry (<= 2 ms, xk_spin_ge) every few thousand updates at most.
     h->persist_ok = false;
+    h->fast_giveups++; h->fast_reason = pst; h->clean_classic = -1;   // (-1: the retry of THIS update is not a clean update)
+    if (h->fast_giveups > 1) h->rearm_after = std::min(4096, std::max(1, h->rearm_after) * 2);
+    h->xsync_dirty = true; h->psync_dirty = true;
     h->have_rows = h->have_R = false;
-    snprintf(h->err, sizeof(h->err), "single-launch CAQR gave up (reason %d): workgroups not co-resident; using the multi-launch schedule from now on", pst);
+    snprintf(h->err, sizeof(h->err), "single-launch CAQR gave up (reason %d): workgroups not co-resident; multi-launch schedule for the next %d updates", pst, h->rearm_after);
     return allow_retry ? XK_RETRY_CLASSIC : XK_EDEVICE;
   }
   if (st != 0) return fail(h, st, "innovation covariance not positive definite");
@@ -2115,6 +2146,16 @@ extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
   const double waves = (double)blocks * 4;
   const double flops = use_mfma ? waves * iters * 4.0 * (2.0 * 16 * 16 * 4) : waves * 64.0 * iters * 8.0 * 2.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
+  return XK_OK;
+}
+
+// Which schedule compressed the last update, and how the fast path has fared on this handle (include/xk.h).
+extern "C" int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason) {
+  if (!h) return XK_EINVAL;
+  if (schedule) *schedule = !h->last_resident ? 0 : (h->last_pipe ? 2 : 1);
+  if (armed) *armed = h->persist_ok ? 1 : 0;
+  if (giveups) *giveups = h->fast_giveups;
+  if (last_reason) *last_reason = h->fast_reason;
   return XK_OK;
 }
 

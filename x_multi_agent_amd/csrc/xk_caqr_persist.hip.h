@@ -88,14 +88,19 @@ __device__ __forceinline__ unsigned xk_xcc_id() {
   return x & 7u;
 }
 
-// one lane polls one word (relaxed, L1-bypassing) until it reaches `target`; gives up after ~0.2 s
+// one lane polls one word (relaxed, L1-bypassing) until it reaches `target`; gives up after XK_SPIN_TICKS (2 ms: the longest
+// wait of a healthy launch is the last level's for the first roots, tens of microseconds; 0.2 s -- the first version --
+// was six dropped camera frames)
+#ifndef XK_SPIN_TICKS
+#define XK_SPIN_TICKS 200000LL      // 100 MHz ticks
+#endif
 __device__ __forceinline__ bool xk_spin_ge(unsigned *p, unsigned target, unsigned *abort_, unsigned reason) {
   const long long t0 = wall_clock64();
   for (unsigned it = 0;; ++it) {
     if (__hip_atomic_load(p, XK_RLX_AGENT) >= target) return true;
     if ((it & 63u) == 63u) {
       if (__hip_atomic_load(abort_, XK_RLX_AGENT)) return false;
-      if (wall_clock64() - t0 > 20000000LL) break;      // 100 MHz ticks
+      if (wall_clock64() - t0 > XK_SPIN_TICKS) break;
     }
     __builtin_amdgcn_s_sleep(XK_SPIN_SLEEP);
   }

@@ -26,29 +26,34 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "xk_caqr_resident.hip.h"
 
 #define XK_PIPE_THREADS 768
 #define XK_PIPE_RPL 32              // rows per lane of a fat tile: 4 x 32 = 128 rows
 #define XK_PIPE_NT 23               // tile workgroups per XCD
 #define XK_PIPE_NM 8                // first-level workgroups per XCD   (NT + NM + 1 = 32 = CUs of an XCD)
-#ifndef XK_PIPE_ARR
-#define XK_PIPE_ARR 9               // the iteration whose barrier carries "rows 0..7 are out" (their stores drain meanwhile)
+#ifndef XK_PIPE_NPH
+#define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
+#endif
+#ifndef XK_PIPE_ARRD
+#define XK_PIPE_ARRD 1              // a phase's rows are counted in at the barrier ARRD steps after their stores were issued
+#endif
+#ifndef XK_PIPE_CHUNK
+#define XK_PIPE_CHUNK 0             // 1: tile steps fetch the reflector in two halves (no spills; measured 2 % slower than the spills)
 #endif
 
 enum {
   XP_CENSUS = 0,                    // [8] workgroups per XCD
   XP_ABORT = 9,
-  // per XCD, monotonic (an arrival counter + the generation word the waiters poll; generation = panel + 1)
-  XP_TA_CNT = 16, XP_TA_GEN = 24,   // tiles: rows 0..7 of the pivot strips are out
-  XP_TB_CNT = 32, XP_TB_GEN = 40,   // tiles: rows 8..15
-  XP_MB_CNT = 48, XP_MB_GEN = 56,   // first level: the strips are back
-  // per panel (XCDs run up to two panels apart)
-  XP_X1A_CNT = 64, XP_X1A_FLAG = 64 + XK_PERSIST_MAXP,             // first-level items whose root rows 0..7 are out
-  XP_X1B_CNT = 64 + 2 * XK_PERSIST_MAXP, XP_X1B_FLAG = 64 + 3 * XK_PERSIST_MAXP,   // rows 8..15
-  XP_P_CNT = 64 + 4 * XK_PERSIST_MAXP, XP_P_FLAG = 64 + 5 * XK_PERSIST_MAXP,       // last-level workgroups whose pending strips are out
-  XP_ON_CNT = 64 + 6 * XK_PERSIST_MAXP, XP_ON_FLAG = 64 + 7 * XK_PERSIST_MAXP,     // ... whose share of the next panel's columns is out
-  XP_WORDS = 64 + 8 * XK_PERSIST_MAXP
+  // per XCD, monotonic arrival counters (a panel is complete at NT (k + 1) resp. NM (k + 1))
+  XP_TQ_CNT = 16,                   // [4][8] tiles: rows of phase q of the pivot strips are out
+  XP_MB_CNT = 48,                   // [8] first level: the strips are back
+  // per panel (XCDs run up to a panel apart)
+  XP_X1_CNT = 64,                   // [4][MAXP] first-level items whose root rows of phase q are out
+  XP_P_CNT = 64 + 4 * XK_PERSIST_MAXP,   // [MAXP] last-level workgroups whose pending strips are out
+  XP_WORDS = 64 + 5 * XK_PERSIST_MAXP
 };
 
 struct XkCaqrPipeArgs {
@@ -58,14 +63,14 @@ struct XkCaqrPipeArgs {
   int R, TR;              // valid rows in total, rows per fat tile (<= 128)
   int C1P, C1;
   double *Rout;           // [C1P][C1P] row-major
-  double *S;              // [8 NT][16][C1P] pivot strips (XCD-local)
-  double *PB;             // [8 NT][16][16]  their panel blocks
-  double *X1, *X1P;       // [panels][8][16][C1P] / [panels][8][16][16]: the root of XCD x (write-through)
-  double *X2;             // [panels][8][16][C1P]: strips the last level sends down to XCD s (write-through)
-  double *ON;             // [panels][8][16][16]: the NEXT panel's columns of the strips the last level keeps
+  double *S;              // [8 NT][16 x C1P] pivot strips, block layout (xk_blk), XCD-local
+  double *PB;             // [8 NT][16 x 16]  their panel blocks
+  double *X1, *X1P;       // [panels][8][16 x C1P] / [panels][8][16 x 16]: the root of XCD x (write-through)
+  double *X2;             // [panels][8][16 x C1P]: what the last level sends down to XCD s (write-through)
   unsigned *sync, *sync_next;
   int *status;
   long long *dbg;
+  int test_stall;         // test hook: one tile workgroup leaves at once -- everybody else runs into the bound of their spins
 };
 typedef const XkCaqrPipeArgs __attribute__((address_space(4))) *XkPipeArgsPtr;
 __device__ __forceinline__ XkCaqrPipeArgs xk_pipe_args(XkPipeArgsPtr ap) {
@@ -74,9 +79,12 @@ __device__ __forceinline__ XkCaqrPipeArgs xk_pipe_args(XkPipeArgsPtr ap) {
   return a;
 }
 
-__device__ __forceinline__ void xk_pipe_arrive(unsigned *cnt, unsigned *gen, unsigned n, unsigned epoch) {
-  const unsigned old = __hip_atomic_fetch_add(cnt, 1u, XK_RLX_AGENT);
-  if (old == n * epoch - 1u) __hip_atomic_store(gen, epoch, XK_RLX_AGENT);
+// Hand-off counters: the producer's thread 0 adds one WITHOUT asking for the old value (a returning atomic is a round trip to
+// the L2 that its wave -- and, at the next barrier, its whole workgroup -- sits out: ~0.7 us per hand-off in the first
+// version, which kept an arrival counter + a flag the last arriver raised); the consumers poll the counter itself.  They are
+// few (8 first-level workgroups per tile counter, 23 tiles per first-level counter, one lane each, s_sleep between polls).
+__device__ __forceinline__ void xk_pipe_arrive(unsigned *cnt) {
+  (void)__hip_atomic_fetch_add(cnt, 1u, XK_RLX_AGENT);
 }
 // Hides a per-lane constant from loop-invariant code motion: the sixteen unrolled steps of a panel derive 0/1 masks, LDS
 // addresses and predicates from (part, column); hoisted out of the panel loop they are ~60 live registers that end up in
@@ -98,42 +106,98 @@ __device__ __forceinline__ bool xk_pipe_wait(unsigned *word, unsigned target, un
   return ok;
 }
 
-// the 16 steps of a tile's panel in two halves, one-reflector look-ahead (xk_caqr_form / xk_caqr_apply, tile layout)
-template <int RPL>
-__device__ __forceinline__ void xk_pipe_tsteps_a(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc) {
-  xk_caqr_form<0, 4, RPL>(b, rel, part, ubuf, sc);
-  __syncthreads();
-#define XK_IT(K)                                                                                  \
-  if (K < nsteps) { xk_caqr_apply<K - 1, 4, RPL>(b, rel, live, part, ubuf, sc); xk_caqr_form<K, 4, RPL>(b, rel, part, ubuf, sc); __syncthreads(); } \
-  else if (K == nsteps) xk_caqr_apply<K - 1, 4, RPL>(b, rel, live, part, ubuf, sc);
-  XK_IT(1) XK_IT(2) XK_IT(3) XK_IT(4) XK_IT(5) XK_IT(6) XK_IT(7)
-#undef XK_IT
-  if (nsteps >= 8) xk_caqr_apply<7, 4, RPL>(b, rel, live, part, ubuf, sc);
+// xk_caqr_apply (tile layout, 4 lanes per column) with the reflector fetched in two halves: at 32 rows per lane the lane's
+// rows (64 VGPRs) + the whole reflector (64) + the step's temporaries do not fit 168 registers, and what the compiler
+// spilled was reloaded inside every step.  Same sums in the same order; the first half is read from LDS a second time.
+template <int KK, int RPL>
+__device__ __forceinline__ void xk_pipe_tapply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
+#if XK_PIPE_CHUNK
+  constexpr int RPLP = RPL + 2, H = RPL / 4;
+  constexpr int pb = KK & 1;
+  const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
+  const double mtt = sc[pb * 4];
+  if (rel > KK && live && mtt != 0.0) {
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+    {
+      xk_d2 u[H];
+#pragma unroll
+      for (int r = 0; r < H; ++r) u[r] = useg[r];
+#pragma unroll
+      for (int r = 0; r < H; ++r) {
+        if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+        else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+      }
+    }
+    xk_d2 v[H];
+#pragma unroll
+    for (int r = 0; r < H; ++r) v[r] = useg[H + r];
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      if ((H + r) & 1) { d2 = fma(v[r][0], b[2 * (H + r)], d2); d3 = fma(v[r][1], b[2 * (H + r) + 1], d3); }
+      else { d0 = fma(v[r][0], b[2 * (H + r)], d0); d1 = fma(v[r][1], b[2 * (H + r) + 1], d1); }
+    }
+    const double w = mtt * xk_group_sum<4>((d0 + d1) + (d2 + d3));
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      b[2 * (H + r)] = fma(w, v[r][0], b[2 * (H + r)]);
+      b[2 * (H + r) + 1] = fma(w, v[r][1], b[2 * (H + r) + 1]);
+    }
+    const xk_d2 *useg2 = useg + xk_launder(0);             // (a second look at the same LDS words, not the registers of the first)
+#pragma unroll
+    for (int r = 0; r < H; ++r) {
+      const xk_d2 u = useg2[r];
+      b[2 * r] = fma(w, u[0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[1], b[2 * r + 1]);
+    }
+  }
+#else
+  xk_caqr_apply<KK, 4, RPL>(b, rel, live, part, ubuf, sc);
+#endif
 }
-// second half; the barrier of iteration ARR is where thread 0 tells the first level that rows 0..7 are out (every wave has
-// drained its stores by then).  Returns whether that happened (it does not for a panel of <= ARR columns).
-template <int RPL, int ARR>
-__device__ __forceinline__ bool xk_pipe_tsteps_b(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc,
-                                                 unsigned *cnt, unsigned *gen, unsigned n, unsigned epoch) {
-  if (8 < nsteps) xk_caqr_form<8, 4, RPL>(b, rel, part, ubuf, sc);
+
+// Steps [K0, K1) of a panel with the one-reflector look-ahead of xk_caqr_steps_la; on entry every reflector < K0 has been
+// applied, on return every reflector < min(K1, nsteps).  TILE = the tile layout (4 lanes per column), else the merge layout.
+// KH: the iteration whose barrier carries a hand-off -- every wave drains its stores before it, thread 0 runs `hook` after it.
+template <bool TILE, int K, int RPL>
+__device__ __forceinline__ void xk_pipe_form(double (&b)[RPL], int rel, int part, double *ubuf, double *sc) {
+  if constexpr (TILE) xk_caqr_form<K, 4, RPL>(b, rel, part, ubuf, sc);
+  else xk_caqr_mform<K, RPL>(b, rel, part, ubuf, sc);
+}
+template <bool TILE, int K, int RPL>
+__device__ __forceinline__ void xk_pipe_apply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
+  if constexpr (TILE) xk_pipe_tapply<K, RPL>(b, rel, live, part, ubuf, sc);
+  else xk_caqr_apply<K, 16, RPL>(b, rel, live, part, ubuf, sc);
+}
+template <bool TILE, int K, int K1, int KH, int RPL, typename Hook>
+__device__ __forceinline__ void xk_pipe_range_it(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc, bool hook_on, Hook hook) {
+  if constexpr (K < K1) {
+    if (K < nsteps) {
+      xk_pipe_apply<TILE, K - 1, RPL>(b, rel, live, part, ubuf, sc);
+      xk_pipe_form<TILE, K, RPL>(b, rel, part, ubuf, sc);
+      if (K == KH && hook_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (K == KH && hook_on && threadIdx.x == 0) hook();
+    } else if (K == nsteps) {
+      xk_pipe_apply<TILE, K - 1, RPL>(b, rel, live, part, ubuf, sc);
+    }
+    xk_pipe_range_it<TILE, K + 1, K1, KH, RPL>(b, rel, live, part, nsteps, ubuf, sc, hook_on, hook);
+  }
+}
+template <bool TILE, int K0, int K1, int KH, int RPL, typename Hook>
+__device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc, bool hook_on, Hook hook) {
+  if (K0 < nsteps) xk_pipe_form<TILE, K0, RPL>(b, rel, part, ubuf, sc);
+  if (KH == K0 && hook_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-#define XK_IT(K)                                                                                  \
-  if (K < nsteps) {                                                                               \
-    xk_caqr_apply<K - 1, 4, RPL>(b, rel, live, part, ubuf, sc); xk_caqr_form<K, 4, RPL>(b, rel, part, ubuf, sc); \
-    if (K == ARR) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
-    __syncthreads();                                                                              \
-    if (K == ARR && threadIdx.x == 0) xk_pipe_arrive(cnt, gen, n, epoch);                         \
-  } else if (K == nsteps) xk_caqr_apply<K - 1, 4, RPL>(b, rel, live, part, ubuf, sc);
-  XK_IT(9) XK_IT(10) XK_IT(11) XK_IT(12) XK_IT(13) XK_IT(14) XK_IT(15)
-#undef XK_IT
-  if (nsteps == 16) xk_caqr_apply<15, 4, RPL>(b, rel, live, part, ubuf, sc);
-  return nsteps > ARR;
+  if (KH == K0 && hook_on && threadIdx.x == 0) hook();
+  xk_pipe_range_it<TILE, K0 + 1, K1, KH, RPL>(b, rel, live, part, nsteps, ubuf, sc, hook_on, hook);
+  if (nsteps >= K1) xk_pipe_apply<TILE, K1 - 1, RPL>(b, rel, live, part, ubuf, sc);
 }
 
 // ---- role T: one fat tile in registers for the whole factorisation
 template <int RPL>
 __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NT = XK_PIPE_NT, NM = XK_PIPE_NM;
+  constexpr int NT = XK_PIPE_NT, NPH = XK_PIPE_NPH, G = 16 / NPH, ARRD = XK_PIPE_ARRD;
+  static_assert(ARRD < G, "a phase is counted in before the next one is published");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -165,56 +229,51 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     const int part = xk_launder(part_);
     const int rel = xk_launder(cabs) - c0;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
+    const bool full = nsteps == 16;                        // (a short panel -- the last one -- hands everything over at its end)
     const bool hot = (rel >> 4) == 0;
     const bool pub = mine && part == 0 && rel >= 0;
-    if (stamp) a.dbg[16 * k + 0] = wall_clock64();
+    const unsigned epoch = (unsigned)(k + 1);
+    if (stamp) { a.dbg[16 * k + 0] = wall_clock64(); a.dbg[16 * k + 8] = clock64(); }
     if (hot) __builtin_amdgcn_s_setprio(3);
-    xk_pipe_tsteps_a<RPL>(b, rel, mine, part, nsteps, ubuf, sc);
-    bool told = false;
-    if (nsteps > 8) {
-      // rows 0..7 of the pivot strip are final: out they go, the first level starts on them while steps 8..15 run here
+    // phase q: steps [q G, (q + 1) G), then rows [q G, (q + 1) G) of the pivot strip are final and go out; they are counted in
+    // ARRD steps into the next phase (their stores drain behind those steps), the last phase after the panel
+    auto phase = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      auto hook = [&]() { xk_pipe_arrive(sync + (XP_TQ_CNT + (q - 1) * 8 + xcc) * 16); };
+      xk_pipe_range<true, q * G, (q + 1) * G, (q > 0 ? q * G + ARRD : -1), RPL>(b, rel, mine, part, nsteps, ubuf, sc, full, hook);
       if (pub) {
         if (rel < 16) {
           double *pb = xk_opaque(myPB + xk_blk(rel, 0));
 #pragma unroll
-          for (int r = 0; r < 8; ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
+          for (int r = q * G; r < (q + 1) * G; ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
         } else {
           double *ps = xk_opaque(myS + xk_blk(cabs, 0));
 #pragma unroll
-          for (int r = 0; r < 8; ++r) ps[r * 4] = b[r];
+          for (int r = q * G; r < (q + 1) * G; ++r) ps[r * 4] = b[r];
         }
       }
-      if (stamp) a.dbg[16 * k + 1] = wall_clock64();
-      told = xk_pipe_tsteps_b<RPL, XK_PIPE_ARR>(b, rel, mine, part, nsteps, ubuf, sc, sync + (XP_TA_CNT + xcc) * 16, sync + (XP_TA_GEN + xcc) * 16,
-                                                (unsigned)NT, (unsigned)(k + 1));
+      if (stamp && q < 4) a.dbg[16 * k + 1 + q] = wall_clock64();
+    };
+    phase(std::integral_constant<int, 0>{});
+    if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
+    if constexpr (NPH >= 4) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
+    if constexpr (NPH >= 8) {
+      phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
+      phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{});
     }
     if (hot) __builtin_amdgcn_s_setprio(0);
-    if (stamp) a.dbg[16 * k + 2] = wall_clock64();
-    if (pub) {
-      const int r0 = (nsteps > 8) ? 8 : 0;
-      if (rel < 16) {
-        double *pb = xk_opaque(myPB + xk_blk(rel, 0));
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (r >= r0) pb[r * 4] = (r > rel) ? 0.0 : b[r];
-      } else {
-        double *ps = xk_opaque(myS + xk_blk(cabs, 0));
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (r >= r0) ps[r * 4] = b[r];
-      }
-    }
+    if (stamp) { a.dbg[16 * k + 9] = clock64(); a.dbg[16 * k + 10] = wall_clock64(); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      if (!told) xk_pipe_arrive(sync + (XP_TA_CNT + xcc) * 16, sync + (XP_TA_GEN + xcc) * 16, (unsigned)NT, (unsigned)(k + 1));
-      xk_pipe_arrive(sync + (XP_TB_CNT + xcc) * 16, sync + (XP_TB_GEN + xcc) * 16, (unsigned)NT, (unsigned)(k + 1));
+      for (int q = full ? NPH - 1 : 0; q < NPH; ++q)
+        xk_pipe_arrive(sync + (XP_TQ_CNT + q * 8 + xcc) * 16);
     }
-    if (stamp) a.dbg[16 * k + 3] = wall_clock64();
+    if (stamp) a.dbg[16 * k + 5] = wall_clock64();
     if (k + 1 == npanels) break;
     // my strip comes back from the first level (trailing columns of the NEXT panels only: everything up to c0 + 15 is finished)
-    if (!xk_pipe_wait(sync + (XP_MB_GEN + xcc) * 16, (unsigned)(k + 1), ab, 2u, s_ok)) return false;
-    if (stamp) a.dbg[16 * k + 4] = wall_clock64();
+    if (!xk_pipe_wait(sync + (XP_MB_CNT + xcc) * 16, (unsigned)XK_PIPE_NM * epoch, ab, 2u, s_ok)) return false;
+    if (stamp) a.dbg[16 * k + 6] = wall_clock64();
     if (mine && rel >= 16 && part == 0) {
       const double *ps = xk_opaque(myS + xk_blk(cabs, 0));
 #pragma unroll
@@ -224,10 +283,9 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
       double sink = 0;
       for (int r = 0; r < 16; ++r) sink += b[r];
       asm volatile("" ::"v"(sink));
-      a.dbg[16 * k + 5] = wall_clock64();
+      a.dbg[16 * k + 7] = wall_clock64();
     }
   }
-  (void)NM;
   if (stamp) a.dbg[1538] = wall_clock64();
   return true;
 }
@@ -235,7 +293,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
 // ---- role M: the first merge level of this XCD's 23 strips (+ the pending strip), 16 panel + <= 32 trailing columns per workgroup
 // 16 lanes per column: lane p = row p of every strip, register 0 = the pending strip = the pivot strip, register 1 + t = tile t
 __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NT = XK_PIPE_NT, NM = XK_PIPE_NM, RM = NT + 1, NP = 16;
+  constexpr int NT = XK_PIPE_NT, NM = XK_PIPE_NM, RM = NT + 1, NP = 16, NPH = XK_PIPE_NPH, G = 16 / NPH;
   static_assert(RM % 2 == 0, "register count of the merge layout must be even");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
@@ -254,79 +312,70 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     const int col = panel ? c0 + cidx : c0 + 16 + item * mch + (cidx - 16);
     const bool mine = active && col < a.C1 && (panel || cidx - 16 < mch);
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
+    const bool full = nsteps == 16;
+    const unsigned epoch = (unsigned)(k + 1);
     const size_t slab = (size_t)k * 8 + xcc;
     double b[RM];
-    // the pending strip: what the last level left of the roots of panel k - 2 (XCD 0 gets none)
+    // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
+    const int trail_prev = a.C1 - c0, lchalf_prev = max(4, 4 * ((trail_prev + 31) / 32));
+    const int lsplit_prev = max(1, (trail_prev + lchalf_prev - 1) / lchalf_prev);   // last-level workgroups of panel k - 1
     if (k >= 1 && xcc != 0) {
-      if (!xk_pipe_wait(sync + (XP_P_FLAG + k - 1) * 16, 1u, ab, 4u, s_ok)) return false;
+      if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
       if (mine) b[0] = xk_ld_sc1(a.X2 + ((size_t)(k - 1) * 8 + xcc) * SS + xk_blk(col, part));
     }
-    if (!xk_pipe_wait(sync + (XP_TA_GEN + xcc) * 16, (unsigned)(k + 1), ab, 6u, s_ok)) return false;
-    if (stamp) a.dbg[512 + 16 * k + 0] = wall_clock64();
+#pragma unroll
+    for (int s = 1; s < RM; ++s) b[s] = 0.0;
     const size_t lane_off = panel ? xk_blk(cidx, part) : xk_blk(col, part);
     const size_t strip_step = panel ? 256 : SS;
     double *g0 = (panel ? a.PB + (size_t)base * 256 : a.S + (size_t)base * SS) + lane_off;
-    if (active) {
-      {
-        double *g = xk_opaque(g0);
-#pragma unroll
-        for (int s = 1; s < RM; ++s) b[s] = (mine && part < 8) ? xk_ld_sc1(g + (size_t)(s - 1) * strip_step) : 0.0;
-      }
-      if (stamp) {
-        double sink = 0;
-        for (int s = 0; s < RM; ++s) sink += b[s];
-        asm volatile("" ::"v"(sink));
-        a.dbg[512 + 16 * k + 1] = wall_clock64();
-      }
-      if (panel) __builtin_amdgcn_s_setprio(3);
-      xk_res_msteps_a<RM>(b, cidx, mine, part, nsteps, ubuf, sc);
-      if (panel) __builtin_amdgcn_s_setprio(0);
-      // rows 0..7 of the root are final: out they go (write-through: the last level sits on other XCDs)
-      if (mine && part < 8) {
-        if (panel) {
-          if (item == 0) xk_st_sc1(a.X1P + slab * 256 + xk_blk(cidx, part), (part > cidx) ? 0.0 : b[0]);
-        } else {
-          xk_st_sc1(a.X1 + slab * SS + xk_blk(col, part), b[0]);
-        }
-      }
-      if (stamp) a.dbg[512 + 16 * k + 2] = wall_clock64();
-    }
-    if (!xk_pipe_wait(sync + (XP_TB_GEN + xcc) * 16, (unsigned)(k + 1), ab, 7u, s_ok)) return false;
-    if (stamp) a.dbg[512 + 16 * k + 3] = wall_clock64();
-    unsigned *cnt_a = sync + (XP_X1A_CNT + k) * 16, *flag_a = sync + (XP_X1A_FLAG + k) * 16;
-    if (active) {
-      if (mine && part >= 8) {
+    double *x1 = panel ? a.X1P + slab * 256 + xk_blk(cidx, part) : a.X1 + slab * SS + xk_blk(col, part);
+    const bool x1_mine = mine && (!panel || item == 0);
+    bool ok = true;
+    auto phase = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if (!ok) return;
+      if (!xk_pipe_wait(sync + (XP_TQ_CNT + q * 8 + xcc) * 16, (unsigned)NT * epoch, ab, 6u, s_ok)) { ok = false; return; }
+      if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
+      if (!active) return;
+      if (mine && part >= q * G && part < (q + 1) * G) {
         double *g = xk_opaque(g0);
 #pragma unroll
         for (int s = 1; s < RM; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
-      // (its first barrier, behind the loads above, is where rows 0..7 of the root are counted in)
-      xk_res_msteps_b<RM>(b, cidx, mine, part, nsteps, ubuf, sc, cnt_a, flag_a, 8u * NM);
+      // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
+      auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_PERSIST_MAXP + k) * 16); };
+      xk_pipe_range<false, q * G, (q + 1) * G, (q > 0 ? q * G : -1), RM>(b, cidx, mine, part, nsteps, ubuf, sc, full, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
-      if (stamp) a.dbg[512 + 16 * k + 4] = wall_clock64();
-      if (mine) {
-        if (!panel) {
-          // the tiles' strips first (the tiles wait for them), then the rest of the root
-          double *g = xk_opaque(g0);
+      // rows [q G, (q + 1) G) of the root are final: out they go (write-through: the last level sits on other XCDs)
+      if (q < NPH - 1 && x1_mine && part >= q * G && part < (q + 1) * G) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
+    };
+    phase(std::integral_constant<int, 0>{});
+    if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
+    if constexpr (NPH >= 4) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
+    if constexpr (NPH >= 8) {
+      phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
+      phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{});
+    }
+    if (!ok) return false;
+    if (mine) {
+      if (!panel) {
+        // the tiles' strips first (the tiles wait for them), then the last rows of the root
+        double *g = xk_opaque(g0);
 #pragma unroll
-          for (int s = 1; s < RM; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
-          if (part >= 8) xk_st_sc1(a.X1 + slab * SS + xk_blk(col, part), b[0]);
-        } else if (item == 0 && part >= 8) {
-          xk_st_sc1(a.X1P + slab * 256 + xk_blk(cidx, part), (part > cidx) ? 0.0 : b[0]);
-        }
+        for (int s = 1; s < RM; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
       }
-    } else if (tid == 0) {
-      xk_count_in(cnt_a, flag_a, 1u, 8u * NM);
+      if (x1_mine && part >= (NPH - 1) * G) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      xk_pipe_arrive(sync + (XP_MB_CNT + xcc) * 16, sync + (XP_MB_GEN + xcc) * 16, (unsigned)NM, (unsigned)(k + 1));
-      xk_count_in(sync + (XP_X1B_CNT + k) * 16, sync + (XP_X1B_FLAG + k) * 16, 1u, 8u * NM);
+      xk_pipe_arrive(sync + (XP_MB_CNT + xcc) * 16);
+      for (int q = (full && active) ? NPH - 1 : 0; q < NPH; ++q) xk_pipe_arrive(sync + (XP_X1_CNT + q * XK_PERSIST_MAXP + k) * 16);
     }
-    if (stamp) a.dbg[512 + 16 * k + 5] = wall_clock64();
+    if (stamp) a.dbg[512 + 16 * k + 8] = wall_clock64();
   }
   return true;
 }
@@ -335,10 +384,10 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 // its 16 columns redundantly.  Register s = the root of XCD s (register 0 is the pivot strip); what is left of registers
 // 1..7 goes down to XCD s as the pending strip of its first level in the NEXT panel.  (That is a dependency loop -- last
 // level -> first level -> last level -- but with the first level on CUs of its own it is shorter than the tiles' loop:
-// rows 8..15 of the roots leave the first level together with the tiles' strips, 8 steps later the pending strips are out,
-// and the next first level does not start before its tiles are half way through their panel.)
+// the last rows of the roots leave the first level together with the tiles' strips, a few steps later the pending strips
+// are out, and the next first level does not start before its tiles have published the first rows of their strips.)
 __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NP = 16, RL = 8;
+  constexpr int NP = 16, RL = 8, NPH = XK_PIPE_NPH, G = 16 / NPH;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -359,26 +408,31 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     const double *src = panel ? a.X1P + (size_t)k * 8 * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * 8 * SS + xk_blk(col, part);
     const size_t sstep = panel ? 256 : SS;
     double b[RL];
-    if (!xk_pipe_wait(sync + (XP_X1A_FLAG + k) * 16, 1u, ab, 5u, s_ok)) return false;
-    if (stamp) a.dbg[1024 + 16 * k + 0] = wall_clock64();
 #pragma unroll
-    for (int s = 0; s < RL; ++s) b[s] = (mine && part < 8) ? xk_ld_sc1(src + s * sstep) : 0.0;
-    if (panel) __builtin_amdgcn_s_setprio(3);
-    xk_res_msteps_a<RL>(b, panel ? cidx : 16, mine, part, nsteps, ubuf, sc);
-    if (panel) __builtin_amdgcn_s_setprio(0);
-    if (stamp) a.dbg[1024 + 16 * k + 1] = wall_clock64();
-    if (nsteps > 8) {
-      if (!xk_pipe_wait(sync + (XP_X1B_FLAG + k) * 16, 1u, ab, 5u, s_ok)) return false;
-      if (stamp) a.dbg[1024 + 16 * k + 2] = wall_clock64();
-      if (mine && part >= 8) {
+    for (int s = 0; s < RL; ++s) b[s] = 0.0;
+    bool ok = true;
+    auto phase = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if (!ok || nsteps <= q * G) return;                  // (a short last panel: the roots' rows past its columns are zero)
+      if (!xk_pipe_wait(sync + (XP_X1_CNT + q * XK_PERSIST_MAXP + k) * 16, 8u * XK_PIPE_NM, ab, 5u, s_ok)) { ok = false; return; }
+      if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
+      if (mine && part >= q * G && part < (q + 1) * G) {
 #pragma unroll
         for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
-      xk_res_msteps_b<RL>(b, panel ? cidx : 16, mine, part, nsteps, ubuf, sc, nullptr, nullptr, 0u);
+      xk_pipe_range<false, q * G, (q + 1) * G, -1, RL>(b, panel ? cidx : 16, mine, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
+      if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q + 1] = wall_clock64();
+    };
+    phase(std::integral_constant<int, 0>{});
+    if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
+    if constexpr (NPH >= 4) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
+    if constexpr (NPH >= 8) {
+      phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
+      phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{});
     }
-    if (stamp) a.dbg[1024 + 16 * k + 3] = wall_clock64();
+    if (!ok) return false;
     if (mine) {
       if (panel) {
         if (lidx == 0 && c0 + part < a.C1) a.Rout[(size_t)(c0 + part) * a.C1P + col] = (part > cidx) ? 0.0 : b[0];
@@ -393,8 +447,8 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && k + 1 < npanels) xk_count_in(sync + (XP_P_CNT + k) * 16, sync + (XP_P_FLAG + k) * 16, 1u, (unsigned)lsplit);
-    if (stamp) a.dbg[1024 + 16 * k + 4] = wall_clock64();
+    if (tid == 0 && k + 1 < npanels) xk_pipe_arrive(sync + (XP_P_CNT + k) * 16);
+    if (stamp) a.dbg[1024 + 16 * k + 8] = wall_clock64();
   }
   if (stamp) a.dbg[1539] = wall_clock64();
   return true;
@@ -424,6 +478,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   if (!s_ok) return;
   const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
   __syncthreads();
+  if (a.test_stall && xcc == 3 && slot == 5) return;
   bool ok;
   if (slot < NT) ok = xk_pipe_tile<RPL>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok);
   else if (slot < NT + NM) ok = xk_pipe_first(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok);

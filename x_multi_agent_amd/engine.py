@@ -29,7 +29,7 @@ SYMBOLS = [
     "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
     "xk_stage_msckf_slam", "xk_msckf_slam_results", "xk_init_msckf_slam_features", "xk_init_standard_slam_features",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
-    "xk_apply_ci_resident", "xk_snapshot_P", "xk_debug_persist_stamps", "xk_build_compress_async", "xk_fetch_flags",
+    "xk_apply_ci_resident", "xk_snapshot_P", "xk_debug_persist_stamps", "xk_caqr_status", "xk_build_compress_async", "xk_fetch_flags",
     "xk_pr_create", "xk_pr_destroy", "xk_pr_vlad_bytes", "xk_pr_size", "xk_pr_compute_vlad", "xk_pr_add_keyframe",
     "xk_pr_find_candidate", "xk_pr_keyframe", "xk_pr_copy_keyframe", "xk_pr_knn_match",
 ]
@@ -414,6 +414,13 @@ class Engine:
                             for s in range(XK_NSTAGE)},
                     n=t.n, c1=t.c1, k_tracks=t.k_tracks, rows_stacked=t.rows_stacked, n_leaf=t.n_leaf,
                     n_levels=t.n_levels)
+
+    def caqr_status(self):
+        """xk_caqr_status: schedule of the last compression (0 multi-launch, 1 resident, 2 pipelined), whether the
+        single-launch path is armed, give-ups so far, reason of the last one."""
+        v = [C.c_int() for _ in range(4)]
+        self._chk(self.L.xk_caqr_status(self.h, *[C.byref(x) for x in v]), "xk_caqr_status")
+        return dict(schedule=v[0].value, armed=bool(v[1].value), giveups=v[2].value, last_reason=v[3].value)
 
     def probe_fp64_peak(self, use_mfma=True):
         t = C.c_double()
