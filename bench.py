@@ -23,6 +23,8 @@ The JSON line also carries
   frame_loop    whole filter frames through the C++ mirror of the reference API
                 (7 IMU steps, manage(), update, State::correct) with the
                 covariance resident on the device -- the drop-in's own rate
+  other_configs BASELINE configs 2 (SLAM rows, 331 columns) and 3 (50-pose window, 800 tracks) on the
+                same path: updates/s, stage times, QR roofline fraction, parity against the oracle
   cpu_baseline  the C restatement of the reference path (oracle/xk_oracle.c),
                 single thread, timed on this box's host cores (rank 0, N=1)
 """
@@ -40,7 +42,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
-ROUND_TAG = "r02"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
+ROUND_TAG = "r03"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
 CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
 CI_TRACKS = 2             # shared MSCKF tracks fused per CI round
 PR_SCORE_THR = 0.6        # pr_score_thr (vio.cpp:670): minimum VLAD similarity for a keyframe to be sent back
@@ -193,6 +195,49 @@ def cpu_baseline(sc, budget_s=20.0):
     return out
 
 
+def other_configs(engine, synth, with_cpu=True):
+    """BASELINE.json configs 2 and 3 on the same path (one GPU, device-only replay like `value`): updates/s, stage times,
+    QR roofline fraction on the rows actually stacked, and one update checked against the C oracle on the same inputs."""
+    out = {}
+    for cfg, steps in ((2, 200), (3, 60)):
+        try:
+            N, K, M = synth.CONFIGS[cfg]
+            sc = synth.make_config(cfg)
+            eng = engine.Engine(N, M, K)
+            eng.stage(sc)
+            eng.run_steps(sc["sigma_img"], 5)
+            t0 = time.perf_counter()
+            eng.run_steps(sc["sigma_img"], steps)
+            dt = time.perf_counter() - t0
+            tm = eng.bench_staged(sc["sigma_img"], 2, 10)
+            st = tm["stages"]
+            rows = tm["rows_stacked"]
+            _, f_qr, _ = alg_flops(N, K, M, rows=rows)
+            qr_ms = sum(v["ms"] for k, v in st.items() if k.startswith("xk_caqr"))
+            e = {"workload": f"BASELINE.json configs[{cfg - 1}]: N={N}, K={K}, M={M}, n={15 + 6 * N + 3 * M}",
+                 "value": steps / dt, "unit": "updates/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                 "stages_ms": {k: v["ms"] for k, v in st.items() if v["launches"]},
+                 "qr_launches": sum(v["launches"] for k, v in st.items() if k.startswith("xk_caqr")),
+                 "qr_schedule": eng.caqr_status()["schedule"], "rows_stacked": rows,
+                 "qr_frac_of_fp64_peak": f_qr / (qr_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+            if with_cpu:
+                from oracle import c_oracle
+                eng.stage(sc)
+                got = eng.visual_update_staged(sc["sigma_img"])
+                P = eng.download_P()
+                t0 = time.perf_counter()
+                ref = c_oracle.visual_update(sc)
+                e["cpu_ms_per_update_1core"] = 1e3 * (time.perf_counter() - t0)
+                e["parity"] = {"rel_dP_fro": float(np.linalg.norm(P - ref["P"]) / np.linalg.norm(ref["P"])),
+                               "inlier_masks_identical": bool(np.array_equal(got["inlier"], ref["inlier"])),
+                               "inliers": int(np.sum(ref["inlier"])), "of": int(K), "bar_rel_dP": 1e-6}
+            eng.close()
+            out[f"config{cfg}"] = e
+        except Exception as ex:      # an extra must not take the headline line down
+            out[f"config{cfg}"] = {"error": repr(ex)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +246,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame-loop", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -362,8 +408,9 @@ def main():
                 "traffic_note": "bytes between the L2s and the fabric per update, QR kernels, PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE from "
                                 f"profiles/{ROUND_TAG}_pmc_traffic.json; Infinity-Cache hits are included (no counter separates them)",
                 "pmc_file": pmc_state, "per_kernel": per_kernel,
-                "kernel": ("xk_caqr_resident (Householder QR compression of the stacked [H|res]: ONE launch, the row stack resident in "
-                           "registers; stage keys " + "+".join(qr_keys) + ")") if tm.get("n_levels") == 1 else
+                "kernel": ("xk_caqr_pipe (Householder QR compression of the stacked [H|res]: ONE launch, the row stack resident in "
+                           "registers, the three levels of the CAQR tree pipelined on workgroups of their own; stage keys "
+                           + "+".join(qr_keys) + ")") if tm.get("n_levels") == 1 else
                           "+".join(qr_keys) + " (Householder QR compression of the stacked [H|res], multi-launch CAQR)",
                 "alg_flops_per_update": f_qr, "rows_stacked": rows, "stage_ms": qr_ms,
                 "launches_per_update": sum(st[k]["launches"] for k in qr_keys),
@@ -386,6 +433,13 @@ def main():
             fl = frame_loop(sc)
             if fl and "ms_per_frame" in fl:
                 fl["ratio_to_replay"] = fl["ms_per_frame"] / (1e3 * dt / args.steps)
+        others = None
+        if world == 1 and args.config == 4 and not args.no_other_configs:
+            try:
+                eng.close()
+            except Exception:
+                pass
+            others = other_configs(engine, synth, with_cpu=not args.no_cpu)
         cpu = None
         parity = None
         if world == 1 and not args.no_cpu:
@@ -410,10 +464,12 @@ def main():
                                       + (f"request/response every {ci_every} updates: binary-VLAD request, best keyframe of the responder's database back (ring)" if args.config == 5
                                          else f"CI payload all-gather every {ci_every} updates"),
                           "n_poses_max": N, "k_msckf": K, "m_slam": M, "agents": world,
+                          "tracks_passing_the_gate_rank0": (int(np.sum(gpu_res["inlier"])) if gpu_res is not None else None),
+                          "rows_stacked_rank0": rows,
                           "ci_every": ci_every, "payload_bytes": 8 * pay_n, "ci_tracks_per_round": CI_TRACKS,
                           "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"],
                           **({"keyframes_received_rank0": ci_stats.get("keyframes_received", 0)} if args.config == 5 else {})},
-               "roofline": roof, "frame_loop": fl, "parity": parity, "cpu_baseline": cpu,
+               "roofline": roof, "frame_loop": fl, "other_configs": others, "parity": parity, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
         print(json.dumps(out), flush=True)
     try:

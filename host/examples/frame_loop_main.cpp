@@ -77,6 +77,7 @@ int main(int argc, char **argv) {
   VioUpdater updater(0, N, 0, K, sigma_img);
   updater.setManageWindow(true);
   Propagator prop(g, ImuNoise());
+  Propagator::acknowledgeModelProcessNoise();   // this benchmark knowingly runs the mirror's clean q_d model (a drop-in keeps the reference's)
   prop.setEngine(updater.engine());
   Ekf ekf(updater);
   ekf.set(4 * imu_per_frame + 8, State(N, 0), &prop, 0.5 * dt_imu);

@@ -3,6 +3,7 @@
 // SlamUpdate::computeInverseDepthsNew.
 #include <vector>
 
+#include "xk.h"
 #include "x/ekf/propagator.h"
 #include "x/ekf/simple_state.h"
 #include "x/vio/slam_update.h"
@@ -21,6 +22,7 @@ void x_host_discrete_state_transition(double dt, const double *e_w, const double
 void x_host_process_noise_model(double dt, const double *q_xyzw, const double *e_w, const double *e_a, double n_w, double n_bw,
                                 double n_a, double n_ba, double *out) {
   Propagator p;
+  Propagator::acknowledgeModelProcessNoise();          // (this entry point exists to look at the model)
   const CoreCovMatrix q = p.discreteProcessNoiseCov(dt, Quaternion(q_xyzw[3], q_xyzw[0], q_xyzw[1], q_xyzw[2]),
                                                     Vector3(e_w[0], e_w[1], e_w[2]), Vector3(e_a[0], e_a[1], e_a[2]), n_w, n_bw,
                                                     n_a, n_ba);
@@ -45,6 +47,47 @@ void x_host_propagate_state(const double *s0, double *s1, const double *g) {
   p.propagateState(a, b);
   for (int i = 0; i < 3; ++i) { s1[1 + i] = b.p_(i); s1[4 + i] = b.v_(i); s1[11 + i] = b.b_w_(i); s1[14 + i] = b.b_a_(i); }
   s1[7] = b.q_.x(); s1[8] = b.q_.y(); s1[9] = b.q_.z(); s1[10] = b.q_.w();
+}
+// One IMU step of the covariance through the mirror (Propagator::propagateCovariance: upload, xk_cov_propagate, download) with
+// the discrete process noise INJECTED through setProcessNoiseFunction -- what a drop-in does with the reference's own q_d.
+// s0 / s1 as above; qd225 column-major; P_in / P_out n x n column-major, n = 15 + 6 N + 3 M.  Needs a GPU (device 0).
+int x_host_propagate_covariance_with_qd(const double *s0, const double *s1, const double *qd225, const double *P_in, int N, int M,
+                                        double *P_out, double *fd_out, int *qd_calls) {
+  auto load = [](const double *s, State &st) {
+    st.time_ = s[0];
+    for (int i = 0; i < 3; ++i) { st.p_(i) = s[1 + i]; st.v_(i) = s[4 + i]; st.b_w_(i) = s[11 + i]; st.b_a_(i) = s[14 + i]; st.w_m_(i) = s[17 + i]; st.a_m_(i) = s[20 + i]; }
+    st.q_ = Quaternion(s[10], s[7], s[8], s[9]);
+  };
+  xk_handle *xk = nullptr;
+  try {
+    if (xk_create(0, N, M, 4, &xk) != XK_OK) return 2;
+    State a(N, M), b(N, M);
+    load(s0, a);
+    load(s1, b);
+    const int n = 15 + 6 * N + 3 * M;
+    a.cov_.resize(n, n);
+    for (int k = 0; k < n * n; ++k) a.cov_.data()[k] = P_in[k];
+    Propagator p(Vector3(0, 0, -9.81), ImuNoise());
+    p.setEngine(xk);
+    int calls = 0;
+    p.setProcessNoiseFunction([&](double, const Quaternion &, const Vector3 &, const Vector3 &, double, double, double, double) {
+      CoreCovMatrix q;
+      for (int k = 0; k < 225; ++k) q.m[k] = qd225[k];
+      ++calls;
+      return q;
+    });
+    CoreCovMatrix f_d, q_d;
+    p.transition(a, b, f_d, q_d);
+    for (int k = 0; k < 225; ++k) fd_out[k] = f_d.m[k];
+    p.propagateCovariance(a, b);
+    for (int k = 0; k < n * n; ++k) P_out[k] = b.cov_.data()[k];
+    *qd_calls = calls;
+    xk_destroy(xk);
+    return 0;
+  } catch (...) {
+    if (xk) xk_destroy(xk);
+    return 1;
+  }
 }
 // SimpleState::fromPayload -> accessors -> toPayload; lists_out = [attitudes 4N | positions 3N] as the CI code reads them
 int x_host_simple_state_roundtrip(const double *payload_in, int N, int M, double *payload_out, double *lists_out) {

@@ -104,7 +104,11 @@ std::optional<State> Ekf::processImu(double timestamp, unsigned int seq, const V
   last_seq_ = seq;
   const Vector3 a_m_smoothed = a_m.norm() < a_m_max_ ? a_m : last_state.a_m_;   // accelerometer spikes (:119-129)
   const int next = (tail_ + 1) % (int)buffer_.size();                     // state_buffer_.enqueueInPlace()
-  if (resident_ && next == cov_idx_) throw std::runtime_error("Ekf: the state ring wrapped onto the slot whose covariance is resident");
+  // The ring wraps onto the slot whose covariance is resident on the device (buffer_sz - 1 IMU steps without a vision update:
+  // before the first frame, during a tracking dropout).  The reference's enqueueInPlace() just overwrites the oldest state;
+  // so does this, after moving the device covariance one slot on (it then belongs to the oldest state that survives).
+  if (resident_ && next == cov_idx_ && !advanceDeviceCovariance((cov_idx_ + 1) % (int)buffer_.size()))
+    throw std::runtime_error("Ekf: cannot advance the resident covariance past the slot the ring overwrites");
   State &next_state = buffer_[next];
   next_state.setImu(timestamp, seq, w_m, a_m_smoothed);
   if (!propagator_) throw std::runtime_error("Ekf::processImu: no propagator");
@@ -168,6 +172,9 @@ Matrix Ekf::covarianceAt(int idx) {
   if (idx < 0) idx = tail_;
   if (!resident_) return buffer_[idx].cov_;
   const int n = buffer_[idx].nErrorStates(), sz = (int)buffer_.size();
+  // only slots between the resident covariance's and the tail have a covariance any more (older ones were consumed)
+  if ((idx - cov_idx_ + sz) % sz > (tail_ - cov_idx_ + sz) % sz)
+    throw std::out_of_range("Ekf::covarianceAt: that state is older than the covariance resident on the device");
   Matrix P(n, n);
   check(updater_.engine(), xk_download_P(updater_.engine(), P.data(), n, n), "xk_download_P");
   const int steps = (idx - cov_idx_ + sz) % sz;

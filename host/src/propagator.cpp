@@ -2,6 +2,9 @@
 // covariance propagation goes through the C ABI to the device.
 #include "x/ekf/propagator.h"
 
+#include <atomic>
+#include <cstdio>
+
 #include <cmath>
 #include <stdexcept>
 #include <string>
@@ -119,8 +122,16 @@ CoreCovMatrix Propagator::discreteStateTransition(double dt, const Vector3 &e_w,
   return f_d;
 }
 
+static std::atomic<bool> g_model_qd_acknowledged{false};
+void Propagator::acknowledgeModelProcessNoise(bool on) { g_model_qd_acknowledged.store(on); }
+
 CoreCovMatrix Propagator::discreteProcessNoiseCov(double dt, const Quaternion &q, const Vector3 &e_w, const Vector3 &e_a,
                                                   double n_w, double n_bw, double n_a, double n_ba) const {
+  if (!g_model_qd_acknowledged.exchange(true))
+    fprintf(stderr, "x::Propagator: discreteProcessNoiseCov is the mirror's clean model (exact integral of F_d G Q_c G^T F_d^T), NOT the "
+                    "reference's generated q_d (propagator.cpp:207-840): the propagated covariance differs from the upstream filter's. "
+                    "A drop-in keeps the reference's function (override the virtual or setProcessNoiseFunction; INTEGRATION.md 3.6); "
+                    "Propagator::acknowledgeModelProcessNoise() silences this.\n");
   // G Q_c G^T for G = [v: -C(q), theta: -I, b_w: I, b_a: I] is block diagonal and does not depend on q:
   // diag(0, n_a^2 I, n_w^2 I, n_bw^2 I, n_ba^2 I).  The integrand F_d(t) (.) F_d(t)^T is a polynomial in t.
   // (degree <= 10 in t: six Gauss-Legendre points are exact)
@@ -160,7 +171,7 @@ void Propagator::transition(const State &state_0, const State &state_1, CoreCovM
   state_1.computeUnbiasedImuMeasurements(e_w_1, e_a_1);
   const double dt = state_1.time_ - state_0.time_;
   f_d = discreteStateTransition(dt, e_w_1, e_a_1, state_1.q_);
-  q_d = discreteProcessNoiseCov(dt, state_1.q_, e_w_1, e_a_1, imu_noise_.n_w, imu_noise_.n_bw, imu_noise_.n_a, imu_noise_.n_ba);
+  q_d = processNoise(dt, state_1.q_, e_w_1, e_a_1);
 }
 
 void Propagator::propagateCovariance(const State &state_0, State &state_1) const {   // propagator.cpp:53-71

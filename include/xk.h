@@ -355,10 +355,9 @@ int xk_run_steps(xk_handle *h, double sigma_img, int steps);
  * xk_last_error() carries the same information as text.  Any pointer may be NULL. */
 int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason);
 
-/* Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST=1 XK_CAQR_PERSIST_DBG=1): per panel k,
- * out[8k + 0..5] = one tile-owning workgroup (tile step start / end, after the XCD barrier, first-level merge start /
- * end, after the second barrier), out[8k + 6..7] = one last-level workgroup; from out[256] on, the same six stamps for
- * every tile-owning workgroup of XCD 0 ([slot][panel][8]).  n_out <= 256 + 64 * 256. */
+/* Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST_DBG=1), for tools/exp/pipe_trace.py: per panel k,
+ * out[16k ..] = one tile workgroup, out[512 + 16k ..] = one first-level workgroup, out[1024 + 16k ..] = one last-level
+ * workgroup (phase by phase), out[1536 ..] = start-up and exit.  n_out <= 256 + 64 * 256. */
 int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out);
 
 /* Micro-benchmark of the fp64 ceiling this path is priced against: a grid of

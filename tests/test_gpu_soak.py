@@ -1,0 +1,66 @@
+"""Bounded soak of the single-launch QR compression (csrc/xk_caqr_pipe.hip.h) -- a kernel whose correctness rests on hand-offs
+between 256 workgroups through per-XCD L2s and counters, i.e. on orderings that only show their failures under variety:
+random shapes inside its window (MSCKF tracks only, 512 <= stacked rows <= 23 552, <= 192 columns; ragged tracks, partial
+windows, heavy rejection, loose and tight priors) against the C oracle, three updates per handle, then 100 headline
+updates on ONE handle (the two sets of sync words alternate; a launch that gave up would show in xk_caqr_status)."""
+import numpy as np
+import pytest
+
+from helpers import rel
+from x_multi_agent_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 30
+
+
+def test_random_shapes_against_the_oracle(xk, oracle_c):
+    rng = np.random.default_rng(20260928)
+    worst, bad, took, ran = 0.0, [], 0, 0
+    while ran < N_CASES:
+        N = int(rng.integers(6, 32))
+        K = int(rng.integers(12, 401))
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.choice([0.0, 0.05, 0.3, 0.8])),
+                  prior_scale=float(rng.choice([0.1, 1.0, 30.0])))
+        if rng.random() < 0.5:
+            kw["track_len"] = (2, N)
+        if rng.random() < 0.25:
+            kw["n_poses"] = int(rng.integers(max(3, N // 2), N))
+            if "track_len" in kw:
+                kw["track_len"] = (2, kw["n_poses"])
+        try:
+            sc = synth.make_scenario(N, K, 0, **kw)
+        except Exception:
+            continue
+        ran += 1
+        ref = oracle_c.visual_update(sc)
+        eng = xk.Engine(N, 0, K)
+        for rep in range(3):
+            eng.stage(sc)
+            got = eng.visual_update_staged(sc["sigma_img"])
+            rp = rel(eng.download_P(), ref["P"])
+            worst = max(worst, rp)
+            if not np.array_equal(got["inlier"], ref["inlier"]) or not (rp <= 1e-8):
+                bad.append((N, K, kw, rep, rp))
+        st = eng.caqr_status()
+        took += int(st["schedule"] == 2)
+        assert st["giveups"] == 0, (N, K, kw, st)
+        eng.close()
+    assert not bad, bad
+    assert took >= N_CASES // 2, f"only {took} of {N_CASES} random shapes took the single-launch path"
+    print(f"soak: {N_CASES} shapes, {took} on the single launch, worst rel dP {worst:.2e}")
+
+
+def test_hundred_headline_updates_on_one_handle(xk, oracle_c):
+    sc = synth.make_config(4)
+    ref = oracle_c.visual_update(sc)
+    eng = xk.Engine(30, 0, 400)
+    for rep in range(100):
+        eng.stage(sc)
+        got = eng.visual_update_staged(sc["sigma_img"])
+        if rep % 20 == 0 or rep == 99:
+            assert np.array_equal(got["inlier"], ref["inlier"])
+            assert rel(eng.download_P(), ref["P"]) <= 1e-8, rep
+    st = eng.caqr_status()
+    assert st["schedule"] == 2 and st["giveups"] == 0 and st["armed"], st
+    eng.close()

@@ -1,5 +1,5 @@
-"""The pipelined register-resident CAQR (xk_caqr_pipe, XK_CAQR_PIPE=1) at a given config: parity against the multi-launch
-schedule and the round-2 resident kernel, stage times, per-panel phase spans of one tile / first-level / last-level
+"""The pipelined register-resident CAQR (xk_caqr_pipe) at a given config: parity against the multi-launch
+schedule, stage times, per-panel phase spans of one tile / first-level / last-level
 workgroup (XK_CAQR_PERSIST_DBG=1)."""
 import ctypes as C, os, sys, subprocess
 sys.path.insert(0, '.')
@@ -10,7 +10,6 @@ from x_multi_agent_amd import engine, synth
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 mode = sys.argv[2] if len(sys.argv) > 2 else "pipe"
 if mode == "multi": os.environ["XK_CAQR_RESIDENT"] = "0"
-if mode == "resident": os.environ["XK_CAQR_PIPE"] = "0"
 sc = synth.make_config(cfg)
 N = sc["n_poses_max"]; K = len(sc["trk_off"]) - 1
 eng = engine.Engine(N, 0, K)
@@ -41,7 +40,7 @@ if mode == "pipe":
     print(f"start-up: entry -> rows gathered {us(w[1537]-w[1536]):.2f} us; tile workgroup leaves {us(w[1538]-w[1536]):.2f} us after its entry, last level {us(w[1539]-w[1536]):.2f} us")
     np.save("/tmp/pipe_P.npy", got["P"]); np.save("/tmp/pipe_c.npy", got["correction"])
     eng.close()
-    for m in ("resident", "multi"):
+    for m in ("multi",):
         r = subprocess.run([sys.executable, __file__, str(cfg), m], capture_output=True, text=True)
         print((r.stdout.strip() or r.stderr.strip()[-400:]))
 else:

@@ -16,8 +16,6 @@
 #include "xk_feature.hip.h"
 #include "xk_slaminit.hip.h"
 #include "xk_linalg.hip.h"
-#include "xk_caqr_persist.hip.h"
-#include "xk_caqr_resident.hip.h"
 #include "xk_caqr_pipe.hip.h"
 #include "xk_ci.hip.h"
 
@@ -48,21 +46,17 @@ struct xk_handle {
   double *d_gam, *d_gam_s, *d_gpf;
   double *d_R;
   int nleaf, nlevels;   // of the last compression
-  // single-launch CAQR (xk_caqr_persist.hip.h): cross-XCD exchange slabs and the sync words
+  // single-launch CAQR (xk_caqr_pipe.hip.h): cross-XCD exchange slabs, XCD-local strips and panel blocks, the row map,
+  // two sets of sync words (a launch uses one and zeroes the other for its successor)
   double *d_x1, *d_x1p, *d_x2;
-  // register-resident single-launch CAQR (xk_caqr_resident.hip.h)
-  double *d_rs, *d_rpb, *d_rhq;
-  // pipelined register-resident CAQR (xk_caqr_pipe.hip.h): its own sync words (two sets, like d_psync)
+  double *d_rs, *d_rpb;
   unsigned *d_xsync;
   int xsync_phase;
   int *d_rowmap;
   int rowmap_R;            // valid rows the device row map describes (-1: stale)
   std::vector<int> *h_rowlens;   // track lengths the row map was built for
-  unsigned *d_psync;    // TWO sets of sync words: a resident launch uses one and zeroes the other for the next launch
-  int psync_phase;
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
   bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
-  bool psync_dirty;     // somebody else (the persist experiment) used set 0: clear both before the next resident launch
   long long *d_pdbg;
   long long *feat_dbg;  // probe builds only: per-workgroup phase stamps of xk_msckf_feature
   bool attr_slaminit, attr_feat_batch;   // hipFuncSetAttribute done for this handle's device
@@ -239,27 +233,21 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     // a CU mask set behind the runtime's back) is caught by the placement census and the bounded spins inside the launch.
     h->persist_ok = h->DB == 64 && h->C1 <= 192 && h->n_cu == 256;
     if (h->persist_ok) {
-      int nb1 = 0, nb2 = 0;
+      int nb1 = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)xk_caqr_pipe, XK_PIPE_THREADS, 0) != hipSuccess) nb1 = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void *)xk_caqr_resident, XK_RES_THREADS, 0) != hipSuccess) nb2 = 0;
-      h->persist_ok = nb1 >= 1 && nb2 >= 1;
+      h->persist_ok = nb1 >= 1;
       (void)hipGetLastError();
     }
     h->fast_capable = h->persist_ok;
     h->rearm_after = env_int("XK_CAQR_REARM", 64);
     if (h->persist_ok) {
-      const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * XK_PERSIST_MAXG * 16;
+      const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * 8 * 16;
       HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
-      HIPCHK(h, dalloc(&h->d_psync, (size_t)2 * XK_PS_WORDS * 16));
-      HIPCHK(h, hipMemset(h->d_psync, 0, sizeof(unsigned) * 2 * XK_PS_WORDS * 16));
-      h->psync_phase = 0; h->psync_dirty = false;
-      HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_RES_NT * 16 * h->C1P));
-      HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_RES_NT * 256));
-      HIPCHK(h, dalloc(&h->d_rhq, (size_t)XK_PERSIST_MAXG * 16 * h->C1P));
-      HIPCHK(h, dalloc(&h->d_rowmap, (size_t)8 * XK_RES_NT * 4 * XK_RES_RPL));
-      static_assert(XK_PIPE_NT * XK_PIPE_RPL <= XK_RES_NT * XK_RES_RPL && XK_PIPE_NT <= XK_RES_NT, "the pipelined kernel shares the resident kernel's strip and row-map buffers");
+      HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_PIPE_NT * 16 * h->C1P));
+      HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_PIPE_NT * 256));
+      HIPCHK(h, dalloc(&h->d_rowmap, (size_t)8 * XK_PIPE_NT * 4 * XK_PIPE_RPL));
       HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
       HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
       h->xsync_phase = 0;
@@ -341,10 +329,10 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_fq) hipFree(h->d_fq);
-  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rhq, (void *)h->d_rowmap, (void *)h->d_xsync})
+  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rowmap, (void *)h->d_xsync})
     if (p4) hipFree(p4);
   delete h->h_rowlens;
-  for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_psync, (void *)h->d_pdbg})
+  for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_pdbg})
     if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
   if (h->d_batch) hipFree(h->d_batch);
@@ -747,7 +735,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   const bool overlap = overlap_env && (arity1 == 20 || arity1 == 40) && groups1 >= 2 && groups1 <= 20;
   a.hole_stride = 0; a.lead_off = 0; a.lead_all = 0; a.pend = 0;
   int launches = 0;
-  // register-resident single launch (xk_caqr_resident.hip.h): MSCKF tracks only, valid rows <= 248 fat tiles of 96
+  // register-resident single launch (xk_caqr_pipe.hip.h): MSCKF tracks only, valid rows <= 184 fat tiles of 128
   const int resident_env = env_int("XK_CAQR_RESIDENT", 1);   // (read per call: tests switch it inside one process)
   if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && h->M == 0 && h->K2 == 0 && h->K > 0 &&
       ++h->clean_classic > h->rearm_after) {
@@ -764,7 +752,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       R = 0;
       for (int k = 0; k < h->K; ++k) { (*h->h_rowlens)[k] = h->h_trk_off[k + 1] - h->h_trk_off[k]; R += 2 * (*h->h_rowlens)[k] - 3; }
       h->rowmap_R = -1;
-      if (R <= 8 * XK_RES_NT * 4 * XK_RES_RPL && (size_t)R * sizeof(int) <= h->stage_bytes) {
+      if (R <= 8 * XK_PIPE_NT * 4 * XK_PIPE_RPL && (size_t)R * sizeof(int) <= h->stage_bytes) {
         int *st = (int *)stage_slot(h, sizeof(int) * (size_t)R);
         int g = 0;
         for (int k = 0; k < h->K; ++k)
@@ -773,10 +761,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
         h->rowmap_R = R;
       }
     }
-    // pipelined schedule (xk_caqr_pipe.hip.h): 184 fat tiles of <= 128 rows, the merge levels on workgroups of their own
-    const int pipe_env = env_int("XK_CAQR_PIPE", 1);
     const int NTP = 8 * XK_PIPE_NT;
-    if (pipe_env && h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTP - 1) / NTP <= 4 * XK_PIPE_RPL) {
+    if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTP - 1) / NTP <= 4 * XK_PIPE_RPL) {
       XkCaqrPipeArgs pa;
       pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.rowmap = h->d_rowmap; pa.R = h->rowmap_R; pa.TR = (h->rowmap_R + NTP - 1) / NTP;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
@@ -804,69 +790,6 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
       return XK_OK;
     }
-    const int NTL = 8 * XK_RES_NT;
-    if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTL - 1) / NTL <= 4 * XK_RES_RPL) {
-      XkCaqrResidentArgs ra;
-      ra.A = h->d_A; ra.tile_rows = h->d_tile_rows; ra.rowmap = h->d_rowmap; ra.R = h->rowmap_R; ra.TR = (h->rowmap_R + NTL - 1) / NTL;
-      ra.C1P = h->C1P; ra.C1 = h->C1; ra.Rout = h->d_R; ra.S = h->d_rs; ra.PB1 = h->d_rpb; ra.Hq = h->d_rhq;
-      // no memset between the per-feature kernel and this one (it cost stream time in every update): the sync words are
-      // double-buffered, every launch leaves the other set zeroed for its successor
-      if (h->psync_dirty) {
-        if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * 2 * XK_PS_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
-        h->psync_dirty = false; h->psync_phase = 0;
-      }
-      ra.X1 = h->d_x1; ra.X1P = h->d_x1p; ra.X2 = h->d_x2; ra.status = h->d_status;
-      ra.sync = h->d_psync + (size_t)h->psync_phase * XK_PS_WORDS * 16;
-      ra.sync_next = h->d_psync + (size_t)(h->psync_phase ^ 1) * XK_PS_WORDS * 16;
-      h->psync_phase ^= 1;
-      // test hook: raise the abort word before the launch -- every workgroup gives up at its first spin, exactly what an
-      // uneven placement or a missing workgroup leads to, and the host has to redo the update with the multi-launch schedule
-      if (env_int("XK_CAQR_RESIDENT_POISON", 0)) {
-        const unsigned seven = 7u;
-        if (hipMemcpyAsync(ra.sync + XK_PS_ABORT * 16, &seven, sizeof(unsigned), hipMemcpyHostToDevice, h->stream) != hipSuccess)
-          return fail(h, XK_EDEVICE, "poison");
-        hipStreamSynchronize(h->stream);
-      }
-      static const int rdbg = env_int("XK_CAQR_PERSIST_DBG", 0);
-      ra.dbg = rdbg ? h->d_pdbg : nullptr;
-      hipLaunchKernelGGL(xk_caqr_resident, dim3(h->n_cu), dim3(XK_RES_THREADS), 0, h->stream, ra);
-      if (mid) hipEventRecord(mid, h->stream);
-      h->nleaf = NTL; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = false;
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
-      return XK_OK;
-    }
-  }
-  // single-launch schedule (xk_caqr_persist.hip.h): every workgroup of the grid must be resident at once (2 per CU)
-  static const int persist_env = env_int("XK_CAQR_PERSIST", 0);
-  static const int persist_min = env_int("XK_CAQR_PERSIST_MIN", 64);
-  if (persist_env && h->persist_ok && ntiles >= persist_min && ntiles <= 8 * 50) {
-    XkCaqrPersistArgs pa;
-    pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.ntiles = ntiles; pa.rows_max = std::max(a.rows_max, 32);
-    pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.PB1 = h->d_panel[0];
-    pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.sync = h->d_psync;
-    pa.TPX = (ntiles + 7) / 8;
-    pa.G = pa.TPX > 27 ? 2 : 1;                       // first-level arity <= 27 (14 rows per lane, one of them pending)
-    pa.A1 = (pa.TPX + pa.G - 1) / pa.G;
-    const int trail0 = std::max(0, h->C1 - 16);
-    pa.NT = std::min(50, std::max(pa.TPX, pa.G * std::max(1, (trail0 + 7) / 8)));
-    const int NL = 8 * (2 * h->n_cu / 8 - pa.NT);
-    pa.lchalf = std::min(8, 2 * std::max(1, (trail0 + 2 * NL - 1) / (2 * NL)));
-    pa.status = h->d_status;
-    static const int pdbg = env_int("XK_CAQR_PERSIST_DBG", 0);
-    pa.dbg = pdbg ? h->d_pdbg : nullptr;
-    if (hipMemsetAsync(h->d_psync, 0, sizeof(unsigned) * XK_PS_WORDS * 16, h->stream) != hipSuccess)
-      return fail(h, XK_EDEVICE, "sync words");
-    h->psync_dirty = true;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_persist<14>), dim3(2 * h->n_cu), dim3(XK_PERSIST_THREADS), 0, h->stream, pa);
-    if (mid) hipEventRecord(mid, h->stream);
-    h->nleaf = ntiles;
-    h->nlevels = 1;
-    h->have_R = true;
-    h->last_resident = true; h->last_pipe = false;
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
-    return XK_OK;
   }
   auto tile_geom = [&](int c0, int &tsplit, int &tchalf, int &tthreads) {
     const int trail = std::max(0, h->C1 - c0 - 16);
@@ -1118,7 +1041,7 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
     h->persist_ok = false;
     h->fast_giveups++; h->fast_reason = pst; h->clean_classic = -1;   // (-1: the retry of THIS update is not a clean update)
     if (h->fast_giveups > 1) h->rearm_after = std::min(4096, std::max(1, h->rearm_after) * 2);
-    h->xsync_dirty = true; h->psync_dirty = true;
+    h->xsync_dirty = true;
     h->have_rows = h->have_R = false;
     snprintf(h->err, sizeof(h->err), "single-launch CAQR gave up (reason %d): workgroups not co-resident; multi-launch schedule for the next %d updates", pst, h->rearm_after);
     return allow_retry ? XK_RETRY_CLASSIC : XK_EDEVICE;

@@ -28,7 +28,8 @@
 
 #include <type_traits>
 
-#include "xk_caqr_resident.hip.h"
+#include "xk_linalg.hip.h"
+#include "xk_xcd_sync.hip.h"
 
 #define XK_PIPE_THREADS 768
 #define XK_PIPE_RPL 32              // rows per lane of a fat tile: 4 x 32 = 128 rows
@@ -52,8 +53,8 @@ enum {
   XP_MB_CNT = 48,                   // [8] first level: the strips are back
   // per panel (XCDs run up to a panel apart)
   XP_X1_CNT = 64,                   // [4][MAXP] first-level items whose root rows of phase q are out
-  XP_P_CNT = 64 + 4 * XK_PERSIST_MAXP,   // [MAXP] last-level workgroups whose pending strips are out
-  XP_WORDS = 64 + 5 * XK_PERSIST_MAXP
+  XP_P_CNT = 64 + 4 * XK_CAQR_MAXP,   // [MAXP] last-level workgroups whose pending strips are out
+  XP_WORDS = 64 + 5 * XK_CAQR_MAXP
 };
 
 struct XkCaqrPipeArgs {
@@ -345,7 +346,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
-      auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_PERSIST_MAXP + k) * 16); };
+      auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
       xk_pipe_range<false, q * G, (q + 1) * G, (q > 0 ? q * G : -1), RM>(b, cidx, mine, part, nsteps, ubuf, sc, full, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
       // rows [q G, (q + 1) G) of the root are final: out they go (write-through: the last level sits on other XCDs)
@@ -373,7 +374,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     __syncthreads();
     if (tid == 0) {
       xk_pipe_arrive(sync + (XP_MB_CNT + xcc) * 16);
-      for (int q = (full && active) ? NPH - 1 : 0; q < NPH; ++q) xk_pipe_arrive(sync + (XP_X1_CNT + q * XK_PERSIST_MAXP + k) * 16);
+      for (int q = (full && active) ? NPH - 1 : 0; q < NPH; ++q) xk_pipe_arrive(sync + (XP_X1_CNT + q * XK_CAQR_MAXP + k) * 16);
     }
     if (stamp) a.dbg[512 + 16 * k + 8] = wall_clock64();
   }
@@ -414,7 +415,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (!ok || nsteps <= q * G) return;                  // (a short last panel: the roots' rows past its columns are zero)
-      if (!xk_pipe_wait(sync + (XP_X1_CNT + q * XK_PERSIST_MAXP + k) * 16, 8u * XK_PIPE_NM, ab, 5u, s_ok)) { ok = false; return; }
+      if (!xk_pipe_wait(sync + (XP_X1_CNT + q * XK_CAQR_MAXP + k) * 16, 8u * XK_PIPE_NM, ab, 5u, s_ok)) { ok = false; return; }
       if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
       if (mine && part >= q * G && part < (q + 1) * G) {
 #pragma unroll

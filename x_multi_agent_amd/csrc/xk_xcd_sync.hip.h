@@ -1,0 +1,61 @@
+// xk_xcd_sync.hip.h -- what workgroups of ONE launch use to hand data to each other on MI355X (8 XCDs, one L2 each; the L2s
+// are not coherent with each other).
+//
+//   * inside an XCD: plain stores + s_waitcnt vmcnt(0) on the producer (the data is in the XCD's L2 once vmcnt reaches 0)
+//     and L1-bypassing (sc1) loads on the consumer -- measured 2.8 us per hand-off including 24 KB out and 24 KB in per
+//     workgroup, 0 stale words in 3e8 (tools/exp/xcd_sync_probe.hip);
+//   * across XCDs: write-through (sc1) stores into buffers that are read with sc1 loads only and never reused inside a launch,
+//     so that no L2 ever holds a stale or dirty copy of them;
+//   * a workgroup learns the XCD it runs on from HW_REG_XCC_ID (placement is measured, never assumed: the dispatcher's
+//     round-robin over the XCDs starts wherever the previous kernel left it);
+//   * every spin is bounded and looks at an abort word: a launch whose workgroups are not all resident gives up, the host
+//     redoes the update with the multi-launch schedule (xk_api.hip).
+// These orderings are stronger than what the relaxed agent-scope atomics below promise in the HIP memory model; they are what
+// gfx950 does, and tests/test_gpu_resident_caqr.py + tests/test_gpu_soak.py (random shapes against the C oracle) are the gate.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#ifndef XK_SPIN_SLEEP
+#define XK_SPIN_SLEEP 8             // s_sleep argument between two polls of a flag (x 64 clocks)
+#endif
+// a poll gives up after XK_SPIN_TICKS (2 ms: the longest wait of a healthy launch is the last level's for the first roots, tens
+// of microseconds; the first version's 0.2 s was six dropped camera frames)
+#ifndef XK_SPIN_TICKS
+#define XK_SPIN_TICKS 200000LL      // 100 MHz ticks
+#endif
+#define XK_CAQR_MAXP 32             // panels per launch (C1 <= 512)
+#define XK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ double xk_ld_sc1(const double *p) {
+  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), XK_RLX_AGENT));
+}
+__device__ __forceinline__ void xk_st_sc1(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), XK_RLX_AGENT);
+}
+__device__ __forceinline__ unsigned xk_xcc_id() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 7u;
+}
+
+// one lane polls one word (relaxed, L1-bypassing) until it reaches `target`
+__device__ __forceinline__ bool xk_spin_ge(unsigned *p, unsigned target, unsigned *abort_, unsigned reason) {
+  const long long t0 = wall_clock64();
+  for (unsigned it = 0;; ++it) {
+    if (__hip_atomic_load(p, XK_RLX_AGENT) >= target) return true;
+    if ((it & 63u) == 63u) {
+      if (__hip_atomic_load(abort_, XK_RLX_AGENT)) return false;
+      if (wall_clock64() - t0 > XK_SPIN_TICKS) break;
+    }
+    __builtin_amdgcn_s_sleep(XK_SPIN_SLEEP);
+  }
+  __hip_atomic_store(abort_, reason, XK_RLX_AGENT);
+  return false;
+}
+
+// Hides a pointer from loop-invariant code motion: the per-row addresses of a strip are then formed where they are used (one
+// 64-bit add each) instead of being hoisted out of the panel loop, dozens of registers' worth, and spilled.
+template <typename T> __device__ __forceinline__ T *xk_opaque(T *p) {
+  asm volatile("" : "+v"(p));
+  return p;
+}
