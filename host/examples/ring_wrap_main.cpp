@@ -36,12 +36,12 @@ static Matrix tail_cov(bool resident, int n_steps, int bsz, int N, bool *old_idx
     ekf.processImu(t, (unsigned)k, w, a);            // (the first call only records the measurement)
   }
   if (resident && old_idx_refused) {
-    // slot `tail + 1` is now the OLDEST state; the slot before the resident covariance's is older than it: no covariance
+    // a slot the ring never filled (only before the first wrap; afterwards the resident covariance belongs to the oldest
+    // state and every slot up to the tail has one) holds no covariance: covarianceAt must say so, not wrap around
     *old_idx_refused = false;
-    try {
-      // walk back from the tail until covarianceAt refuses
-      for (int back = 0; back < bsz; ++back) (void)ekf.covarianceAt(((int)(n_steps % bsz) - back + 4 * bsz) % bsz);
-    } catch (const std::out_of_range &) { *old_idx_refused = true; }
+    if (n_steps < bsz - 1) {
+      try { (void)ekf.covarianceAt((n_steps + 1) % bsz); } catch (const std::out_of_range &) { *old_idx_refused = true; }
+    }
   }
   return ekf.covarianceAt(-1);
 }
@@ -54,9 +54,8 @@ int main(int argc, char **argv) {
     double num = 0, den = 0;
     for (size_t i = 0; i < a.size(); ++i) { num += (a.data()[i] - b.data()[i]) * (a.data()[i] - b.data()[i]); den += b.data()[i] * b.data()[i]; }
     const double relv = std::sqrt(num / den);
-    // (n_steps < bsz - 1: nothing wrapped, every slot still has a covariance, nothing to refuse)
-    const bool wrapped = n_steps >= bsz - 1;
-    if (relv <= 1e-12 && (refused || !wrapped)) { printf("OK %.3e wrapped=%d refused_old=%d\n", relv, (int)wrapped, (int)refused); return 0; }
+    const bool wrapped = n_steps >= bsz, expect_refusal = n_steps < bsz - 1;
+    if (relv <= 1e-12 && refused == expect_refusal) { printf("OK %.3e wrapped=%d refused_old=%d\n", relv, (int)wrapped, (int)refused); return 0; }
     printf("FAIL rel=%.3e refused_old=%d\n", relv, (int)refused);
     return 1;
   } catch (const std::exception &e) {
