@@ -2,7 +2,10 @@
 //   Ekf::processUpdateMeasurement -> Updater::update -> VioUpdater::constructUpdate (stacked rows + MSCKF-MSCKF CI lists)
 //   -> applyCI per list entry -> applyUpdate -> State::correct
 // with the covariance owned by the State (reference semantics) or resident on the device (argv[3] = 1).
-//   in : N K n_agents n_matches sigma_img ci_msckf_w | per agent: q[4N] p[3N] P[n*n] | L_k[K] | obs[2*sum L]
+// A negative K means |K| regular tracks FOLLOWED BY short tracks (vio_updater.cpp:218-264; the MULTI_UAV build only takes
+// their CI entries, updater.cpp:52-66): the header then carries n_short right after ci_msckf_w, the short tracks' lengths and
+// observations follow the regular ones, and a match whose track index is >= K refers to short track (index - K).
+//   in : N K n_agents n_matches sigma_img ci_msckf_w [n_short] | per agent: q[4N] p[3N] P[n*n] | L_k[K (+ n_short)] | obs[2*sum L]
 //        | per match: track agent L obs[2L]
 //   out: P_post[n*n] | p_array[3N] q_array[4N] | p v q(xyzw) b_w b_a [16] | n_ci | inlier_msckf[K]
 #include <cstdio>
@@ -32,8 +35,9 @@ int main(int argc, char **argv) {
   const bool resident = argc > 3 && atoi(argv[3]) != 0;
   const std::vector<double> in = slurp(argv[1]);
   size_t at = 0;
-  const int N = (int)in[at++], K = (int)in[at++], n_agents = (int)in[at++], n_matches = (int)in[at++];
+  const int N = (int)in[at++], Kin = (int)in[at++], n_agents = (int)in[at++], n_matches = (int)in[at++];
   const double sigma_img = in[at++], ci_msckf_w = in[at++];
+  const int K = Kin < 0 ? -Kin : Kin, n_short = Kin < 0 ? (int)in[at++] : 0;
   const int n = kSizeCoreErr + 6 * N;
   std::vector<std::shared_ptr<SimpleState>> others(n_agents);
   State s(N, 0);
@@ -53,13 +57,13 @@ int main(int argc, char **argv) {
   }
   VioMeasurement meas;
   meas.timestamp = 1.0;
-  std::vector<int> L(K);
-  for (int k = 0; k < K; ++k) L[k] = (int)in[at++];
-  for (int k = 0; k < K; ++k) {
+  std::vector<int> L(K + n_short);
+  for (int k = 0; k < K + n_short; ++k) L[k] = (int)in[at++];
+  for (int k = 0; k < K + n_short; ++k) {
     Track t;
     t.setId(1000 + k);
     for (int i = 0; i < L[k]; ++i) { t.emplace_back(in[at], in[at + 1]); at += 2; }
-    meas.msckf_tracks.push_back(t);
+    (k < K ? meas.msckf_tracks : meas.msckf_short_tracks).push_back(t);
   }
   for (int m = 0; m < n_matches; ++m) {
     const int trk = (int)in[at++], agent = (int)in[at++], Lm = (int)in[at++];

@@ -94,6 +94,9 @@ struct xk_handle {
   // pinned staging ring for inputs copied to the device WITHOUT a host synchronisation (window, tracks, sparse operands):
   // a slot is reused XK_STAGE_SLOTS calls later, by which time an update's final synchronisation has long passed
   char *h_stage[XK_STAGE_SLOTS];
+  hipEvent_t stage_ev[XK_STAGE_SLOTS];   // recorded behind the copy that reads the slot; waited for before the slot is reused
+  bool stage_ev_set[XK_STAGE_SLOTS];
+  int stage_open;          // slot handed out last: its copy is queued by the time the next slot is asked for (-1: none)
   size_t stage_bytes;
   int stage_next;
   bool flags_direct;       // no SLAM rows in the last build: nothing was copied, the kernel wrote the cache
@@ -101,6 +104,7 @@ struct xk_handle {
   int *h_flag_i;
   double *h_flag_d;
   char *trk_slot;          // xk_stage_tracks_begin .. _end: the staging slot being filled
+  int trk_slot_idx;
   int trk_slot_K, trk_slot_nobs;
   bool async_pending;      // xk_build_compress_async ran: xk_apply_update owns the retry if the single-launch CAQR gave up
   // host pinned staging
@@ -302,6 +306,8 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
                              (sizeof(int) + sizeof(double)) * h->csr_cap + sizeof(int) * ((size_t)h->n + 1) + sizeof(double) * (XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max),
                              sizeof(double) * 8 * (size_t)std::max(n_feat_max, 1)}) + 256;
   for (auto &sp : h->h_stage) HIPCHK(h, hipHostMalloc((void **)&sp, h->stage_bytes));
+  for (auto &ev : h->stage_ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  h->stage_open = -1;
   HIPCHK(h, hipHostMalloc((void **)&h->h_flag_i, sizeof(int) * ((size_t)k_max + n_feat_max + 8)));
   HIPCHK(h, hipHostMalloc((void **)&h->h_flag_d, sizeof(double) * ((size_t)k_max + n_feat_max + 8)));
   memset(h->d_status, 0, sizeof(int) * 4);
@@ -345,6 +351,8 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
   for (auto &sp : h->h_stage)
     if (sp) hipHostFree(sp);
+  for (auto &ev : h->stage_ev)
+    if (ev) hipEventDestroy(ev);
   if (h->h_flag_i) hipHostFree(h->h_flag_i);
   if (h->h_flag_d) hipHostFree(h->h_flag_d);
   for (auto &e : h->ev)
@@ -362,11 +370,24 @@ extern "C" int xk_destroy(xk_handle *h) {
 // ---------------------------------------------------------------------------
 // next slot of the pinned ring: host inputs are copied there and go to the device with an asynchronous copy, so that
 // staging never waits for the device (the caller's buffers are free on return, as before)
+// A slot is reused XK_STAGE_SLOTS staging calls later.  Nothing in between need have synchronised the stream (a loop of
+// xk_cov_congruence, repeated re-staging), so the copy that reads a slot is followed by an event, recorded when the NEXT
+// slot is asked for -- every caller queues its copy right after taking its slot -- and waited for before the slot goes out
+// again: free in the normal case, the copy finished long ago.
+static void stage_close(xk_handle *h) {
+  if (h->stage_open >= 0) {
+    if (hipEventRecord(h->stage_ev[h->stage_open], h->stream) == hipSuccess) h->stage_ev_set[h->stage_open] = true;
+    h->stage_open = -1;
+  }
+}
 static char *stage_slot(xk_handle *h, size_t bytes) {
   if (bytes > h->stage_bytes) return nullptr;
-  char *p = h->h_stage[h->stage_next];
-  h->stage_next = (h->stage_next + 1) % XK_STAGE_SLOTS;
-  return p;
+  stage_close(h);
+  const int s = h->stage_next;
+  if (h->stage_ev_set[s]) { hipEventSynchronize(h->stage_ev[s]); h->stage_ev_set[s] = false; }
+  h->stage_open = s;
+  h->stage_next = (s + 1) % XK_STAGE_SLOTS;
+  return h->h_stage[s];
 }
 
 extern "C" int xk_stage_window(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses) {
@@ -396,6 +417,7 @@ extern "C" int xk_stage_tracks_begin(xk_handle *h, int K, int n_obs, int **trk_o
   char *st = stage_slot(h, ob + sizeof(int) * (K + 1));
   if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
   h->trk_slot = st; h->trk_slot_K = K; h->trk_slot_nobs = n_obs;
+  h->trk_slot_idx = h->stage_open; h->stage_open = -1;     // (its copy is queued by _end, which records the slot's event itself)
   *obs_xy = (double *)st;
   *trk_off = (int *)(st + ob);
   return XK_OK;
@@ -420,6 +442,7 @@ extern "C" int xk_stage_tracks_end(xk_handle *h) {
     HIPCHK(h, hipSetDevice(h->device));
     h->d_trk_off = (int *)(h->d_obs + 2 * (size_t)trk_off[K]);         // offsets right behind the observations in use
     HIPCHK(h, hipMemcpyAsync(h->d_obs, st, ob + sizeof(int) * (K + 1), hipMemcpyHostToDevice, h->stream));
+    if (h->trk_slot_idx >= 0 && hipEventRecord(h->stage_ev[h->trk_slot_idx], h->stream) == hipSuccess) h->stage_ev_set[h->trk_slot_idx] = true;
     memcpy(h->h_trk_off, trk_off, sizeof(int) * (K + 1));
   }
   h->K = K;
@@ -1312,11 +1335,31 @@ extern "C" int xk_apply_ci(xk_handle *h, double *P_out, int ldp, const double *c
 
 // applyCI on the RESIDENT covariance: P <- sym((I - K H) ci_P) replaces the handle's covariance and stays on the
 // device (the host mirror's resident mode; the compressed [T_H | z] of a pending xk_apply_update is not touched).
+// A build + compression queued by xk_build_compress_async whose single-launch CAQR gave up must be redone (multi-launch
+// schedule) while the covariance it was linearised at is still the resident one: BEFORE a CI entry replaces it.  After this
+// the compressed [T_H | z] is known to be good and xk_apply_update has nothing to retry.
+static int settle_async(xk_handle *h) {
+  if (!h->async_pending) return XK_OK;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int rc = eval_status(h, h->d_status[0], h->d_status[1], true);
+  if (rc == XK_RETRY_CLASSIC) {
+    if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
+    if ((rc = cache_flags(h)) != XK_OK) return rc;
+    if ((rc = launch_compress(h)) != XK_OK) return rc;
+  }
+  if (rc == XK_OK) h->async_pending = false;
+  return rc;
+}
+
 extern "C" int xk_apply_ci_resident(xk_handle *h, const double *ci_P, int ldc, int n, const double *H, int ldh, int m,
                                     const double *res, const double *S, int lds, double *correction) {
   if (!h || !ci_P || !H || !res || !S || !correction || n != h->n || ldc < n || ldh < m || lds < m || m <= 0) return XK_EINVAL;
   if (m > h->CM) return fail(h, XK_ECAPACITY, "m exceeds the dense workspace");
   HIPCHK(h, hipSetDevice(h->device));
+  {
+    const int rs = settle_async(h);
+    if (rs != XK_OK) return rs;
+  }
   HIPCHK(h, hipMemcpy2DAsync(h->d_tmpP, sizeof(double) * n, ci_P, sizeof(double) * ldc, sizeof(double) * n, n,
                              hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpy2DAsync(h->d_tmpH, sizeof(double) * m, H, sizeof(double) * ldh, sizeof(double) * m, n,

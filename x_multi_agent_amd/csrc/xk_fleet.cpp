@@ -54,8 +54,8 @@ extern "C" int xk_fleet_create(xk_handle *h, const unsigned char id[XK_FLEET_ID_
 
 extern "C" int xk_fleet_destroy(xk_fleet *f) {
   if (!f) return XK_OK;
-  hipSetDevice(f->device);
-  hipStreamSynchronize(f->stream);
+  (void)hipSetDevice(f->device);
+  (void)hipStreamSynchronize(f->stream);
   ncclCommDestroy(f->comm);
   free(f);
   return XK_OK;
@@ -78,9 +78,15 @@ extern "C" int xk_fleet_send_recv(xk_fleet *f, const double *d_send, long send_c
   if ((send_peer >= 0 && (!d_send || send_count <= 0)) || (recv_peer >= 0 && (!d_recv || recv_count <= 0))) return XK_EINVAL;
   if (hipSetDevice(f->device) != hipSuccess) return XK_EDEVICE;
   NCHK(f, ncclGroupStart());
-  if (send_peer >= 0) NCHK(f, ncclSend(d_send, (size_t)send_count, ncclDouble, send_peer, f->comm, f->stream));
-  if (recv_peer >= 0) NCHK(f, ncclRecv(d_recv, (size_t)recv_count, ncclDouble, recv_peer, f->comm, f->stream));
-  NCHK(f, ncclGroupEnd());
+  // (a group that was opened is always closed, also when a call inside it fails: a communicator left inside a group would
+  //  swallow every later call)
+  ncclResult_t rs = ncclSuccess, rr = ncclSuccess;
+  if (send_peer >= 0) rs = ncclSend(d_send, (size_t)send_count, ncclDouble, send_peer, f->comm, f->stream);
+  if (rs == ncclSuccess && recv_peer >= 0) rr = ncclRecv(d_recv, (size_t)recv_count, ncclDouble, recv_peer, f->comm, f->stream);
+  const ncclResult_t re = ncclGroupEnd();
+  NCHK(f, rs);
+  NCHK(f, rr);
+  NCHK(f, re);
   return XK_OK;
 }
 
