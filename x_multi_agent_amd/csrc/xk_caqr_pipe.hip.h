@@ -107,6 +107,27 @@ __device__ __forceinline__ bool xk_pipe_wait(unsigned *word, unsigned target, un
   return ok;
 }
 
+// Waits for phase q of a producer and looks (without waiting) how many of the following phases are complete as well: the
+// consumer then fetches all of them at once.  A level that runs behind its producer finds the next phases ready and saves
+// their waits and load latencies; rows fetched early are harmless -- the strips are upper triangular in the panel columns,
+// so the reflectors of the earlier steps are zero in those rows.  cnt0 = phase 0's counter, `stride` words between phases.
+// Returns the number of complete phases (> q), 0 if the wait gave up.
+__device__ __forceinline__ int xk_pipe_wait_phases(unsigned *cnt0, int stride, int q, int nph, unsigned target, unsigned *ab, unsigned reason,
+                                                   unsigned *s_ok) {
+  if (threadIdx.x == 0) {
+    unsigned av = 0;
+    if (xk_spin_ge(cnt0 + (size_t)q * stride, target, ab, reason)) {
+      av = (unsigned)q + 1u;
+      while ((int)av < nph && __hip_atomic_load(cnt0 + (size_t)av * stride, XK_RLX_AGENT) >= target) ++av;
+    }
+    *s_ok = av;
+  }
+  __syncthreads();
+  const int av = (int)*s_ok;
+  __syncthreads();
+  return av;
+}
+
 // xk_caqr_apply (tile layout, 4 lanes per column) with the reflector fetched in two halves: at 32 rows per lane the lane's
 // rows (64 VGPRs) + the whole reflector (64) + the step's temporaries do not fit 168 registers, and what the compiler
 // spilled was reloaded inside every step.  Same sums in the same order; the first half is read from LDS a second time.
@@ -208,18 +229,28 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
   const int npanels = (a.C1 + 15) / 16;
   const bool stamp = a.dbg && xcc == 0 && slot == 1 && tid == 0;
   double b[RPL];
-  {   // the one pass over the stack: gather my rows through the row map
+  {   // The one pass over the stack: gather my rows through the row map.  Branch-free and in batches -- every index is clamped into
+      // range and every load issued whether or not its value is used -- so that 32 (row map) resp. 16 + 16 (verdict + row) loads
+      // are in flight at a time: with a branch per row the compiler waited for each row's row-map entry and then for its data,
+      // 64 dependent round trips = 22 us of the launch.
     const int g0 = j * a.TR + part_ * RPL, gend = min(min((j + 1) * a.TR, g0 + RPL), a.R);
+    const int last = max(a.R - 1, 0);
+    int pr[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-      const int g = g0 + r;
-      double v = 0.0;
-      if (mine && g < gend) {
-        const int pr = a.rowmap[g];
-        const double x = a.A[(size_t)pr * a.C1P + cabs];
-        v = (a.tile_rows[pr >> 6] > 0) ? x : 0.0;
+    for (int r = 0; r < RPL; ++r) pr[r] = a.rowmap[min(g0 + r, last)];
+    const double *Ac = a.A + cabs;                          // (cabs < C1P: inside the row whether or not the column exists)
+#pragma unroll
+    for (int h0 = 0; h0 < RPL; h0 += 16) {
+      int tr[16];
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (h0 + r < RPL) { tr[r] = a.tile_rows[pr[h0 + r] >> 6]; x[r] = Ac[(size_t)pr[h0 + r] * a.C1P]; }
       }
-      b[r] = v;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (h0 + r < RPL) b[h0 + r] = (mine && g0 + h0 + r < gend && tr[r] > 0) ? x[r] : 0.0;
+      }
     }
   }
   double *myS = a.S + (size_t)j * 16 * a.C1P;
@@ -333,17 +364,22 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     double *x1 = panel ? a.X1P + slab * 256 + xk_blk(cidx, part) : a.X1 + slab * SS + xk_blk(col, part);
     const bool x1_mine = mine && (!panel || item == 0);
     bool ok = true;
+    int loaded = 0;                                        // phases of the tiles' strips that are in registers
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (!ok) return;
-      if (!xk_pipe_wait(sync + (XP_TQ_CNT + q * 8 + xcc) * 16, (unsigned)NT * epoch, ab, 6u, s_ok)) { ok = false; return; }
-      if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
-      if (!active) return;
-      if (mine && part >= q * G && part < (q + 1) * G) {
-        double *g = xk_opaque(g0);
+      if (loaded <= q) {
+        const int av = xk_pipe_wait_phases(sync + (XP_TQ_CNT + xcc) * 16, 8 * 16, q, NPH, (unsigned)NT * epoch, ab, 6u, s_ok);
+        if (av == 0) { ok = false; return; }
+        if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
+        if (active && mine && part >= loaded * G && part < av * G) {
+          double *g = xk_opaque(g0);
 #pragma unroll
-        for (int s = 1; s < RM; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
+          for (int s = 1; s < RM; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
+        }
+        loaded = av;
       }
+      if (!active) return;
       if (panel) __builtin_amdgcn_s_setprio(3);
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
@@ -412,14 +448,19 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
 #pragma unroll
     for (int s = 0; s < RL; ++s) b[s] = 0.0;
     bool ok = true;
+    int loaded = 0;
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (!ok || nsteps <= q * G) return;                  // (a short last panel: the roots' rows past its columns are zero)
-      if (!xk_pipe_wait(sync + (XP_X1_CNT + q * XK_CAQR_MAXP + k) * 16, 8u * XK_PIPE_NM, ab, 5u, s_ok)) { ok = false; return; }
-      if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
-      if (mine && part >= q * G && part < (q + 1) * G) {
+      if (loaded <= q) {
+        const int av = xk_pipe_wait_phases(sync + (XP_X1_CNT + k) * 16, XK_CAQR_MAXP * 16, q, NPH, 8u * XK_PIPE_NM, ab, 5u, s_ok);
+        if (av == 0) { ok = false; return; }
+        if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
+        if (mine && part >= loaded * G && part < av * G) {
 #pragma unroll
-        for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
+          for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
+        }
+        loaded = av;
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
       xk_pipe_range<false, q * G, (q + 1) * G, -1, RL>(b, panel ? cidx : 16, mine, part, nsteps, ubuf, sc, false, []() {});
