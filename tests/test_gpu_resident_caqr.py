@@ -14,15 +14,20 @@ from x_multi_agent_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(xk, sc, resident):
+def _run(xk, sc, resident, ms_tracks=None):
     os.environ["XK_CAQR_RESIDENT"] = "1" if resident else "0"
     try:
         N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
-        eng = xk.Engine(N, 0, K)
+        M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+        eng = xk.Engine(N, M, max(K, 1))
         eng.stage(sc)
+        if ms_tracks is not None:
+            eng.stage_msckf_slam(ms_tracks)
         r = eng.visual_update_staged(sc["sigma_img"])
         P = eng.download_P()
         eng.stage(sc)
+        if ms_tracks is not None:
+            eng.stage_msckf_slam(ms_tracks)
         t = eng.bench_staged(sc["sigma_img"], 0, 1)
         eng.close()
         return r, P, t
@@ -38,7 +43,15 @@ CASES = {
     "partial_window": lambda: synth.make_scenario(30, 120, 0, seed=903, n_poses=17),
     "just_enough_rows": lambda: synth.make_scenario(12, 26, 0, seed=904),       # 546 rows: 3 rows per fat tile
     "stress_prior": lambda: synth.make_scenario(24, 350, 0, seed=905, prior_kind="stress", prior_scale=0.01),
+    # SLAM rows and systems wider than 192 columns: the wide geometry (2 lanes per column, 152 tiles of 80 rows)
+    "cfg2": lambda: synth.make_config(2),
+    "slam_heavy": lambda: synth.make_scenario(20, 150, 40, seed=908),
+    "slam_ragged": lambda: synth.make_scenario(30, 120, 25, seed=909, track_len=(2, 30)),
+    "wide_no_slam_rows": lambda: synth.make_scenario(33, 150, 0, seed=910),          # 199 columns: wide because of the window alone
+    # SLAM rows in a system that still fits 192 columns: the narrow geometry with all three row kinds in its row map
+    "narrow_with_slam": lambda: synth.make_scenario(20, 200, 10, seed=912),
 }
+NLEAF = {"cfg2": 152, "slam_heavy": 152, "slam_ragged": 152, "wide_no_slam_rows": 152}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -46,7 +59,7 @@ def test_resident_equals_multi_launch(xk, oracle_c, name):
     sc = CASES[name]()
     ra, Pa, ta = _run(xk, sc, True)
     rb, Pb, tb = _run(xk, sc, False)
-    assert ta["n_levels"] == 1 and ta["n_leaf"] == 184, "the resident path did not run"
+    assert ta["n_levels"] == 1 and ta["n_leaf"] == NLEAF.get(name, 184), "the single-launch path did not run"
     assert tb["n_levels"] > 1
     assert np.array_equal(ra["inlier"], rb["inlier"])
     assert rel(Pa, Pb) <= 1e-11 and rel(ra["correction"], rb["correction"]) <= 1e-9
@@ -55,15 +68,30 @@ def test_resident_equals_multi_launch(xk, oracle_c, name):
     assert rel(Pa, ref["P"]) <= 1e-8
 
 
+def test_msckf_slam_rows_go_through_the_single_launch_too(xk, oracle_c):
+    """All three row kinds of vio_updater.cpp:406-422 in one stack -- MSCKF tracks, MSCKF-SLAM tracks (the landmark becomes a
+    persistent feature this frame), SLAM rows -- single launch against the multi-launch schedule."""
+    sc = synth.make_scenario(16, 60, 6, seed=913)
+    tr = synth.tracks_as_list(sc)
+    sc2 = dict(sc)
+    sc2["trk_off"] = sc["trk_off"][:51].copy()
+    sc2["obs_xy"] = sc["obs_xy"][:sc["trk_off"][50]].copy()
+    ra, Pa, ta = _run(xk, sc2, True, ms_tracks=tr[50:56])
+    rb, Pb, tb = _run(xk, sc2, False, ms_tracks=tr[50:56])
+    assert ta["n_levels"] == 1 and ta["n_leaf"] == 184 and tb["n_levels"] > 1
+    assert np.array_equal(ra["inlier"], rb["inlier"])
+    assert rel(Pa, Pb) <= 1e-11 and rel(ra["correction"], rb["correction"]) <= 1e-9
+
+
 def test_resident_path_steps_aside_when_it_does_not_apply(xk):
-    """SLAM rows, too many rows for 184 x 128, or too few rows: the multi-launch schedule runs (and nothing breaks)."""
-    for sc in (synth.make_config(2), synth.make_scenario(40, 420, 0, seed=906), synth.make_scenario(8, 10, 0, seed=907)):
+    """Windows of more than 33 poses (128-row slots), too many rows, or too few rows: the multi-launch schedule runs."""
+    for sc in (synth.make_config(3), synth.make_scenario(40, 420, 0, seed=906), synth.make_scenario(8, 10, 0, seed=907)):
         N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
         M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
         eng = xk.Engine(N, M, K)
         eng.stage(sc)
         t = eng.bench_staged(sc["sigma_img"], 0, 1)
-        assert t["n_leaf"] != 184
+        assert t["n_levels"] > 1
         eng.close()
 
 

@@ -235,10 +235,11 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     // the device must expose 256 CUs to this process (SPX mode, no CU mask visible in the properties) and the runtime must
     // agree that a 768-thread workgroup of each kernel fits a CU; what cannot be known here (another process on the GPU,
     // a CU mask set behind the runtime's back) is caught by the placement census and the bounded spins inside the launch.
-    h->persist_ok = h->DB == 64 && h->C1 <= 192 && h->n_cu == 256;
+    h->persist_ok = h->DB == 64 && h->C1 <= XkPipeWide::COLS && h->n_cu == 256;
     if (h->persist_ok) {
       int nb1 = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void *)xk_caqr_pipe, XK_PIPE_THREADS, 0) != hipSuccess) nb1 = 0;
+      const void *kfn = h->C1 <= XkPipeNarrow::COLS ? (const void *)xk_caqr_pipe<XkPipeNarrow> : (const void *)xk_caqr_pipe<XkPipeWide>;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, kfn, XK_PIPE_THREADS, 0) != hipSuccess) nb1 = 0;
       h->persist_ok = nb1 >= 1;
       (void)hipGetLastError();
     }
@@ -249,9 +250,9 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
-      HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_PIPE_NT * 16 * h->C1P));
-      HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_PIPE_NT * 256));
-      HIPCHK(h, dalloc(&h->d_rowmap, (size_t)8 * XK_PIPE_NT * 4 * XK_PIPE_RPL));
+      HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_PIPE_NT_MAX * 16 * h->C1P));
+      HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_PIPE_NT_MAX * 256));
+      HIPCHK(h, dalloc(&h->d_rowmap, (size_t)XK_PIPE_ROWS_MAX));
       HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
       HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
       h->xsync_phase = 0;
@@ -760,32 +761,45 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   int launches = 0;
   // register-resident single launch (xk_caqr_pipe.hip.h): MSCKF tracks only, valid rows <= 184 fat tiles of 128
   const int resident_env = env_int("XK_CAQR_RESIDENT", 1);   // (read per call: tests switch it inside one process)
-  if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && h->M == 0 && h->K2 == 0 && h->K > 0 &&
-      ++h->clean_classic > h->rearm_after) {
+  const bool fast_shape = h->K + h->K2 > 0 || h->M > 0;
+  if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && fast_shape && ++h->clean_classic > h->rearm_after) {
     h->persist_ok = true;                         // (the sync words of a launch that gave up are cleared below)
     h->clean_classic = 0;
   }
-  if (resident_env && h->persist_ok && h->M == 0 && h->K2 == 0 && h->K > 0) {
-    // row map: valid row g -> physical row of the 64-row slots (depends on the track lengths only)
-    bool same = h->rowmap_R >= 0 && (int)h->h_rowlens->size() == h->K;
-    for (int k = 0; same && k < h->K; ++k) same = (*h->h_rowlens)[k] == h->h_trk_off[k + 1] - h->h_trk_off[k];
-    int R = h->rowmap_R;
+  if (resident_env && h->persist_ok && fast_shape) {
+    // row map: valid row g -> physical row of the 64-row slots, in the reference's stacking order (vio_updater.cpp:406-422):
+    // MSCKF tracks (2 L - 3 rows each), MSCKF-SLAM tracks, then the packed SLAM rows.  It depends on the track lengths and
+    // the number of persistent features only, so it is rebuilt (and uploaded) when those change.
+    const bool narrow = h->C1 <= XkPipeNarrow::COLS;
+    const int rows_cap = narrow ? XkPipeNarrow::ROWS : XkPipeWide::ROWS;
+    std::vector<int> &key = *h->h_rowlens;
+    const size_t nkey = (size_t)h->K + h->K2 + 2;
+    bool same = h->rowmap_R >= 0 && key.size() == nkey && key[h->K] == -1 - h->K2 && key[nkey - 1] == h->M;
+    for (int k = 0; same && k < h->K; ++k) same = key[k] == h->h_trk_off[k + 1] - h->h_trk_off[k];
+    for (int k = 0; same && k < h->K2; ++k) same = key[h->K + 1 + k] == h->h_trk2_off[k + 1] - h->h_trk2_off[k];
     if (!same) {
-      h->h_rowlens->resize(h->K);
-      R = 0;
-      for (int k = 0; k < h->K; ++k) { (*h->h_rowlens)[k] = h->h_trk_off[k + 1] - h->h_trk_off[k]; R += 2 * (*h->h_rowlens)[k] - 3; }
+      key.resize(nkey);
+      int R = 0;
+      for (int k = 0; k < h->K; ++k) { key[k] = h->h_trk_off[k + 1] - h->h_trk_off[k]; R += 2 * key[k] - 3; }
+      key[h->K] = -1 - h->K2;
+      for (int k = 0; k < h->K2; ++k) { key[h->K + 1 + k] = h->h_trk2_off[k + 1] - h->h_trk2_off[k]; R += 2 * key[h->K + 1 + k] - 3; }
+      key[nkey - 1] = h->M;
+      R += 2 * h->M;
       h->rowmap_R = -1;
-      if (R <= 8 * XK_PIPE_NT * 4 * XK_PIPE_RPL && (size_t)R * sizeof(int) <= h->stage_bytes) {
+      if (R <= rows_cap && (size_t)R * sizeof(int) <= h->stage_bytes) {
         int *st = (int *)stage_slot(h, sizeof(int) * (size_t)R);
         int g = 0;
         for (int k = 0; k < h->K; ++k)
-          for (int i = 0; i < 2 * (*h->h_rowlens)[k] - 3; ++i) st[g++] = k * 64 + i;
+          for (int i = 0; i < 2 * key[k] - 3; ++i) st[g++] = k * 64 + i;
+        for (int k = 0; k < h->K2; ++k)
+          for (int i = 0; i < 2 * key[h->K + 1 + k] - 3; ++i) st[g++] = (h->K + k) * 64 + i;
+        for (int i = 0; i < 2 * h->M; ++i) st[g++] = (h->K + h->K2) * 64 + i;      // (SLAM rows are packed 64 to a slot)
         if (hipMemcpyAsync(h->d_rowmap, st, sizeof(int) * (size_t)R, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "row map");
         h->rowmap_R = R;
       }
     }
-    const int NTP = 8 * XK_PIPE_NT;
-    if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTP - 1) / NTP <= 4 * XK_PIPE_RPL) {
+    const int NTP = 8 * (narrow ? XkPipeNarrow::NT : XkPipeWide::NT), rows_tile = narrow ? XkPipeNarrow::LPC * XkPipeNarrow::RPL : XkPipeWide::LPC * XkPipeWide::RPL;
+    if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTP - 1) / NTP <= rows_tile) {
       XkCaqrPipeArgs pa;
       pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.rowmap = h->d_rowmap; pa.R = h->rowmap_R; pa.TR = (h->rowmap_R + NTP - 1) / NTP;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
@@ -797,6 +811,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       pa.sync = h->d_xsync + (size_t)h->xsync_phase * XP_WORDS * 16;
       pa.sync_next = h->d_xsync + (size_t)(h->xsync_phase ^ 1) * XP_WORDS * 16;
       h->xsync_phase ^= 1;
+      // test hook: raise the abort word before the launch -- every workgroup gives up at its first spin, exactly what an
+      // uneven placement or a missing workgroup leads to, and the host has to redo the update with the multi-launch schedule
       if (env_int("XK_CAQR_RESIDENT_POISON", 0)) {
         const unsigned seven = 7u;
         if (hipMemcpyAsync(pa.sync + XP_ABORT * 16, &seven, sizeof(unsigned), hipMemcpyHostToDevice, h->stream) != hipSuccess)
@@ -806,7 +822,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
       pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
       pa.test_stall = env_int("XK_CAQR_TEST_STALL", 0);
-      hipLaunchKernelGGL(xk_caqr_pipe, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeWide>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       if (mid) hipEventRecord(mid, h->stream);
       h->nleaf = NTP; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = true;
       hipError_t e = hipGetLastError();

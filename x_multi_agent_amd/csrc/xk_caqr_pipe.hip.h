@@ -32,9 +32,22 @@
 #include "xk_xcd_sync.hip.h"
 
 #define XK_PIPE_THREADS 768
-#define XK_PIPE_RPL 32              // rows per lane of a fat tile: 4 x 32 = 128 rows
-#define XK_PIPE_NT 23               // tile workgroups per XCD
-#define XK_PIPE_NM 8                // first-level workgroups per XCD   (NT + NM + 1 = 32 = CUs of an XCD)
+// Geometry of a launch.  LPC lanes per column x RPL rows per lane = rows of a fat tile (768 / LPC columns per workgroup);
+// per XCD: NT tile workgroups + NM first-level workgroups + 1 last-level workgroup = 32 = the CUs of an XCD; NCL = column
+// sets per last-level thread (its 8 workgroups cover NCL x 8 x <= 32 trailing columns).
+template <int LPC_, int RPL_, int NT_, int NM_, int NCL_>
+struct XkPipeGeom {
+  static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_;
+  static constexpr int RM = (NT_ + 2) & ~1;                // registers of a first-level lane: pending strip + NT strips, even
+  static constexpr int COLS = XK_PIPE_THREADS / LPC_;      // widest system (C1P) a tile workgroup holds
+  static constexpr int ROWS = 8 * NT_ * LPC_ * RPL_;       // most stacked rows
+  static_assert(NT_ + NM_ + 1 == 32, "one workgroup per CU, 32 CUs per XCD");
+  static_assert(RPL_ % 4 == 0 && RPL_ >= 16, "the pivot strip is the first 16 rows of the part-0 lane");
+};
+using XkPipeNarrow = XkPipeGeom<4, 32, 23, 8, 1>;          // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
+using XkPipeWide = XkPipeGeom<2, 40, 19, 12, 2>;           // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
+#define XK_PIPE_NT_MAX 23
+#define XK_PIPE_ROWS_MAX 23552
 #ifndef XK_PIPE_NPH
 #define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
 #endif
@@ -128,103 +141,114 @@ __device__ __forceinline__ int xk_pipe_wait_phases(unsigned *cnt0, int stride, i
   return av;
 }
 
-// xk_caqr_apply (tile layout, 4 lanes per column) with the reflector fetched in two halves: at 32 rows per lane the lane's
-// rows (64 VGPRs) + the whole reflector (64) + the step's temporaries do not fit 168 registers, and what the compiler
-// spilled was reloaded inside every step.  Same sums in the same order; the first half is read from LDS a second time.
-template <int KK, int RPL>
+// xk_caqr_apply (tile layout, LPC lanes per column) with the reflector fetched in two halves: past 32 rows per lane the lane's
+// rows + the whole reflector + the step's temporaries do not fit 168 registers.  Same sums in the same order; the first half
+// is read from LDS a second time.  (At 32 rows per lane the plain version spills a few loop invariants and is still 2 %
+// faster: XK_PIPE_CHUNK = 0.)
+template <int KK, int LPC, int RPL>
 __device__ __forceinline__ void xk_pipe_tapply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
-#if XK_PIPE_CHUNK
-  constexpr int RPLP = RPL + 2, H = RPL / 4;
-  constexpr int pb = KK & 1;
-  const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * 4 + part) * RPLP);
-  const double mtt = sc[pb * 4];
-  if (rel > KK && live && mtt != 0.0) {
-    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-    {
-      xk_d2 u[H];
+  if constexpr (XK_PIPE_CHUNK || RPL > 32) {
+    constexpr int RPLP = RPL + 2, H = RPL / 4;
+    constexpr int pb = KK & 1;
+    const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * LPC + part) * RPLP);
+    const double mtt = sc[pb * 4];
+    if (rel > KK && live && mtt != 0.0) {
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+      {
+        xk_d2 u[H];
 #pragma unroll
-      for (int r = 0; r < H; ++r) u[r] = useg[r];
+        for (int r = 0; r < H; ++r) u[r] = useg[r];
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+          if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+          else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+        }
+      }
+      xk_d2 v[H];
+#pragma unroll
+      for (int r = 0; r < H; ++r) v[r] = useg[H + r];
 #pragma unroll
       for (int r = 0; r < H; ++r) {
-        if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
-        else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+        if ((H + r) & 1) { d2 = fma(v[r][0], b[2 * (H + r)], d2); d3 = fma(v[r][1], b[2 * (H + r) + 1], d3); }
+        else { d0 = fma(v[r][0], b[2 * (H + r)], d0); d1 = fma(v[r][1], b[2 * (H + r) + 1], d1); }
+      }
+      const double w = mtt * xk_group_sum<LPC>((d0 + d1) + (d2 + d3));
+#pragma unroll
+      for (int r = 0; r < H; ++r) {
+        b[2 * (H + r)] = fma(w, v[r][0], b[2 * (H + r)]);
+        b[2 * (H + r) + 1] = fma(w, v[r][1], b[2 * (H + r) + 1]);
+      }
+      const xk_d2 *useg2 = useg + xk_launder(0);             // (a second look at the same LDS words, not the registers of the first)
+#pragma unroll
+      for (int r = 0; r < H; ++r) {
+        const xk_d2 u = useg2[r];
+        b[2 * r] = fma(w, u[0], b[2 * r]);
+        b[2 * r + 1] = fma(w, u[1], b[2 * r + 1]);
       }
     }
-    xk_d2 v[H];
-#pragma unroll
-    for (int r = 0; r < H; ++r) v[r] = useg[H + r];
-#pragma unroll
-    for (int r = 0; r < H; ++r) {
-      if ((H + r) & 1) { d2 = fma(v[r][0], b[2 * (H + r)], d2); d3 = fma(v[r][1], b[2 * (H + r) + 1], d3); }
-      else { d0 = fma(v[r][0], b[2 * (H + r)], d0); d1 = fma(v[r][1], b[2 * (H + r) + 1], d1); }
-    }
-    const double w = mtt * xk_group_sum<4>((d0 + d1) + (d2 + d3));
-#pragma unroll
-    for (int r = 0; r < H; ++r) {
-      b[2 * (H + r)] = fma(w, v[r][0], b[2 * (H + r)]);
-      b[2 * (H + r) + 1] = fma(w, v[r][1], b[2 * (H + r) + 1]);
-    }
-    const xk_d2 *useg2 = useg + xk_launder(0);             // (a second look at the same LDS words, not the registers of the first)
-#pragma unroll
-    for (int r = 0; r < H; ++r) {
-      const xk_d2 u = useg2[r];
-      b[2 * r] = fma(w, u[0], b[2 * r]);
-      b[2 * r + 1] = fma(w, u[1], b[2 * r + 1]);
-    }
+  } else {
+    xk_caqr_apply<KK, LPC, RPL>(b, rel, live, part, ubuf, sc);
   }
-#else
-  xk_caqr_apply<KK, 4, RPL>(b, rel, live, part, ubuf, sc);
-#endif
 }
 
 // Steps [K0, K1) of a panel with the one-reflector look-ahead of xk_caqr_steps_la; on entry every reflector < K0 has been
-// applied, on return every reflector < min(K1, nsteps).  TILE = the tile layout (4 lanes per column), else the merge layout.
+// applied, on return every reflector < min(K1, nsteps).
 // KH: the iteration whose barrier carries a hand-off -- every wave drains its stores before it, thread 0 runs `hook` after it.
-template <bool TILE, int K, int RPL>
+// LPC > 0: the tile layout with LPC lanes per column; LPC = 0: the merge layout (16 lanes per column).  b2 (merge layout only):
+// a second set of trailing columns of the same lanes -- it only ever takes reflectors, it never owns one.
+template <int LPC, int K, int RPL>
 __device__ __forceinline__ void xk_pipe_form(double (&b)[RPL], int rel, int part, double *ubuf, double *sc) {
-  if constexpr (TILE) xk_caqr_form<K, 4, RPL>(b, rel, part, ubuf, sc);
+  if constexpr (LPC > 0) xk_caqr_form<K, LPC, RPL>(b, rel, part, ubuf, sc);
   else xk_caqr_mform<K, RPL>(b, rel, part, ubuf, sc);
 }
-template <bool TILE, int K, int RPL>
+template <int LPC, int K, int RPL>
 __device__ __forceinline__ void xk_pipe_apply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
-  if constexpr (TILE) xk_pipe_tapply<K, RPL>(b, rel, live, part, ubuf, sc);
+  if constexpr (LPC > 0) xk_pipe_tapply<K, LPC, RPL>(b, rel, live, part, ubuf, sc);
   else xk_caqr_apply<K, 16, RPL>(b, rel, live, part, ubuf, sc);
 }
-template <bool TILE, int K, int K1, int KH, int RPL, typename Hook>
-__device__ __forceinline__ void xk_pipe_range_it(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc, bool hook_on, Hook hook) {
+template <int LPC, int K, int RPL>
+__device__ __forceinline__ void xk_pipe_apply2(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, const double *ubuf,
+                                               const double *sc) {
+  xk_pipe_apply<LPC, K, RPL>(b, rel, live, part, ubuf, sc);
+  if (b2) xk_pipe_apply<LPC, K, RPL>(*b2, 16, live2, part, ubuf, sc);
+}
+template <int LPC, int K, int K1, int KH, int RPL, typename Hook>
+__device__ __forceinline__ void xk_pipe_range_it(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, int nsteps,
+                                                 double *ubuf, double *sc, bool hook_on, Hook hook) {
   if constexpr (K < K1) {
     if (K < nsteps) {
-      xk_pipe_apply<TILE, K - 1, RPL>(b, rel, live, part, ubuf, sc);
-      xk_pipe_form<TILE, K, RPL>(b, rel, part, ubuf, sc);
+      xk_pipe_apply2<LPC, K - 1, RPL>(b, b2, rel, live, live2, part, ubuf, sc);
+      xk_pipe_form<LPC, K, RPL>(b, rel, part, ubuf, sc);
       if (K == KH && hook_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (K == KH && hook_on && threadIdx.x == 0) hook();
     } else if (K == nsteps) {
-      xk_pipe_apply<TILE, K - 1, RPL>(b, rel, live, part, ubuf, sc);
+      xk_pipe_apply2<LPC, K - 1, RPL>(b, b2, rel, live, live2, part, ubuf, sc);
     }
-    xk_pipe_range_it<TILE, K + 1, K1, KH, RPL>(b, rel, live, part, nsteps, ubuf, sc, hook_on, hook);
+    xk_pipe_range_it<LPC, K + 1, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook);
   }
 }
-template <bool TILE, int K0, int K1, int KH, int RPL, typename Hook>
-__device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], int rel, bool live, int part, int nsteps, double *ubuf, double *sc, bool hook_on, Hook hook) {
-  if (K0 < nsteps) xk_pipe_form<TILE, K0, RPL>(b, rel, part, ubuf, sc);
+template <int LPC, int K0, int K1, int KH, int RPL, typename Hook>
+__device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, int nsteps,
+                                              double *ubuf, double *sc, bool hook_on, Hook hook) {
+  if (K0 < nsteps) xk_pipe_form<LPC, K0, RPL>(b, rel, part, ubuf, sc);
   if (KH == K0 && hook_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (KH == K0 && hook_on && threadIdx.x == 0) hook();
-  xk_pipe_range_it<TILE, K0 + 1, K1, KH, RPL>(b, rel, live, part, nsteps, ubuf, sc, hook_on, hook);
-  if (nsteps >= K1) xk_pipe_apply<TILE, K1 - 1, RPL>(b, rel, live, part, ubuf, sc);
+  xk_pipe_range_it<LPC, K0 + 1, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook);
+  if (nsteps >= K1) xk_pipe_apply2<LPC, K1 - 1, RPL>(b, b2, rel, live, live2, part, ubuf, sc);
 }
 
 // ---- role T: one fat tile in registers for the whole factorisation
-template <int RPL>
+template <class G>
 __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NT = XK_PIPE_NT, NPH = XK_PIPE_NPH, G = 16 / NPH, ARRD = XK_PIPE_ARRD;
-  static_assert(ARRD < G, "a phase is counted in before the next one is published");
+  constexpr int NT = G::NT, LPC = G::LPC, RPL = G::RPL, NPH = XK_PIPE_NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
+  static_assert(ARRD < GS, "a phase is counted in before the next one is published");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
   const int j = xcc * NT + slot;                           // my fat tile: valid rows [j TR, (j + 1) TR)
-  const int cabs = tid >> 2, part_ = tid & 3;              // ABSOLUTE column of this thread, all panels
+  const int cabs = tid / LPC, part_ = tid % LPC;           // ABSOLUTE column of this thread, all panels
   const bool mine = cabs < a.C1;
   const int npanels = (a.C1 + 15) / 16;
   const bool stamp = a.dbg && xcc == 0 && slot == 1 && tid == 0;
@@ -262,26 +286,27 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     const int rel = xk_launder(cabs) - c0;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
     const bool full = nsteps == 16;                        // (a short panel -- the last one -- hands everything over at its end)
-    const bool hot = (rel >> 4) == 0;
+    const int wrel = (tid >> 6) * (64 / LPC) - c0;         // first column of my wave, relative to the panel
+    const bool hot = wrel <= 0 && wrel > -(64 / LPC);       // my wave holds panel columns (wave-uniform)
     const bool pub = mine && part == 0 && rel >= 0;
     const unsigned epoch = (unsigned)(k + 1);
     if (stamp) { a.dbg[16 * k + 0] = wall_clock64(); a.dbg[16 * k + 8] = clock64(); }
     if (hot) __builtin_amdgcn_s_setprio(3);
-    // phase q: steps [q G, (q + 1) G), then rows [q G, (q + 1) G) of the pivot strip are final and go out; they are counted in
+    // phase q: steps [q GS, (q + 1) GS), then rows [q GS, (q + 1) GS) of the pivot strip are final and go out; they are counted in
     // ARRD steps into the next phase (their stores drain behind those steps), the last phase after the panel
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_TQ_CNT + (q - 1) * 8 + xcc) * 16); };
-      xk_pipe_range<true, q * G, (q + 1) * G, (q > 0 ? q * G + ARRD : -1), RPL>(b, rel, mine, part, nsteps, ubuf, sc, full, hook);
+      xk_pipe_range<LPC, q * GS, (q + 1) * GS, (q > 0 ? q * GS + ARRD : -1), RPL>(b, nullptr, rel, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (pub) {
         if (rel < 16) {
           double *pb = xk_opaque(myPB + xk_blk(rel, 0));
 #pragma unroll
-          for (int r = q * G; r < (q + 1) * G; ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
+          for (int r = q * GS; r < (q + 1) * GS; ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
         } else {
           double *ps = xk_opaque(myS + xk_blk(cabs, 0));
 #pragma unroll
-          for (int r = q * G; r < (q + 1) * G; ++r) ps[r * 4] = b[r];
+          for (int r = q * GS; r < (q + 1) * GS; ++r) ps[r * 4] = b[r];
         }
       }
       if (stamp && q < 4) a.dbg[16 * k + 1 + q] = wall_clock64();
@@ -304,7 +329,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     if (stamp) a.dbg[16 * k + 5] = wall_clock64();
     if (k + 1 == npanels) break;
     // my strip comes back from the first level (trailing columns of the NEXT panels only: everything up to c0 + 15 is finished)
-    if (!xk_pipe_wait(sync + (XP_MB_CNT + xcc) * 16, (unsigned)XK_PIPE_NM * epoch, ab, 2u, s_ok)) return false;
+    if (!xk_pipe_wait(sync + (XP_MB_CNT + xcc) * 16, (unsigned)G::NM * epoch, ab, 2u, s_ok)) return false;
     if (stamp) a.dbg[16 * k + 6] = wall_clock64();
     if (mine && rel >= 16 && part == 0) {
       const double *ps = xk_opaque(myS + xk_blk(cabs, 0));
@@ -322,11 +347,12 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
   return true;
 }
 
-// ---- role M: the first merge level of this XCD's 23 strips (+ the pending strip), 16 panel + <= 32 trailing columns per workgroup
+// ---- role M: the first merge level of this XCD's NT strips (+ the pending strip), 16 panel + <= 32 trailing columns per workgroup
 // 16 lanes per column: lane p = row p of every strip, register 0 = the pending strip = the pivot strip, register 1 + t = tile t
+// (register RM - 1 stays zero when NT is even)
+template <class G>
 __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NT = XK_PIPE_NT, NM = XK_PIPE_NM, RM = NT + 1, NP = 16, NPH = XK_PIPE_NPH, G = 16 / NPH;
-  static_assert(RM % 2 == 0, "register count of the merge layout must be even");
+  constexpr int NT = G::NT, NM = G::NM, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -350,8 +376,8 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     double b[RM];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
-    const int trail_prev = a.C1 - c0, lchalf_prev = max(4, 4 * ((trail_prev + 31) / 32));
-    const int lsplit_prev = max(1, (trail_prev + lchalf_prev - 1) / lchalf_prev);   // last-level workgroups of panel k - 1
+    const int trail_prev = a.C1 - c0, lchalf_prev = max(4, 4 * ((trail_prev + 32 * NCL - 1) / (32 * NCL)));
+    const int lsplit_prev = min(8, max(1, (trail_prev + lchalf_prev - 1) / lchalf_prev));   // last-level workgroups of panel k - 1
     if (k >= 1 && xcc != 0) {
       if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
       if (mine) b[0] = xk_ld_sc1(a.X2 + ((size_t)(k - 1) * 8 + xcc) * SS + xk_blk(col, part));
@@ -372,10 +398,10 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         const int av = xk_pipe_wait_phases(sync + (XP_TQ_CNT + xcc) * 16, 8 * 16, q, NPH, (unsigned)NT * epoch, ab, 6u, s_ok);
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
-        if (active && mine && part >= loaded * G && part < av * G) {
+        if (active && mine && part >= loaded * GS && part < av * GS) {
           double *g = xk_opaque(g0);
 #pragma unroll
-          for (int s = 1; s < RM; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
+          for (int s = 1; s <= NT; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
         }
         loaded = av;
       }
@@ -383,10 +409,10 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       if (panel) __builtin_amdgcn_s_setprio(3);
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
-      xk_pipe_range<false, q * G, (q + 1) * G, (q > 0 ? q * G : -1), RM>(b, cidx, mine, part, nsteps, ubuf, sc, full, hook);
+      xk_pipe_range<0, q * GS, (q + 1) * GS, (q > 0 ? q * GS : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
-      // rows [q G, (q + 1) G) of the root are final: out they go (write-through: the last level sits on other XCDs)
-      if (q < NPH - 1 && x1_mine && part >= q * G && part < (q + 1) * G) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      // rows [q GS, (q + 1) GS) of the root are final: out they go (write-through: the last level sits on other XCDs)
+      if (q < NPH - 1 && x1_mine && part >= q * GS && part < (q + 1) * GS) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
       if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
     };
     phase(std::integral_constant<int, 0>{});
@@ -402,9 +428,9 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         // the tiles' strips first (the tiles wait for them), then the last rows of the root
         double *g = xk_opaque(g0);
 #pragma unroll
-        for (int s = 1; s < RM; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
+        for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
       }
-      if (x1_mine && part >= (NPH - 1) * G) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if (x1_mine && part >= (NPH - 1) * GS) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -423,8 +449,10 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 // level -> first level -> last level -- but with the first level on CUs of its own it is shorter than the tiles' loop:
 // the last rows of the roots leave the first level together with the tiles' strips, a few steps later the pending strips
 // are out, and the next first level does not start before its tiles have published the first rows of their strips.)
+// Wide systems (NCL = 2): a trailing thread holds TWO columns, 8 lchalf apart -- the second set only takes reflectors.
+template <class G>
 __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NP = 16, RL = 8, NPH = XK_PIPE_NPH, G = 16 / NPH;
+  constexpr int NP = 16, RL = 8, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NM = G::NM;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -435,45 +463,50 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
   const size_t SS = (size_t)16 * a.C1P;                   // doubles per strip
   for (int k = 0; k < npanels; ++k) {
     const int c0 = 16 * k, trail = max(0, a.C1 - c0 - 16);
-    const int lchalf = max(4, 4 * ((trail + 31) / 32));   // trailing columns per workgroup: all 8 share the range
-    const int lsplit = max(1, (trail + lchalf - 1) / lchalf);
+    const int lchalf = max(4, 4 * ((trail + 32 * NCL - 1) / (32 * NCL)));   // trailing columns per chunk: 8 NCL chunks cover the range
+    const int lsplit = max(1, (trail + lchalf - 1) / lchalf);               // chunks in use; workgroup x takes chunks x and x + 8
     if (lidx >= lsplit) continue;
     const int cidx = xk_launder(cidx_), part = xk_launder(part_);
     const int col = panel ? c0 + cidx : c0 + 16 + lidx * lchalf + (cidx - 16);
+    const int col2 = col + 8 * lchalf;
     const bool mine = col < a.C1 && (panel || cidx - 16 < lchalf);
+    const bool mine2 = NCL > 1 && !panel && cidx - 16 < lchalf && col2 < a.C1;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
     const double *src = panel ? a.X1P + (size_t)k * 8 * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * 8 * SS + xk_blk(col, part);
+    const double *src2 = a.X1 + (size_t)k * 8 * SS + xk_blk(min(col2, a.C1P - 1), part);
     const size_t sstep = panel ? 256 : SS;
-    double b[RL];
+    double b[RL], b2[RL];
 #pragma unroll
-    for (int s = 0; s < RL; ++s) b[s] = 0.0;
+    for (int s = 0; s < RL; ++s) { b[s] = 0.0; b2[s] = 0.0; }
     bool ok = true;
     int loaded = 0;
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      if (!ok || nsteps <= q * G) return;                  // (a short last panel: the roots' rows past its columns are zero)
+      if (!ok || nsteps <= q * GS) return;                 // (a short last panel: the roots' rows past its columns are zero)
       if (loaded <= q) {
-        const int av = xk_pipe_wait_phases(sync + (XP_X1_CNT + k) * 16, XK_CAQR_MAXP * 16, q, NPH, 8u * XK_PIPE_NM, ab, 5u, s_ok);
+        const int av = xk_pipe_wait_phases(sync + (XP_X1_CNT + k) * 16, XK_CAQR_MAXP * 16, q, NPH, 8u * NM, ab, 5u, s_ok);
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
-        if (mine && part >= loaded * G && part < av * G) {
+        if (part >= loaded * GS && part < av * GS) {
+          if (mine) {
 #pragma unroll
-          for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
+            for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
+          }
+          if (mine2) {
+#pragma unroll
+            for (int s = 0; s < RL; ++s) b2[s] = xk_ld_sc1(src2 + s * SS);
+          }
         }
         loaded = av;
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
-      xk_pipe_range<false, q * G, (q + 1) * G, -1, RL>(b, panel ? cidx : 16, mine, part, nsteps, ubuf, sc, false, []() {});
+      xk_pipe_range<0, q * GS, (q + 1) * GS, -1, RL>(b, NCL > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
       if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q + 1] = wall_clock64();
     };
     phase(std::integral_constant<int, 0>{});
     if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
     if constexpr (NPH >= 4) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
-    if constexpr (NPH >= 8) {
-      phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
-      phase(std::integral_constant<int, 6>{}); phase(std::integral_constant<int, 7>{});
-    }
     if (!ok) return false;
     if (mine) {
       if (panel) {
@@ -487,6 +520,14 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         if (c0 + part < a.C1) a.Rout[(size_t)(c0 + part) * a.C1P + col] = b[0];
       }
     }
+    if (mine2) {
+      if (k + 1 < npanels) {
+        double *dst = a.X2 + (size_t)k * 8 * SS + xk_blk(col2, part);
+#pragma unroll
+        for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b2[s]);
+      }
+      if (c0 + part < a.C1) a.Rout[(size_t)(c0 + part) * a.C1P + col2] = b2[0];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && k + 1 < npanels) xk_pipe_arrive(sync + (XP_P_CNT + k) * 16);
@@ -496,9 +537,10 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
   return true;
 }
 
+template <class G>
 __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a) {
-  constexpr int RPL = XK_PIPE_RPL, NT = XK_PIPE_NT, NM = XK_PIPE_NM, RM = NT + 1;
-  constexpr int LDS_T = 2 * 4 * (RPL + 2), LDS_M = 2 * 16 * (RM + 2), LDS_L = 2 * 16 * 10;
+  constexpr int RPL = G::RPL, NT = G::NT, NM = G::NM, RM = G::RM, LPC = G::LPC;
+  constexpr int LDS_T = 2 * LPC * (RPL + 2), LDS_M = 2 * 16 * (RM + 2), LDS_L = 2 * 16 * 10;
   constexpr int LDS_MAX = LDS_T > LDS_M ? (LDS_T > LDS_L ? LDS_T : LDS_L) : (LDS_M > LDS_L ? LDS_M : LDS_L);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
@@ -522,12 +564,12 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __syncthreads();
   if (a.test_stall && xcc == 3 && slot == 5) return;
   bool ok;
-  if (slot < NT) ok = xk_pipe_tile<RPL>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok);
-  else if (slot < NT + NM) ok = xk_pipe_first(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok);
+  if (slot < NT) ok = xk_pipe_tile<G>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok);
+  else if (slot < NT + NM) ok = xk_pipe_first<G>(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok);
   else {
     // nothing to do until the first roots arrive: leave the other set of sync words zeroed for the next launch
     for (int i = (int)xcc * XK_PIPE_THREADS + threadIdx.x; i < XP_WORDS * 16; i += 8 * XK_PIPE_THREADS) a.sync_next[i] = 0u;
-    ok = xk_pipe_last(ap, (int)xcc, ubuf, sc, &s_ok);
+    ok = xk_pipe_last<G>(ap, (int)xcc, ubuf, sc, &s_ok);
   }
   if (!ok && threadIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
 }
