@@ -63,3 +63,63 @@ def test_bench_multi_rank_path_on_one_gpu(config, ranks):
     d = json.loads(line)
     assert d["n_gpus"] == ranks and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["ci_rounds_rank0"] >= 2 and d["config"]["ci_fused_rank0"] > 0
+
+
+def test_cpp_request_response_tick_in_loop_back(xk, tmp_path):
+    """host/examples/fleet_main.cpp -- keyframe insert -> VLAD request -> keyframe reply from HBM -> xk_ci_round_device ->
+    update, i.e. VIO::processOtherRequests / processOtherMeasurements (vio.cpp:462-570) in C++ over xk.h + xk_fleet.h -- in its
+    loop-back mode (one process plays both agents, every message goes through xk_fleet_send_recv to itself), against the same
+    tick done with the Python bindings: same keyframe chosen, same tracks fused, same posterior."""
+    import torch
+    from x_multi_agent_amd import fleet, place
+    N, K, n_shared, w, thr = 12, 40, 3, 0.05, 0.6
+    sa = synth.make_scenario(N, K, 0, seed=7101)
+    sb = synth.make_scenario(N, K, 0, seed=7102, agent_offset=0.03, landmarks=sa["landmarks_true"])
+    voc = place.load_vocabulary("visual")
+    scene = synth.make_descriptors(96, 32, seed=0x5EED)
+    kf = [synth.observe_descriptors(scene, 4, seed=11 + a) for a in (0, 1)]
+    qd = [synth.observe_descriptors(scene, 4, seed=23 + a) for a in (0, 1)]
+    parts = [np.array([N, K, n_shared, sa["sigma_img"], w, thr]),
+             np.array([int(voc["k"]), int(voc["L"]), voc["desc"].shape[0], voc["children"].shape[1], voc["desc"].shape[1], len(voc["node_of_word"])], float),
+             voc["desc"].astype(float).ravel(), voc["children"].astype(float).ravel(), voc["word_of_node"].astype(float),
+             voc["node_of_word"].astype(float)]
+    for a, s in enumerate((sa, sb)):
+        parts += [s["C_q_G"].ravel(), s["G_p_C"].ravel(), np.asfortranarray(s["P"]).ravel(order="F"), np.diff(s["trk_off"]).astype(float),
+                  s["obs_xy"].ravel(), np.array([len(kf[a])], float), kf[a].astype(float).ravel(), np.array([len(qd[a])], float),
+                  qd[a].astype(float).ravel()]
+    fin, fout = str(tmp_path / "case.bin"), str(tmp_path / "out.bin")
+    np.concatenate(parts).astype("<f8").tofile(fin)
+    pkg = os.path.join(ROOT, "x_multi_agent_amd")
+    env = dict(os.environ, LD_LIBRARY_PATH=pkg + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([os.path.join(pkg, "xk_fleet_example"), fin, fout], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ok loop-back" in r.stdout, r.stdout + r.stderr      # (RCCL prints its banner first)
+    out = np.fromfile(fout, dtype="<f8")
+    n = 15 + 6 * N
+    found, tag, n_fused = out[:3]
+    corr, P = out[3:3 + n], out[3 + n:].reshape(n, n, order="F")
+
+    # the same tick through the Python bindings
+    ea, eb = xk.Engine(N, 0, K), xk.Engine(N, 0, K)
+    ea.stage(sa); eb.stage(sb)
+    pay_n, trk_n = ea.payload_doubles(), n_shared * (1 + 2 * N)
+    dyn = np.zeros(16); dyn[9] = 1.0
+    pb = torch.zeros(pay_n, dtype=torch.float64, device="cuda:0")
+    tb = torch.from_numpy(fleet.pack_tracks(sb, n_shared, N).ravel()).cuda()
+    torch.cuda.synchronize()
+    eb.pack_payload_into(1, 200.0, dyn, pb.data_ptr())
+    db = place.Database(eb, voc, thr, payload_doubles=pay_n, tracks_doubles=trk_n, max_desc=1024)
+    db.add_keyframe(kf[1], pb.data_ptr(), tb.data_ptr(), tag=200)
+    da = place.Database(ea, voc, thr, max_desc=1024)
+    idx, score, etag = db.find_candidate(0, da.compute_vlad(qd[0]))
+    assert idx >= 0 and etag == 200 and score > thr
+    assert found == 1.0 and tag == 200.0
+    allp = torch.stack([torch.zeros_like(pb), pb])
+    allt = torch.stack([torch.from_numpy(fleet.pack_tracks(sa, n_shared, N).ravel()).cuda(), tb])
+    fused, _ = fleet.ci_round_device(ea, sa, 0, 2, allp, allt, n_shared, w)
+    assert fused == int(n_fused) and fused >= 1
+    rr = ea.visual_update_staged(sa["sigma_img"])
+    Pe = ea.download_P()
+    relP = np.linalg.norm(P - Pe) / np.linalg.norm(Pe)
+    assert relP <= 1e-12, relP
+    assert np.linalg.norm(corr - rr["correction"]) <= 1e-10 * np.linalg.norm(rr["correction"])
+    db.close(); da.close(); ea.close(); eb.close()

@@ -54,8 +54,12 @@ def build_host(force=False, verbose=True):
             continue
         name = f[:-len("_main.cpp")]
         out = os.path.join(HERE, "xk_%s_example" % short.get(name, name))
-        cmds.append(["g++", "-std=c++17", "-O2", "-Wall"] + inc + [os.path.join(root, "host", "examples", f), "-o", out,
-                                                                   "-L" + HERE, "-lx_host"] + link[1:])
+        extra_inc, extra_lib = [], []
+        if name == "fleet":   # the one example that talks to the HIP runtime and RCCL itself (device buffers, xk_fleet.h)
+            extra_inc = ["-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-Wno-unused-result"]
+            extra_lib = ["-lxk_fleet", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"]
+        cmds.append(["g++", "-std=c++17", "-O2", "-Wall"] + inc + extra_inc + [os.path.join(root, "host", "examples", f), "-o", out,
+                                                                               "-L" + HERE, "-lx_host"] + extra_lib + link[1:])
     for c in cmds:
         if verbose:
             print(" ".join(c), flush=True)
