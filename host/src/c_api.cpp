@@ -1,10 +1,12 @@
 // Plain-C entry points into the host-only pieces of the mirror (no device work), so that the CPU test suite can check
 // them against the oracle through ctypes: the IMU closed forms of x::Propagator, the SimpleState <-> payload bridge and
 // SlamUpdate::computeInverseDepthsNew.
+#include <stdexcept>
 #include <vector>
 
 #include "xk.h"
 #include "x/ekf/propagator.h"
+#include "x/ekf/updater.h"
 #include "x/ekf/simple_state.h"
 #include "x/vio/slam_update.h"
 
@@ -88,6 +90,54 @@ int x_host_propagate_covariance_with_qd(const double *s0, const double *s1, cons
     if (xk) xk_destroy(xk);
     return 1;
   }
+}
+// Updater::update with a subclass that hands applyUpdate a DENSE h (its own rows, not VioUpdater's device-resident
+// construction), covariance owned by the State (resident = 0) or resident on the device (1).  Needs a GPU (device 0).
+namespace {
+class DenseUpdater : public Updater {
+ public:
+  DenseUpdater(int N, int M, const double *H, int m, const double *res, const double *rdiag) : H_(H), m_(m), res_(res), rdiag_(rdiag) {
+    if (xk_create(0, N, M, 4, &xk_) != XK_OK) throw std::runtime_error("xk_create");
+  }
+  ~DenseUpdater() override { xk_destroy(xk_); }
+  double getTime() const override { return 0.0; }
+ protected:
+  void preProcess(const State &) override {}
+  bool preUpdate(State &) override { return true; }
+  bool preUpdateShortMsckf() override { return false; }
+  bool preUpdateCI() override { return false; }
+  void constructSlamCIUpdate(const State &, MatrixList &, MatrixList &, MatrixList &, MatrixList &) override {}
+  void constructUpdate(const State &state, Matrix &h, Matrix &res, Matrix &r) override {
+    const int n = state.nErrorStates();
+    h = Matrix(m_, n); res = Matrix(m_, 1); r = Matrix::Zero(m_, m_);
+    for (int k = 0; k < m_ * n; ++k) h.data()[k] = H_[k];
+    for (int i = 0; i < m_; ++i) { res(i) = res_[i]; r(i, i) = rdiag_[i]; }
+  }
+  void constructShortMsckfUpdate(const State &, Matrix &, Matrix &, Matrix &) override {}
+  void postUpdate(State &, const Matrix &) override {}
+ private:
+  const double *H_; int m_; const double *res_, *rdiag_;
+};
+}  // namespace
+int x_host_dense_update(const double *P_in, int N, int M, const double *H, int m, const double *res, const double *rdiag, int resident,
+                        double *P_out, double *core16_out) {
+  try {
+    const int n = 15 + 6 * N + 3 * M;
+    DenseUpdater u(N, M, H, m, res, rdiag);
+    u.setResident(resident != 0);
+    State s(N, M);
+    if (resident) {
+      if (xk_upload_P(u.engine(), P_in, n, n) != XK_OK) return 2;
+    } else {
+      s.cov_.resize(n, n);
+      for (int k = 0; k < n * n; ++k) s.cov_.data()[k] = P_in[k];
+    }
+    u.update(s);
+    if (resident) { if (xk_download_P(u.engine(), P_out, n, n) != XK_OK) return 3; }
+    else for (int k = 0; k < n * n; ++k) P_out[k] = s.cov_.data()[k];
+    s.getDynamicStates(core16_out);
+    return 0;
+  } catch (...) { return 1; }
 }
 // SimpleState::fromPayload -> accessors -> toPayload; lists_out = [attitudes 4N | positions 3N] as the CI code reads them
 int x_host_simple_state_roundtrip(const double *payload_in, int N, int M, double *payload_out, double *lists_out) {

@@ -90,12 +90,22 @@ void Updater::applyUpdate(State &state, const Matrix &H, const Matrix &res, cons
     compressed_on_device_ = false;
     for (int i = 0; i < n; ++i) correction_total(i) += correction(i);                     // :140
   } else {
-    if (resident_) throw std::runtime_error("Updater::applyUpdate: dense h with a resident covariance is not supported");
+    // A dense h (a subclass that builds its own rows instead of going through buildAndCompress).  With a resident covariance
+    // there is no host copy to update: it is fetched, updated by the dense route and sent back -- two n x n transfers, the
+    // price of leaving the device-resident construction, not an error.
+    Matrix fetched;
+    Matrix *Pd = &P;
+    if (resident_) {
+      fetched = Matrix(n, n);
+      check(xk_, xk_download_P(xk_, fetched.data(), n, n), "xk_download_P");
+      Pd = &fetched;
+    }
     std::vector<double> rdiag(H.rows());
     for (int i = 0; i < H.rows(); ++i) rdiag[i] = R(i, i);
-    check(xk_, xk_apply_update_dense(xk_, P.data(), n, n, H.data(), H.rows(), H.rows(), res.data(), rdiag.data(),
+    check(xk_, xk_apply_update_dense(xk_, Pd->data(), n, n, H.data(), H.rows(), H.rows(), res.data(), rdiag.data(),
                                      correction_total.data(), cov_update ? 1 : 0, correction.data()),
           "xk_apply_update_dense");  // adds correction to correction_total (:140)
+    if (resident_ && cov_update) check(xk_, xk_upload_P(xk_, Pd->data(), n, n), "xk_upload_P");
   }
   state.correct(correction);                                                                // :137
 }

@@ -57,3 +57,24 @@ def test_ring_wraps_onto_the_resident_covariance(xk, n_steps, bsz):
     env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     r = subprocess.run([exe, str(n_steps), str(bsz)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("resident", [0, 1])
+def test_dense_apply_update_with_a_resident_covariance(xk, resident):
+    """Updater::applyUpdate (updater.cpp:117-141) handed a DENSE h by a subclass that bypasses the device-resident construction:
+    it used to throw when the covariance is resident; now the covariance is fetched, updated and
+    sent back.  Against oracle/ref_np.apply_update."""
+    host = C.CDLL(os.path.join(PKG, "libx_host.so"))
+    N, M, m = 5, 2, 7
+    n = 15 + 6 * N + 3 * M
+    rng = np.random.default_rng(31)
+    A = rng.standard_normal((n, n))
+    P = np.asfortranarray(A @ A.T * 1e-3 + 1e-2 * np.eye(n))
+    H = np.asfortranarray(rng.standard_normal((m, n)))
+    res, rd = 1e-2 * rng.standard_normal(m), np.full(m, 4e-6)
+    Pout, core = np.zeros((n, n), order="F"), np.zeros(16)
+    rc = host.x_host_dense_update(_p(P), C.c_int(N), C.c_int(M), _p(H), C.c_int(m), _p(res), _p(rd), C.c_int(resident), _p(Pout), _p(core))
+    assert rc == 0
+    Pe, corr = ref_np.apply_update(P, H, res, rd)
+    assert rel(Pout, Pe) <= 1e-11
+    assert rel(core[0:3], corr[0:3]) <= 1e-9 and rel(core[3:6], corr[3:6]) <= 1e-9      # p, v took the correction
