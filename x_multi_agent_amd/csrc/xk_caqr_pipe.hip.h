@@ -34,20 +34,23 @@
 #define XK_PIPE_THREADS 768
 // Geometry of a launch.  LPC lanes per column x RPL rows per lane = rows of a fat tile (768 / LPC columns per workgroup);
 // per XCD: NT tile workgroups + NM first-level workgroups + 1 last-level workgroup = 32 = the CUs of an XCD; NCL = column
-// sets per last-level thread (its 8 workgroups cover NCL x 8 x <= 32 trailing columns).
-template <int LPC_, int RPL_, int NT_, int NM_, int NCL_>
+// sets per last-level thread (its 8 workgroups cover NCL x 8 x <= 32 trailing columns), NCM = column sets per first-level thread.
+template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1>
 struct XkPipeGeom {
-  static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_;
+  static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_, NCM = NCM_;
   static constexpr int RM = (NT_ + 2) & ~1;                // registers of a first-level lane: pending strip + NT strips, even
   static constexpr int COLS = XK_PIPE_THREADS / LPC_;      // widest system (C1P) a tile workgroup holds
   static constexpr int ROWS = 8 * NT_ * LPC_ * RPL_;       // most stacked rows
   static_assert(NT_ + NM_ + 1 == 32, "one workgroup per CU, 32 CUs per XCD");
   static_assert(RPL_ % 4 == 0 && RPL_ >= 16, "the pivot strip is the first 16 rows of the part-0 lane");
 };
-using XkPipeNarrow = XkPipeGeom<4, 32, 23, 8, 1>;          // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
+#ifndef XK_PIPE_NARROW
+#define XK_PIPE_NARROW 4, 32, 23, 8, 1
+#endif
+using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
 using XkPipeWide = XkPipeGeom<2, 40, 19, 12, 2>;           // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
 #define XK_PIPE_NT_MAX 23
-#define XK_PIPE_ROWS_MAX 23552
+#define XK_PIPE_ROWS_MAX 24320
 #ifndef XK_PIPE_NPH
 #define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
 #endif
@@ -206,11 +209,50 @@ __device__ __forceinline__ void xk_pipe_apply(double (&b)[RPL], int rel, bool li
   if constexpr (LPC > 0) xk_pipe_tapply<K, LPC, RPL>(b, rel, live, part, ubuf, sc);
   else xk_caqr_apply<K, 16, RPL>(b, rel, live, part, ubuf, sc);
 }
+// One reflector applied to TWO column sets of the same lanes (merge layout): the reflector is fetched from LDS once.  A merge
+// step is bound by what the LDS can deliver -- every wave pulls the whole reflector, 8 bytes per lane and row -- so a lane that
+// holds two columns halves that traffic per column.
+template <int KK, int RPL>
+__device__ __forceinline__ void xk_pipe_mapply_pair(double (&b)[RPL], double (&b2)[RPL], int rel, bool live, bool live2, int part, const double *ubuf,
+                                                    const double *sc) {
+  constexpr int RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * 16 + part) * RPLP);
+  const double mtt = sc[pb * 4];
+  if (rel > KK && (live || live2) && mtt != 0.0) {
+    xk_d2 u[RPL / 2];
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      if (r & 1) {
+        d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3);
+        e2 = fma(u[r][0], b2[2 * r], e2); e3 = fma(u[r][1], b2[2 * r + 1], e3);
+      } else {
+        d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1);
+        e0 = fma(u[r][0], b2[2 * r], e0); e1 = fma(u[r][1], b2[2 * r + 1], e1);
+      }
+    }
+    const double w = mtt * xk_group_sum<16>((d0 + d1) + (d2 + d3));
+    const double w2 = mtt * xk_group_sum<16>((e0 + e1) + (e2 + e3));
+#pragma unroll
+    for (int r = 0; r < RPL / 2; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+      b2[2 * r] = fma(w2, u[r][0], b2[2 * r]);
+      b2[2 * r + 1] = fma(w2, u[r][1], b2[2 * r + 1]);
+    }
+  }
+}
 template <int LPC, int K, int RPL>
 __device__ __forceinline__ void xk_pipe_apply2(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, const double *ubuf,
                                                const double *sc) {
+  if constexpr (LPC == 0) {
+    // (a lane with a second set is a trailing lane: rel = 16 for both sets; panel lanes pass b2 with live2 = false)
+    if (b2 && rel >= 16) { xk_pipe_mapply_pair<K, RPL>(b, *b2, rel, live, live2, part, ubuf, sc); return; }
+  }
   xk_pipe_apply<LPC, K, RPL>(b, rel, live, part, ubuf, sc);
-  if (b2) xk_pipe_apply<LPC, K, RPL>(*b2, 16, live2, part, ubuf, sc);
 }
 template <int LPC, int K, int K1, int KH, int RPL, typename Hook>
 __device__ __forceinline__ void xk_pipe_range_it(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, int nsteps,
@@ -352,7 +394,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
 // (register RM - 1 stays zero when NT is even)
 template <class G>
 __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NT = G::NT, NM = G::NM, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL;
+  constexpr int NT = G::NT, NM = G::NM, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NCM = G::NCM;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -365,15 +407,19 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
   for (int k = 0; k < npanels; ++k) {
     const int c0 = 16 * k, trail = max(0, a.C1 - c0 - 16);
     const int cidx = xk_launder(cidx_), part = xk_launder(part_);
-    const int mch = min(32, 4 * ((trail + 4 * NM - 1) / (4 * NM)));     // trailing columns per item (whole quarter-waves)
+    // trailing columns per item: NCM sets of mh columns (whole quarter-waves); a trailing lane holds column col of the first set
+    // and col + mh of the second
+    const int mh = min(32, 4 * ((trail + 4 * NM * NCM - 1) / (4 * NM * NCM))), mch = mh * NCM;
     const bool active = item == 0 || item * mch < trail;
     const int col = panel ? c0 + cidx : c0 + 16 + item * mch + (cidx - 16);
-    const bool mine = active && col < a.C1 && (panel || cidx - 16 < mch);
+    const int col2 = col + mh;
+    const bool mine = active && col < a.C1 && (panel || cidx - 16 < mh);
+    const bool mine2 = NCM > 1 && active && !panel && cidx - 16 < mh && col2 < a.C1;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
     const bool full = nsteps == 16;
     const unsigned epoch = (unsigned)(k + 1);
     const size_t slab = (size_t)k * 8 + xcc;
-    double b[RM];
+    double b[RM], b2[NCM > 1 ? RM : 2];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
     const int trail_prev = a.C1 - c0, lchalf_prev = max(4, 4 * ((trail_prev + 32 * NCL - 1) / (32 * NCL)));
@@ -384,6 +430,13 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     }
 #pragma unroll
     for (int s = 1; s < RM; ++s) b[s] = 0.0;
+    if constexpr (NCM > 1) {
+#pragma unroll
+      for (int s = 0; s < RM; ++s) b2[s] = 0.0;
+      if (k >= 1 && xcc != 0 && mine2) b2[0] = xk_ld_sc1(a.X2 + ((size_t)(k - 1) * 8 + xcc) * SS + xk_blk(col2, part));
+    }
+    double *g02 = a.S + (size_t)base * SS + xk_blk(min(col2, a.C1P - 1), part);
+    double *x12 = a.X1 + ((size_t)k * 8 + xcc) * SS + xk_blk(min(col2, a.C1P - 1), part);
     const size_t lane_off = panel ? xk_blk(cidx, part) : xk_blk(col, part);
     const size_t strip_step = panel ? 256 : SS;
     double *g0 = (panel ? a.PB + (size_t)base * 256 : a.S + (size_t)base * SS) + lane_off;
@@ -403,16 +456,29 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 #pragma unroll
           for (int s = 1; s <= NT; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
         }
+        if constexpr (NCM > 1) {
+          if (mine2 && part >= loaded * GS && part < av * GS) {
+            double *g = xk_opaque(g02);
+#pragma unroll
+            for (int s = 1; s <= NT; ++s) b2[s] = xk_ld_sc1(g + (size_t)(s - 1) * SS);
+          }
+        }
         loaded = av;
       }
       if (!active) return;
       if (panel) __builtin_amdgcn_s_setprio(3);
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
-      xk_pipe_range<0, q * GS, (q + 1) * GS, (q > 0 ? q * GS : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
+      if constexpr (NCM > 1)
+        xk_pipe_range<0, q * GS, (q + 1) * GS, (q > 0 ? q * GS : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full, hook);
+      else
+        xk_pipe_range<0, q * GS, (q + 1) * GS, (q > 0 ? q * GS : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
       // rows [q GS, (q + 1) GS) of the root are final: out they go (write-through: the last level sits on other XCDs)
       if (q < NPH - 1 && x1_mine && part >= q * GS && part < (q + 1) * GS) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if constexpr (NCM > 1) {
+        if (q < NPH - 1 && mine2 && part >= q * GS && part < (q + 1) * GS) xk_st_sc1(x12, b2[0]);
+      }
       if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
     };
     phase(std::integral_constant<int, 0>{});
@@ -431,6 +497,14 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
       }
       if (x1_mine && part >= (NPH - 1) * GS) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+    }
+    if constexpr (NCM > 1) {
+      if (mine2) {
+        double *g = xk_opaque(g02);
+#pragma unroll
+        for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * SS] = b2[s];
+        if (part >= (NPH - 1) * GS) xk_st_sc1(x12, b2[0]);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
