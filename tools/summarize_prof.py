@@ -30,6 +30,14 @@ def csrc_sha16():
     return hh.hexdigest()[:16]
 
 
+def kname(full):
+    """Kernel name without return type, template arguments and parameter list."""
+    n = full.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0].strip() if n.startswith("xk_") else n
+
+
 def find(d, pat):
     return glob.glob(os.path.join(OUT, f"prof_{tag}{suf}_{d}", "**", pat), recursive=True)
 
@@ -40,7 +48,7 @@ if stats:
     shutil.copy(stats[0], os.path.join(PROF, f"{tag}{suf}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats[0])))
     for r in rows:
-        avg_ns[r["Name"].split("(")[0]] = (float(r["AverageNs"]), int(r["Calls"]))
+        avg_ns[kname(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]))
     with open(os.path.join(PROF, f"{tag}{suf}_kernel_stats.md"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {cfg} --steps 20 --warmup 3 --no-cpu --no-frame-loop ({tag})\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
@@ -55,7 +63,7 @@ def counter_sums(d, names):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] not in names:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = kname(r["Kernel_Name"])
             e = out.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
             e[0] += float(r["Counter_Value"])
             e[1] += 1
