@@ -51,6 +51,44 @@ def test_random_shapes_against_the_oracle(xk, oracle_c):
     print(f"soak: {N_CASES} shapes, {took} on the single launch, worst rel dP {worst:.2e}")
 
 
+def test_random_shapes_with_slam_rows_against_the_oracle(xk, oracle_c):
+    """The same for stacks with SLAM rows and systems of up to 384 columns (both geometries of the single launch: narrow when
+    6 N + 3 M + 1 <= 192, wide above)."""
+    rng = np.random.default_rng(20260929)
+    worst, bad, took, wide, ran = 0.0, [], 0, 0, 0
+    while ran < 16:
+        N = int(rng.integers(6, 34))
+        M = int(rng.integers(1, 61))
+        if 6 * N + 3 * M + 1 > 384:
+            continue
+        K = int(rng.integers(10, 201))
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.choice([0.0, 0.05, 0.3])))
+        if rng.random() < 0.5:
+            kw["track_len"] = (2, N)
+        try:
+            sc = synth.make_scenario(N, K, M, **kw)
+        except Exception:
+            continue
+        ran += 1
+        ref = oracle_c.visual_update(sc)
+        eng = xk.Engine(N, M, K)
+        for rep in range(2):
+            eng.stage(sc)
+            got = eng.visual_update_staged(sc["sigma_img"])
+            rp = rel(eng.download_P(), ref["P"])
+            worst = max(worst, rp)
+            if not np.array_equal(got["inlier"], ref["inlier"]) or not np.array_equal(got["inlier_slam"], ref["inlier_slam"]) or not (rp <= 1e-8):
+                bad.append((N, K, M, kw, rep, rp))
+        st = eng.caqr_status()
+        took += int(st["schedule"] == 2)
+        wide += int(st["schedule"] == 2 and 6 * N + 3 * M + 1 > 192)
+        assert st["giveups"] == 0, (N, K, M, kw, st)
+        eng.close()
+    assert not bad, bad
+    assert took >= 8 and wide >= 3, (took, wide)
+    print(f"soak (SLAM rows): 16 shapes, {took} on the single launch ({wide} wide), worst rel dP {worst:.2e}")
+
+
 def test_hundred_headline_updates_on_one_handle(xk, oracle_c):
     sc = synth.make_config(4)
     ref = oracle_c.visual_update(sc)
