@@ -666,8 +666,11 @@ static int launch_build(xk_handle *h, double sigma_img) {
   if (h->n_poses < 2) return fail(h, XK_EINVAL, "window not staged");
   if (h->K > 0 && h->h_pin_i[0] > h->n_poses) return fail(h, XK_EINVAL, "track longer than the staged window");
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
+  XkFeatArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  size_t feat_lds = 0;
   if (h->K > 0) {
-    XkFeatArgs a;
+    XkFeatArgs &a = fa;
     a.q = h->d_q; a.p = h->d_p; a.n_poses = h->n_poses; a.n_poses_max = h->N;
     a.trk_off = h->d_trk_off; a.obs = h->d_obs; a.K = h->K;
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
@@ -675,8 +678,9 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
     a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
     a.inlier_h = h->h_flag_i; a.gamma_h = h->h_flag_d;     // gate results also straight into the pinned flag cache
-    const size_t lds = xk_feature_lds_bytes(h->n_poses);
-    hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), lds, h->stream, a);
+    feat_lds = xk_feature_lds_bytes(h->n_poses);
+    // (with SLAM features the tracks and the features share one launch, below)
+    if (h->M == 0 || h->feat_dbg) hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), feat_lds, h->stream, a);
   }
   if (h->K2 > 0) {   // tracks that become persistent features this frame: tiles K .. K + K2 - 1
     if (h->h_pin_i[1] > h->n_poses) return fail(h, XK_EINVAL, "MSCKF-SLAM track longer than the staged window");
@@ -705,7 +709,8 @@ static int launch_build(xk_handle *h, double sigma_img) {
     s.P = h->d_P; s.n = h->n; s.var_img = sigma_img * sigma_img; s.chi90 = h->d_chi90; s.chi_len = XK_CHI2_LEN;
     s.A = h->d_A + (size_t)(h->K + h->K2) * h->DB * h->C1P; s.DB = h->DB; s.C1P = h->C1P; s.na = h->na;
     s.inlier = h->d_inl_s; s.gamma = h->d_gam_s;
-    hipLaunchKernelGGL(xk_slam_rows, dim3(h->M), dim3(64), 0, h->stream, s);
+    if (h->K > 0 && !h->feat_dbg) hipLaunchKernelGGL(xk_build_rows, dim3(h->K + h->M), dim3(XK_FEAT_THREADS), feat_lds, h->stream, fa, s);
+    else hipLaunchKernelGGL(xk_slam_rows, dim3(h->M), dim3(64), 0, h->stream, s);
     // rows per SLAM tile (gated-out features leave zero rows, as in the reference)
     std::vector<int> tr(slam_tiles);
     for (int t = 0; t < slam_tiles; ++t) tr[t] = std::min(h->DB, 2 * h->M - t * h->DB);

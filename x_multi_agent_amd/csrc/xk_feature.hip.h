@@ -365,7 +365,7 @@ static inline size_t xk_feature_lds_bytes(int n_poses) {
   return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 2 + 256 + 272);
 }
 
-__global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
+__device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   XkFeatArgs a = a_in;
   if (a_in.batch) {
@@ -885,6 +885,10 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu
   XK_WG_END();
 }
 
+__global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
+  xk_msckf_feature_body(a_in);
+}
+
 // ----------------------------------------------------------------------------
 // SLAM rows (src/x/vio/slam_update.cpp:49-214): one 64-thread workgroup per
 // persistent feature; two rows at slot 2j of the SLAM tiles (zero if gated out).
@@ -908,12 +912,12 @@ struct XkSlamArgs {
   double *gamma;
 };
 
-__global__ __launch_bounds__(64) void xk_slam_rows(XkSlamArgs a) {
+__device__ __forceinline__ void xk_slam_rows_body(const XkSlamArgs &a, const int j) {
   __shared__ double hv[2][15];  // values of the up-to-15 nonzero columns
   __shared__ int hc[15];        // their ACTIVE column indices (-1 unused)
   __shared__ double rs[2];
   __shared__ int ok;
-  const int j = blockIdx.x, lane = threadIdx.x;
+  const int lane = threadIdx.x;
   if (lane == 0) {
     for (int c = 0; c < 15; ++c) { hc[c] = -1; hv[0][c] = hv[1][c] = 0.0; }
     const double al = a.feat[3 * j], be = a.feat[3 * j + 1], rho = a.feat[3 * j + 2];
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(64) void xk_slam_rows(XkSlamArgs a) {
   const int row = 2 * j;
   double *r0 = a.A + ((size_t)(row / a.DB) * a.DB + (row % a.DB)) * a.C1P;
   double *r1 = a.A + ((size_t)((row + 1) / a.DB) * a.DB + ((row + 1) % a.DB)) * a.C1P;
-  for (int c = lane; c < a.C1P; c += 64) {
+  for (int c = lane; c < a.C1P; c += (int)blockDim.x) {
     double v0 = 0.0, v1 = 0.0;
     if (ok) {
       if (c == a.na) { v0 = rs[0]; v1 = rs[1]; }
@@ -997,4 +1001,14 @@ __global__ __launch_bounds__(64) void xk_slam_rows(XkSlamArgs a) {
     r0[c] = v0;
     r1[c] = v1;
   }
+}
+
+__global__ __launch_bounds__(64) void xk_slam_rows(XkSlamArgs a) { xk_slam_rows_body(a, (int)blockIdx.x); }
+
+// MSCKF tracks and SLAM features of one update in ONE launch (blocks [0, K) = tracks, [K, K + M) = features): the two row
+// kinds are independent (vio_updater.cpp:279-346 builds them one after the other), and as two launches the 64-thread SLAM
+// kernel -- one serial lane per feature -- was 37 us behind the per-track kernel at BASELINE config 2.
+__global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_build_rows(XkFeatArgs fa, XkSlamArgs sa) {
+  if ((int)blockIdx.x < fa.K) xk_msckf_feature_body(fa);
+  else xk_slam_rows_body(sa, (int)blockIdx.x - fa.K);
 }
