@@ -11,8 +11,9 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 mode = sys.argv[2] if len(sys.argv) > 2 else "pipe"
 if mode == "multi": os.environ["XK_CAQR_RESIDENT"] = "0"
 sc = synth.make_config(cfg)
-N = sc["n_poses_max"]; K = len(sc["trk_off"]) - 1
-eng = engine.Engine(N, 0, K)
+N = int(sc["n_poses_max"]); K = len(sc["trk_off"]) - 1
+MS = int(len(sc['slam_anchor_idxs'])) if 'slam_anchor_idxs' in sc else 0
+eng = engine.Engine(N, MS, K)
 got = eng.visual_update(sc)
 t = eng.bench_staged(sc["sigma_img"], 3, 20)
 print(mode + ":", {k: round(v["ms"], 4) for k, v in t["stages"].items() if v["ms"] > 0}, "total", round(t["total_ms"], 4), "launches", t["n_levels"], "leaves", t["n_leaf"], flush=True)
@@ -22,7 +23,7 @@ if mode == "pipe":
     eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
     w = np.array(list(out), dtype=np.int64)
     T = w[:512].reshape(32, 16); M = w[512:1024].reshape(32, 16); L = w[1024:1536].reshape(32, 16)
-    npan = (6 * N + 1 + 15) // 16
+    npan = int((6 * N + 3 * MS + 1 + 15) // 16)
     t0 = T[0, 0]
     us = lambda x: x / 100.0
     print("tile workgroup (XCD 0, slot 1), us: phase 0 | 1 | 2 | 3 (steps + rows stored) | drain + arrive | wait for the strips | reload || panel total | cumulative")

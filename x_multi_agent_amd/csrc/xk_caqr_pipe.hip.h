@@ -422,7 +422,8 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     double b[RM], b2[NCM > 1 ? RM : 2];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
-    const int trail_prev = a.C1 - c0, lchalf_prev = max(4, 4 * ((trail_prev + 32 * NCL - 1) / (32 * NCL)));
+    const int trail_prev = a.C1 - c0, ncl_prev = (NCL > 1 && trail_prev > 256) ? NCL : 1;
+    const int lchalf_prev = max(4, 4 * ((trail_prev + 32 * ncl_prev - 1) / (32 * ncl_prev)));
     const int lsplit_prev = min(8, max(1, (trail_prev + lchalf_prev - 1) / lchalf_prev));   // last-level workgroups of panel k - 1
     if (k >= 1 && xcc != 0) {
       if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
@@ -537,14 +538,17 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
   const size_t SS = (size_t)16 * a.C1P;                   // doubles per strip
   for (int k = 0; k < npanels; ++k) {
     const int c0 = 16 * k, trail = max(0, a.C1 - c0 - 16);
-    const int lchalf = max(4, 4 * ((trail + 32 * NCL - 1) / (32 * NCL)));   // trailing columns per chunk: 8 NCL chunks cover the range
-    const int lsplit = max(1, (trail + lchalf - 1) / lchalf);               // chunks in use; workgroup x takes chunks x and x + 8
+    // trailing columns per chunk: 8 chunks of <= 32 columns when they cover the range (one column per lane), else 8 NCL chunks
+    // (workgroup x takes chunks x and x + 8: two columns per lane, slower steps -- only the first panels of a wide system)
+    const int ncl = (NCL > 1 && trail > 256) ? NCL : 1;
+    const int lchalf = max(4, 4 * ((trail + 32 * ncl - 1) / (32 * ncl)));
+    const int lsplit = max(1, (trail + lchalf - 1) / lchalf);               // chunks in use
     if (lidx >= lsplit) continue;
     const int cidx = xk_launder(cidx_), part = xk_launder(part_);
     const int col = panel ? c0 + cidx : c0 + 16 + lidx * lchalf + (cidx - 16);
     const int col2 = col + 8 * lchalf;
     const bool mine = col < a.C1 && (panel || cidx - 16 < lchalf);
-    const bool mine2 = NCL > 1 && !panel && cidx - 16 < lchalf && col2 < a.C1;
+    const bool mine2 = ncl > 1 && !panel && cidx - 16 < lchalf && col2 < a.C1;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
     const double *src = panel ? a.X1P + (size_t)k * 8 * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * 8 * SS + xk_blk(col, part);
     const double *src2 = a.X1 + (size_t)k * 8 * SS + xk_blk(min(col2, a.C1P - 1), part);
@@ -574,7 +578,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         loaded = av;
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
-      xk_pipe_range<0, q * GS, (q + 1) * GS, -1, RL>(b, NCL > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
+      xk_pipe_range<0, q * GS, (q + 1) * GS, -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
       if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q + 1] = wall_clock64();
     };
