@@ -57,6 +57,10 @@ using XkPipeWide = XkPipeGeom<2, 40, 19, 12, 2>;           // C1 <= 384 (SLAM fe
 #ifndef XK_PIPE_ARRD
 #define XK_PIPE_ARRD 1              // a phase's rows are counted in at the barrier ARRD steps after their stores were issued
 #endif
+#ifndef XK_PIPE_TRI
+#define XK_PIPE_TRI 0               // 1: merge steps skip the reflector in the rows where the strips' triangular structure makes it zero
+                                    // (measured: the divergent halves cost more than the LDS traffic they save, QR 0.319 -> 0.332 ms)
+#endif
 #ifndef XK_PIPE_CHUNK
 #define XK_PIPE_CHUNK 0             // 1: tile steps fetch the reflector in two halves (no spills; measured 2 % slower than the spills)
 #endif
@@ -190,7 +194,32 @@ __device__ __forceinline__ void xk_pipe_tapply(double (&b)[RPL], int rel, bool l
       }
     }
   } else {
+#if defined(XK_PIPE_PROBE_THALF)
+    // TIMING PROBE ONLY (wrong results): the tile step's apply with half the reflector and half the multiply-adds
+    constexpr int RPLP = RPL + 2;
+    constexpr int pb = KK & 1;
+    const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * LPC + part) * RPLP);
+    const double mtt = sc[pb * 4];
+    if (rel > KK && live && mtt != 0.0) {
+      xk_d2 u[RPL / 4];
+#pragma unroll
+      for (int r = 0; r < RPL / 4; ++r) u[r] = useg[r];
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL / 4; ++r) {
+        if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+        else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+      }
+      const double w = mtt * xk_group_sum<LPC>((d0 + d1) + (d2 + d3));
+#pragma unroll
+      for (int r = 0; r < RPL / 4; ++r) {
+        b[2 * r] = fma(w, u[r][0], b[2 * r]);
+        b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+      }
+    }
+#else
     xk_caqr_apply<KK, LPC, RPL>(b, rel, live, part, ubuf, sc);
+#endif
   }
 }
 
@@ -204,14 +233,84 @@ __device__ __forceinline__ void xk_pipe_form(double (&b)[RPL], int rel, int part
   if constexpr (LPC > 0) xk_caqr_form<K, LPC, RPL>(b, rel, part, ubuf, sc);
   else xk_caqr_mform<K, RPL>(b, rel, part, ubuf, sc);
 }
+// Merge layout, reflector KK applied to one column.  The strips of a merge are upper triangular in the panel columns, so column
+// KK -- the reflector -- is ZERO in rows > KK of every strip except the pivot strip's slot (register 0: the pending strip of the
+// first level is dense).  Lanes part > KK therefore fetch and use register 0's entry only: on average half the lanes skip the
+// reflector.  Correct, and slower (the two lane populations run one after the other): off by default.
+template <int KK, int RPL>
+__device__ __forceinline__ void xk_pipe_mapply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
+#if XK_PIPE_TRI
+  constexpr int RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * 16 + part) * RPLP);
+  const double mtt = sc[pb * 4];
+  if (rel > KK && live && mtt != 0.0) {
+    const bool full = part <= KK;
+    xk_d2 u[RPL / 2];
+    double dsum;
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) u[r] = useg[r];
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) {
+        if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+        else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+      }
+      dsum = (d0 + d1) + (d2 + d3);
+    } else {
+      u[0][0] = reinterpret_cast<const double *>(useg)[0];
+      dsum = u[0][0] * b[0];
+    }
+    const double w = mtt * xk_group_sum<16>(dsum);
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < RPL / 2; ++r) {
+        b[2 * r] = fma(w, u[r][0], b[2 * r]);
+        b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+      }
+    } else {
+      b[0] = fma(w, u[0][0], b[0]);
+    }
+  }
+#elif defined(XK_PIPE_PROBE_HALF)
+  // TIMING PROBES ONLY (wrong results): XK_PIPE_PROBE_HALF = 1 the same arithmetic with half the reflector fetched from LDS,
+  // = 2 half the reflector fetched AND half the multiply-adds -- which of the two a merge step is bound by
+  constexpr int RPLP = RPL + 2;
+  constexpr int pb = KK & 1;
+  constexpr int NR = (XK_PIPE_PROBE_HALF == 2) ? RPL / 4 : RPL / 2;
+  const xk_d2 *useg = reinterpret_cast<const xk_d2 *>(ubuf + (pb * 16 + part) * RPLP);
+  const double mtt = sc[pb * 4];
+  if (rel > KK && live && mtt != 0.0) {
+    xk_d2 u[RPL / 2];
+#pragma unroll
+    for (int r = 0; r < RPL / 4; ++r) u[r] = useg[r];
+#pragma unroll
+    for (int r = RPL / 4; r < RPL / 2; ++r) u[r] = u[r - RPL / 4];
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      if (r & 1) { d2 = fma(u[r][0], b[2 * r], d2); d3 = fma(u[r][1], b[2 * r + 1], d3); }
+      else { d0 = fma(u[r][0], b[2 * r], d0); d1 = fma(u[r][1], b[2 * r + 1], d1); }
+    }
+    const double w = mtt * xk_group_sum<16>((d0 + d1) + (d2 + d3));
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      b[2 * r] = fma(w, u[r][0], b[2 * r]);
+      b[2 * r + 1] = fma(w, u[r][1], b[2 * r + 1]);
+    }
+  }
+#else
+  xk_caqr_apply<KK, 16, RPL>(b, rel, live, part, ubuf, sc);
+#endif
+}
 template <int LPC, int K, int RPL>
 __device__ __forceinline__ void xk_pipe_apply(double (&b)[RPL], int rel, bool live, int part, const double *ubuf, const double *sc) {
   if constexpr (LPC > 0) xk_pipe_tapply<K, LPC, RPL>(b, rel, live, part, ubuf, sc);
-  else xk_caqr_apply<K, 16, RPL>(b, rel, live, part, ubuf, sc);
+  else xk_pipe_mapply<K, RPL>(b, rel, live, part, ubuf, sc);
 }
-// One reflector applied to TWO column sets of the same lanes (merge layout): the reflector is fetched from LDS once.  A merge
-// step is bound by what the LDS can deliver -- every wave pulls the whole reflector, 8 bytes per lane and row -- so a lane that
-// holds two columns halves that traffic per column.
+// One reflector applied to TWO column sets of the same lanes (merge layout): the reflector is fetched from LDS once.  Used by
+// the last level of wide systems (8 rows per lane); in the first level the second set does not fit the registers.
 template <int KK, int RPL>
 __device__ __forceinline__ void xk_pipe_mapply_pair(double (&b)[RPL], double (&b2)[RPL], int rel, bool live, bool live2, int part, const double *ubuf,
                                                     const double *sc) {
