@@ -2,6 +2,7 @@
 #include "x/vio/vio_updater.h"
 
 #include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 
@@ -21,10 +22,14 @@ static void stageTracks(xk_handle *xk, const TrackList &tr) {
   int *off = nullptr;
   double *o = nullptr;
   check(xk, xk_stage_tracks_begin(xk, (int)tr.size(), n_obs, &off, &o), "xk_stage_tracks_begin");
+  // a Track is a contiguous vector of Features and a Feature is its two normalised coordinates: one memcpy per track
+  static_assert(sizeof(Feature) == 2 * sizeof(double), "Feature = (x, y)");
   off[0] = 0;
   for (size_t k = 0; k < tr.size(); ++k) {
-    off[k + 1] = off[k] + (int)tr[k].size();
-    for (const Feature &f : tr[k]) { *o++ = f.getX(); *o++ = f.getY(); }
+    const size_t L = tr[k].size();
+    off[k + 1] = off[k] + (int)L;
+    if (L) memcpy(o, static_cast<const void *>(tr[k].data()), L * sizeof(Feature));
+    o += 2 * L;
   }
   check(xk, xk_stage_tracks_end(xk), "xk_stage_tracks_end");
 }
