@@ -48,10 +48,11 @@ CASES = {
     "slam_heavy": lambda: synth.make_scenario(20, 150, 40, seed=908),
     "slam_ragged": lambda: synth.make_scenario(30, 120, 25, seed=909, track_len=(2, 30)),
     "wide_no_slam_rows": lambda: synth.make_scenario(33, 150, 0, seed=910),          # 199 columns: wide because of the window alone
+    "widest": lambda: synth.make_scenario(33, 120, 61, seed=914),                     # 382 columns: two short of the wide geometry's 384
     # SLAM rows in a system that still fits 192 columns: the narrow geometry with all three row kinds in its row map
     "narrow_with_slam": lambda: synth.make_scenario(20, 200, 10, seed=912),
 }
-NLEAF = {"cfg2": 152, "slam_heavy": 152, "slam_ragged": 152, "wide_no_slam_rows": 152}
+NLEAF = {"cfg2": 152, "slam_heavy": 152, "slam_ragged": 152, "wide_no_slam_rows": 152, "widest": 152}
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
