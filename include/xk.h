@@ -346,8 +346,8 @@ int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_ti
  * them; nothing crosses PCIe.  This is the timed region of bench.py. */
 int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 
-/* Which schedule compressed the last update -- 0 the multi-launch CAQR, 1 the register-resident single launch (round 2), 2 the
- * pipelined single launch -- whether the single-launch path is armed for the next update, how many launches have given up on
+/* Which schedule compressed the last update -- 0 the multi-launch CAQR, 2 the pipelined single launch (1 was round 2's
+ * register-resident kernel, no longer built) -- whether the single-launch path is armed for the next update, how many launches have given up on
  * this handle so far (workgroups not co-resident: another process on the GPU, a CU mask) and the reason code of the last one
  * (2 XCD-local hand-off, 3 uneven XCD placement, 4 / 5 / 6 waiting for the last level / the roots / the tiles).  A launch that
  * gives up costs one bounded retry (<= 2 ms) and the update is redone by the multi-launch schedule with the same result; the
