@@ -57,6 +57,17 @@ using XkPipeWide = XkPipeGeom<2, 40, 19, 12, 2>;           // C1 <= 384 (SLAM fe
 #ifndef XK_PIPE_ARRD
 #define XK_PIPE_ARRD 1              // a phase's rows are counted in at the barrier ARRD steps after their stores were issued
 #endif
+#ifndef XK_PIPE_LOCALLD
+#define XK_PIPE_LOCALLD 0           // 1: XCD-local strip loads as workgroup-scope loads behind an L1 invalidate (buffer_inv sc1):
+                                    // correct, and 0.32 -> 0.59 ms -- the invalidate costs far more than the fabric round trips it saves
+#endif
+#if XK_PIPE_LOCALLD
+#define XK_LD_LOC(p) xk_ld_grp(p)
+#define XK_INV_LOC() xk_inv_l1()
+#else
+#define XK_LD_LOC(p) xk_ld_sc1(p)
+#define XK_INV_LOC()
+#endif
 #ifndef XK_PIPE_TRI
 #define XK_PIPE_TRI 0               // 1: merge steps skip the reflector in the rows where the strips' triangular structure makes it zero
                                     // (measured: the divergent halves cost more than the LDS traffic they save, QR 0.319 -> 0.332 ms)
@@ -472,10 +483,11 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     // my strip comes back from the first level (trailing columns of the NEXT panels only: everything up to c0 + 15 is finished)
     if (!xk_pipe_wait(sync + (XP_MB_CNT + xcc) * 16, (unsigned)G::NM * epoch, ab, 2u, s_ok)) return false;
     if (stamp) a.dbg[16 * k + 6] = wall_clock64();
+    XK_INV_LOC();
     if (mine && rel >= 16 && part == 0) {
       const double *ps = xk_opaque(myS + xk_blk(cabs, 0));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) b[r] = xk_ld_sc1(ps + r * 4);
+      for (int r = 0; r < 16; ++r) b[r] = XK_LD_LOC(ps + r * 4);
     }
     if (stamp) {
       double sink = 0;
@@ -551,10 +563,11 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         const int av = xk_pipe_wait_phases(sync + (XP_TQ_CNT + xcc) * 16, 8 * 16, q, NPH, (unsigned)NT * epoch, ab, 6u, s_ok);
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
+        XK_INV_LOC();
         if (active && mine && part >= loaded * GS && part < av * GS) {
           double *g = xk_opaque(g0);
 #pragma unroll
-          for (int s = 1; s <= NT; ++s) b[s] = xk_ld_sc1(g + (size_t)(s - 1) * strip_step);
+          for (int s = 1; s <= NT; ++s) b[s] = XK_LD_LOC(g + (size_t)(s - 1) * strip_step);
         }
         if constexpr (NCM > 1) {
           if (mine2 && part >= loaded * GS && part < av * GS) {

@@ -29,6 +29,12 @@
 __device__ __forceinline__ double xk_ld_sc1(const double *p) {
   return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), XK_RLX_AGENT));
 }
+// XCD-local variant (experiment, XK_PIPE_LOCALLD=1): a workgroup-scope load (sc0) behind an explicit L1 invalidate -- it may be
+// served by the XCD's L2 instead of going out to the fabric like a device-scope load of a line another CU has written
+__device__ __forceinline__ double xk_ld_grp(const double *p) {
+  return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void xk_inv_l1() { asm volatile("buffer_inv sc1" ::: "memory"); }
 __device__ __forceinline__ void xk_st_sc1(double *p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), XK_RLX_AGENT);
 }
