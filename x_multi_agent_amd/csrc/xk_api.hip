@@ -94,9 +94,7 @@ struct xk_handle {
   // pinned staging ring for inputs copied to the device WITHOUT a host synchronisation (window, tracks, sparse operands):
   // a slot is reused XK_STAGE_SLOTS calls later, by which time an update's final synchronisation has long passed
   char *h_stage[XK_STAGE_SLOTS];
-  hipEvent_t stage_ev[XK_STAGE_SLOTS];   // recorded behind the copy that reads the slot; waited for before the slot is reused
-  bool stage_ev_set[XK_STAGE_SLOTS];
-  int stage_open;          // slot handed out last: its copy is queued by the time the next slot is asked for (-1: none)
+  int stage_since_sync;    // slots handed out since the stream was last known to be idle (stage_slot)
   size_t stage_bytes;
   int stage_next;
   bool flags_direct;       // no SLAM rows in the last build: nothing was copied, the kernel wrote the cache
@@ -104,7 +102,6 @@ struct xk_handle {
   int *h_flag_i;
   double *h_flag_d;
   char *trk_slot;          // xk_stage_tracks_begin .. _end: the staging slot being filled
-  int trk_slot_idx;
   int trk_slot_K, trk_slot_nobs;
   bool async_pending;      // xk_build_compress_async ran: xk_apply_update owns the retry if the single-launch CAQR gave up
   // host pinned staging
@@ -307,8 +304,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
                              (sizeof(int) + sizeof(double)) * h->csr_cap + sizeof(int) * ((size_t)h->n + 1) + sizeof(double) * (XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max),
                              sizeof(double) * 8 * (size_t)std::max(n_feat_max, 1)}) + 256;
   for (auto &sp : h->h_stage) HIPCHK(h, hipHostMalloc((void **)&sp, h->stage_bytes));
-  for (auto &ev : h->stage_ev) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  h->stage_open = -1;
+
   HIPCHK(h, hipHostMalloc((void **)&h->h_flag_i, sizeof(int) * ((size_t)k_max + n_feat_max + 8)));
   HIPCHK(h, hipHostMalloc((void **)&h->h_flag_d, sizeof(double) * ((size_t)k_max + n_feat_max + 8)));
   memset(h->d_status, 0, sizeof(int) * 4);
@@ -352,8 +348,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
   for (auto &sp : h->h_stage)
     if (sp) hipHostFree(sp);
-  for (auto &ev : h->stage_ev)
-    if (ev) hipEventDestroy(ev);
+
   if (h->h_flag_i) hipHostFree(h->h_flag_i);
   if (h->h_flag_d) hipHostFree(h->h_flag_d);
   for (auto &e : h->ev)
@@ -372,21 +367,18 @@ extern "C" int xk_destroy(xk_handle *h) {
 // next slot of the pinned ring: host inputs are copied there and go to the device with an asynchronous copy, so that
 // staging never waits for the device (the caller's buffers are free on return, as before)
 // A slot is reused XK_STAGE_SLOTS staging calls later.  Nothing in between need have synchronised the stream (a loop of
-// xk_cov_congruence, repeated re-staging), so the copy that reads a slot is followed by an event, recorded when the NEXT
-// slot is asked for -- every caller queues its copy right after taking its slot -- and waited for before the slot goes out
-// again: free in the normal case, the copy finished long ago.
-static void stage_close(xk_handle *h) {
-  if (h->stage_open >= 0) {
-    if (hipEventRecord(h->stage_ev[h->stage_open], h->stream) == hipSuccess) h->stage_ev_set[h->stage_open] = true;
-    h->stage_open = -1;
-  }
-}
+// xk_cov_congruence, repeated re-staging), and the copy that reads a slot may still be queued.  The handle counts the slots
+// handed out since it last KNEW its stream to be idle (every update ends with a synchronisation: xk_apply_update,
+// read_status); when the ring is about to wrap without one, it synchronises itself.  In a filter loop that never happens --
+// a frame uses five or six slots -- so staging costs no event and no wait there.
+static void stage_stream_idle(xk_handle *h) { h->stage_since_sync = 0; }
 static char *stage_slot(xk_handle *h, size_t bytes) {
   if (bytes > h->stage_bytes) return nullptr;
-  stage_close(h);
+  if (++h->stage_since_sync >= XK_STAGE_SLOTS) {
+    hipStreamSynchronize(h->stream);
+    h->stage_since_sync = 1;
+  }
   const int s = h->stage_next;
-  if (h->stage_ev_set[s]) { hipEventSynchronize(h->stage_ev[s]); h->stage_ev_set[s] = false; }
-  h->stage_open = s;
   h->stage_next = (s + 1) % XK_STAGE_SLOTS;
   return h->h_stage[s];
 }
@@ -418,7 +410,6 @@ extern "C" int xk_stage_tracks_begin(xk_handle *h, int K, int n_obs, int **trk_o
   char *st = stage_slot(h, ob + sizeof(int) * (K + 1));
   if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
   h->trk_slot = st; h->trk_slot_K = K; h->trk_slot_nobs = n_obs;
-  h->trk_slot_idx = h->stage_open; h->stage_open = -1;     // (its copy is queued by _end, which records the slot's event itself)
   *obs_xy = (double *)st;
   *trk_off = (int *)(st + ob);
   return XK_OK;
@@ -443,7 +434,6 @@ extern "C" int xk_stage_tracks_end(xk_handle *h) {
     HIPCHK(h, hipSetDevice(h->device));
     h->d_trk_off = (int *)(h->d_obs + 2 * (size_t)trk_off[K]);         // offsets right behind the observations in use
     HIPCHK(h, hipMemcpyAsync(h->d_obs, st, ob + sizeof(int) * (K + 1), hipMemcpyHostToDevice, h->stream));
-    if (h->trk_slot_idx >= 0 && hipEventRecord(h->stage_ev[h->trk_slot_idx], h->stream) == hipSuccess) h->stage_ev_set[h->trk_slot_idx] = true;
     memcpy(h->h_trk_off, trk_off, sizeof(int) * (K + 1));
   }
   h->K = K;
@@ -1096,6 +1086,7 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
 }
 static int read_status(xk_handle *h, bool allow_retry = false) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  stage_stream_idle(h);
   return eval_status(h, h->d_status[0], h->d_status[1], allow_retry);
 }
 
@@ -1231,6 +1222,7 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     if (rc != XK_OK) return rc;
     // the kernels wrote the correction and (on failure) the status words into pinned host memory: one synchronisation, no copy
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    stage_stream_idle(h);
     rc = eval_status(h, h->d_status[0], h->d_status[1], async && attempt == 0);
     if (rc != XK_RETRY_CLASSIC) break;
   }
@@ -1363,6 +1355,7 @@ extern "C" int xk_apply_ci(xk_handle *h, double *P_out, int ldp, const double *c
 static int settle_async(xk_handle *h) {
   if (!h->async_pending) return XK_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  stage_stream_idle(h);
   int rc = eval_status(h, h->d_status[0], h->d_status[1], true);
   if (rc == XK_RETRY_CLASSIC) {
     if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
