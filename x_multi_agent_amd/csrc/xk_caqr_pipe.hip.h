@@ -5,24 +5,25 @@
 // then waited for its pivot strip -- tile step -> first level -> tile step is a dependency cycle, and with both halves on the
 // same CU it costs their SUM (10 + 10 us of reflector steps + 4 hand-offs = 30 us per 16-column panel).  Here:
 //
-//   * XCD x = 23 TILE workgroups (a fat tile of <= 128 rows each: 4 lanes per column x 32 rows per lane, the column <-> thread
-//     map absolute) + 8 FIRST-LEVEL workgroups (one group per XCD: 23 strips + the pending strip, 16 lanes per column,
-//     16 panel + trail/8 trailing columns each) + 1 LAST-LEVEL workgroup (the 8 of them share the trailing columns by ABSOLUTE
-//     column slices of C1P/8, so what they keep stays in their registers).
+//   * XCD x = NT TILE workgroups (a fat tile of LPC x RPL rows each, in registers for the whole factorisation, the column <->
+//     thread map absolute) + NM FIRST-LEVEL workgroups (one group per XCD: NT strips + the pending strip, 16 lanes per column,
+//     16 panel + <= 32 trailing columns each) + 1 LAST-LEVEL workgroup (8 roots; the eight of them share the trailing columns
+//     of the panel).  Two geometries: 23 + 8 + 1 with 4 x 32-row lanes (<= 192 columns), 19 + 12 + 1 with 2 x 40 (<= 384).
 //   * The strips of a merge are upper triangular in the panel columns: reflector j of the level above is zero in rows > j of
-//     every strip, so its steps 0..7 need rows 0..7 only.  A tile publishes rows 0..7 of its pivot strip after its step 7 and
-//     rows 8..15 after step 15; the first level runs its steps 0..7 BESIDE the tile's steps 8..15, publishes rows 0..7 of the
-//     root after them, and the last level follows in the same way.  The cycle tile -> first level -> tile is now
-//     16 tile steps + 8 first-level steps + the hand-offs.
-//   * The other cycle of the round-2 kernel (last level -> pending strip -> first level of the next panel -> last level) is
-//     gone: the last level keeps what it leaves of a panel's roots for ONE MORE panel (two generations: 8 dense strips of the
-//     previous panel + 8 triangular roots of this one), and only then sends them down as the pending strip of the first
-//     level two panels later -- by then they have been through both panels' eliminations.  Row 0 of every merge (register 0
-//     = the pending strip, zero when there is none) is the pivot strip, so no tile is special: every tile gets its own strip
-//     back, no leaders, no holes.
-// Hand-offs inside an XCD: plain stores + s_waitcnt vmcnt(0) + sc1 loads (the XCD's L2); across XCDs: write-through stores
-// into per-panel slabs that are never reused inside a launch.  All spins are bounded and look at an abort word; a launch
-// that gives up is redone by the multi-launch schedule (xk_api.hip).  DESIGN 3.2.2 has the anatomy and the numbers.
+//     every strip, so its steps need the rows of the level below only as far as that level has got.  A tile publishes its
+//     pivot strip in FOUR PHASES of 4 rows; the first level runs its steps 0..3 BESIDE the tile's steps 4..7 and so on, and
+//     hands the root to the last level phase by phase in the same way.  The cycle tile -> first level -> tile is now
+//     16 tile steps + the first level's last phase + two hand-offs, and the first level's own chain runs beside the tile's.
+//   * Register 0 of every merge -- the pending strip, zero when there is none -- is the pivot strip: the root is produced in a
+//     slot no tile owns, every tile gets its own strip back (no leaders, no holes).  What the last level leaves of the roots
+//     of XCDs 1..7 goes down as the pending strip of that XCD's first level in the NEXT panel: a strip released after panel
+//     k has seen the eliminations of panels <= k and must enter panel k + 1's tree (keeping it longer at the top does not
+//     move that deadline -- the first version tried).
+//   * Hand-off counters are fire-and-forget (no returning atomics on a producer's chain), consumers poll the counter itself
+//     and fetch every phase that is already complete; strips travel in blocks of 4 columns x 16 rows (xk_blk).
+// Hand-offs inside an XCD: plain stores + s_waitcnt vmcnt(0) + sc1 loads; across XCDs: write-through stores into per-panel
+// slabs that are never reused inside a launch (xk_xcd_sync.hip.h).  All spins are bounded and look at an abort word; a launch
+// that gives up is redone by the multi-launch schedule (xk_api.hip, DESIGN 3.2.3).  DESIGN 3.2.2 has the anatomy and the numbers.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -739,8 +740,9 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   const XkPipeArgsPtr ap = (XkPipeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned xcc = xk_xcc_id();
   const long long t_entry = a.dbg ? wall_clock64() : 0;
-  // placement census as in xk_caqr_resident: a workgroup takes the next slot of the XCD it finds itself on; a 33rd arrival
-  // on one XCD raises the abort word
+  // Placement census: a workgroup reads the XCD it runs on (HW_REG_XCC_ID) and takes the next slot there -- the dispatcher deals
+  // workgroups round-robin over the XCDs, but where it starts depends on what ran before, block b -> XCD b % 8 does NOT hold --
+  // and nobody waits for the census to complete; a 33rd arrival on one XCD raises the abort word
   if (threadIdx.x == 0) {
     const unsigned sl = __hip_atomic_fetch_add(sync + (XP_CENSUS + xcc) * 16, 1u, XK_RLX_AGENT);
     const bool bad = sl >= 32u || gridDim.x != 256u;
