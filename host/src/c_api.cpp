@@ -50,6 +50,32 @@ void x_host_propagate_state(const double *s0, double *s1, const double *g) {
   for (int i = 0; i < 3; ++i) { s1[1 + i] = b.p_(i); s1[4 + i] = b.v_(i); s1[11 + i] = b.b_w_(i); s1[14 + i] = b.b_a_(i); }
   s1[7] = b.q_.x(); s1[8] = b.q_.y(); s1[9] = b.q_.z(); s1[10] = b.q_.w();
 }
+// Propagator::transition (the two closed forms of one IMU step, no device work) with the discrete process noise injected through
+// setProcessNoiseFunction; returns how often the injected function was called.  use_hook = 0: the default model instead
+// (which announces itself on stderr once per process unless acknowledged).
+int x_host_transition(const double *s0, const double *s1, const double *qd225, int use_hook, double *fd_out, double *qd_out) {
+  auto load = [](const double *s, State &st) {
+    st.time_ = s[0];
+    for (int i = 0; i < 3; ++i) { st.p_(i) = s[1 + i]; st.v_(i) = s[4 + i]; st.b_w_(i) = s[11 + i]; st.b_a_(i) = s[14 + i]; st.w_m_(i) = s[17 + i]; st.a_m_(i) = s[20 + i]; }
+    st.q_ = Quaternion(s[10], s[7], s[8], s[9]);
+  };
+  State a(1, 0), b(1, 0);
+  load(s0, a);
+  load(s1, b);
+  Propagator p(Vector3(0, 0, -9.81), ImuNoise());
+  int calls = 0;
+  if (use_hook)
+    p.setProcessNoiseFunction([&](double, const Quaternion &, const Vector3 &, const Vector3 &, double, double, double, double) {
+      CoreCovMatrix q;
+      for (int k = 0; k < 225; ++k) q.m[k] = qd225[k];
+      ++calls;
+      return q;
+    });
+  CoreCovMatrix f_d, q_d;
+  p.transition(a, b, f_d, q_d);
+  for (int k = 0; k < 225; ++k) { fd_out[k] = f_d.m[k]; qd_out[k] = q_d.m[k]; }
+  return calls;
+}
 // One IMU step of the covariance through the mirror (Propagator::propagateCovariance: upload, xk_cov_propagate, download) with
 // the discrete process noise INJECTED through setProcessNoiseFunction -- what a drop-in does with the reference's own q_d.
 // s0 / s1 as above; qd225 column-major; P_in / P_out n x n column-major, n = 15 + 6 N + 3 M.  Needs a GPU (device 0).

@@ -156,6 +156,28 @@ def test_reference_qd_fixture_facts():
     assert asym > 1e-3 and worst_model > 0.1
 
 
+def test_reference_qd_goes_in_through_the_hook(host, capfd):
+    """A drop-in hands the reference's own discreteProcessNoiseCov to the mirror (Propagator::setProcessNoiseFunction): the
+    transition of an IMU step then carries exactly those numbers (here: the fixture generated from the reference's
+    statements), next to the restated f_d; without the hook the default model says on stderr that it is NOT the reference's."""
+    g = np.load(os.path.join(GOLDEN_DIR, "propagator_qd.npz"))
+    for i in (0, 7, 23):
+        dt = float(g["dt"][i])
+        s0 = np.zeros(23); s1 = np.zeros(23)
+        s0[0], s1[0] = 3.0, 3.0 + dt
+        s0[7:11] = s1[7:11] = g["q"][i]
+        s1[17:20], s1[20:23] = g["e_w"][i], g["e_a"][i]
+        Qd = np.asfortranarray(g["Q"][i])
+        fd, qd = np.zeros((15, 15), order="F"), np.zeros((15, 15), order="F")
+        calls = host.x_host_transition(_p(s0), _p(s1), _p(Qd.ravel(order="F")), C.c_int(1), fd.ctypes.data_as(c_dp), qd.ctypes.data_as(c_dp))
+        assert calls == 1 and np.array_equal(qd, g["Q"][i]) and rel(fd, g["F"][i]) <= 1e-14
+    # without the hook: the clean model, announced once
+    calls = host.x_host_transition(_p(s0), _p(s1), _p(Qd.ravel(order="F")), C.c_int(0), fd.ctypes.data_as(c_dp), qd.ctypes.data_as(c_dp))
+    n_w, n_bw, n_a, n_ba = 0.0013, 0.00013, 0.0083, 0.00083        # ImuNoise defaults of the mirror
+    assert calls == 0 and rel(qd, ref_np.process_noise_model(dt, g["e_w"][23], g["e_a"][23], g["q"][23], n_w, n_bw, n_a, n_ba)) <= 1e-12
+    assert not np.array_equal(qd, g["Q"][23])
+
+
 def test_simple_state_payload_bridge(host):
     from x_multi_agent_amd import fleet
     rng = np.random.default_rng(4)
