@@ -49,7 +49,10 @@ struct XkPipeGeom {
 #define XK_PIPE_NARROW 4, 32, 23, 8, 1
 #endif
 using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
-using XkPipeWide = XkPipeGeom<2, 40, 19, 12, 2>;           // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
+#ifndef XK_PIPE_WIDE
+#define XK_PIPE_WIDE 2, 40, 19, 12, 2
+#endif
+using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
 #define XK_PIPE_NT_MAX 23
 #define XK_PIPE_ROWS_MAX 24320
 #ifndef XK_PIPE_NPH
