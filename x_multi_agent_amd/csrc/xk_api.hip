@@ -668,9 +668,11 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
     a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
     a.inlier_h = h->h_flag_i; a.gamma_h = h->h_flag_d;     // gate results also straight into the pinned flag cache
-    feat_lds = xk_feature_lds_bytes(h->n_poses);
+    const bool packed = xk_feature_packed(h->n_poses);      // windows of more than 33 poses: gate matrix as a packed triangle
+    feat_lds = xk_feature_lds_bytes(h->n_poses, packed);
     // (with SLAM features the tracks and the features share one launch, below)
-    if (h->M == 0 || h->feat_dbg) hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), feat_lds, h->stream, a);
+    if (packed) hipLaunchKernelGGL(xk_msckf_feature_packed, dim3(h->K), dim3(XK_FEAT_THREADS), feat_lds, h->stream, a);
+    else if (h->M == 0 || h->feat_dbg) hipLaunchKernelGGL(xk_msckf_feature, dim3(h->K), dim3(XK_FEAT_THREADS), feat_lds, h->stream, a);
   }
   if (h->K2 > 0) {   // tracks that become persistent features this frame: tiles K .. K + K2 - 1
     if (h->h_pin_i[1] > h->n_poses) return fail(h, XK_EINVAL, "MSCKF-SLAM track longer than the staged window");
@@ -699,7 +701,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     s.P = h->d_P; s.n = h->n; s.var_img = sigma_img * sigma_img; s.chi90 = h->d_chi90; s.chi_len = XK_CHI2_LEN;
     s.A = h->d_A + (size_t)(h->K + h->K2) * h->DB * h->C1P; s.DB = h->DB; s.C1P = h->C1P; s.na = h->na;
     s.inlier = h->d_inl_s; s.gamma = h->d_gam_s;
-    if (h->K > 0 && !h->feat_dbg) hipLaunchKernelGGL(xk_build_rows, dim3(h->K + h->M), dim3(XK_FEAT_THREADS), feat_lds, h->stream, fa, s);
+    if (h->K > 0 && !h->feat_dbg && !xk_feature_packed(h->n_poses)) hipLaunchKernelGGL(xk_build_rows, dim3(h->K + h->M), dim3(XK_FEAT_THREADS), feat_lds, h->stream, fa, s);
     else hipLaunchKernelGGL(xk_slam_rows, dim3(h->M), dim3(64), 0, h->stream, s);
     // rows per SLAM tile (gated-out features leave zero rows, as in the reference)
     std::vector<int> tr(slam_tiles);

@@ -242,9 +242,17 @@ __device__ __forceinline__ void xk_gn_accum(const double (&dr)[3][3], const doub
 // only columns > k -- column k and the pivot stay valid through the step, so ONE barrier per step
 // suffices; gamma = sum_k S(d,k)^2 / S(k,k).  Threads form a fixed 16 x 16 grid; each owns an
 // the elements (i,j) = (ti, tj) mod 16 (no index divisions in the loop).
-template <int NT>
+// Gate matrix storage: full rows of ldm doubles (windows <= 33 poses: the row sweeps of the two-sided update want them) or the
+// PACKED lower triangle, element (i, j), i >= j, at i (i + 1) / 2 + j -- half the LDS, so that two workgroups still share a CU
+// at windows of 34..64 poses (81 KB -> 41 KB for the matrix at L = 50).
+template <bool PACKED>
+__device__ __forceinline__ size_t xk_gm(int i, int j, int ldm) {
+  if constexpr (PACKED) return (i >= j) ? (size_t)i * (i + 1) / 2 + j : (size_t)j * (j + 1) / 2 + i;
+  else return (size_t)i * ldm + j;
+}
+template <int NT, bool PACKED>
 __device__ __forceinline__ void xk_chol_gate(double *Mm, int ldm, int d, int tid, double *scal) {
-#define XK_S(i, j) Mm[(size_t)(3 + (i)) * ldm + 3 + (j)]
+#define XK_S(i, j) Mm[xk_gm<PACKED>(3 + (i), 3 + (j), ldm)]
   const int ti = tid >> 4, tj = tid & 15;
   double g = 0.0;
   bool bad = false;
@@ -277,8 +285,9 @@ __device__ __forceinline__ void xk_chol_gate(double *Mm, int ldm, int d, int tid
 // X_jk = L_jj^-1 S_jk on the matrix cores, and the trailing tiles take S_ik -= X_ji^T X_jk straight from
 // registers (a C/D-layout register is both operands of X^T X).  gamma = |L^-1 r|^2 = the squares of the
 // residual column of X.  work: 256 + 16*17 doubles of LDS (diagonal tile row-major, L_jj^-1).
+template <bool PACKED>
 __device__ __forceinline__ void xk_chol_gate_blocked(const double *Mm, int ldm, int d, int lane, double *scal, double *work) {
-#define XK_S(i, j) Mm[(size_t)(3 + (i)) * ldm + 3 + (j)]      // lower triangle valid; row d = the residual
+#define XK_S(i, j) Mm[xk_gm<PACKED>(3 + (i), 3 + (j), ldm)]      // lower triangle valid; row d = the residual
   constexpr int NB = 4;
   const int nb = (d + 15) >> 4, li = lane & 15, lk = lane >> 4;
   double *dbuf = work, *Ls = work + 256;
@@ -360,11 +369,14 @@ __device__ __forceinline__ void xk_chol_gate_blocked(const double *Mm, int ldm, 
 }
 
 // LDS size in bytes for n_poses window poses.
-static inline size_t xk_feature_lds_bytes(int n_poses) {
+static inline bool xk_feature_packed(int n_poses) { return n_poses > 33; }
+static inline size_t xk_feature_lds_bytes(int n_poses, bool packed = false) {
   const int L = n_poses, m2 = 2 * L, ldm = m2 + 1;
-  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + (size_t)(m2 + 1) * ldm + 32 + 6 * (size_t)m2 + 64 + 2 + 256 + 272);
+  const size_t gate = packed ? (size_t)(m2 + 1) * (m2 + 2) / 2 + 1 : (size_t)(m2 + 1) * ldm;
+  return sizeof(double) * (size_t)(9 * L + 3 * L + 6 * L + 6 * L + m2 + 3 * m2 + gate + 32 + 6 * (size_t)m2 + 64 + 2 + 256 + 272);
 }
 
+template <bool PACKED>
 __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   XkFeatArgs a = a_in;
@@ -384,7 +396,7 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
   double *res = Ja + 6 * Lmax;   // [2L]
   double *V = res + 2 * Lmax;    // [3][2L] Hf, then the three reflectors
   double *Mm = V + 6 * Lmax;     // [(2L+1)][ldm] gate matrix (+ appended residual row)
-  double *scal = Mm + (size_t)(2 * Lmax + 1) * ldm;  // 32 scalars (16..24: R factor of Hf)
+  double *scal = Mm + (PACKED ? (((size_t)(2 * Lmax + 1) * (2 * Lmax + 2) / 2 + 1) & ~(size_t)1) : (size_t)(2 * Lmax + 1) * ldm);  // 32 scalars (16..24: R factor of Hf)
   // scal: 0..2 tau, 3 g01, 4 g02, 5 g12, 6..8 gpf, 9 valid, 10 bad, 11 inlier, 12 gamma
 
   const int off = a_in.batch ? 0 : a.trk_off[k], L = a_in.batch ? a_in.batch[k].L : a.trk_off[k + 1] - off;
@@ -678,8 +690,8 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
                        t2[r][0] * jab[3 * s] + t2[r][1] * jab[3 * s + 1] + t2[r][2] * jab[3 * s + 2];
             if (ia == ib && r == s) v += a.var_img;
             if (ia == ib && r > s) continue;  // keep the diagonal block symmetric: use upper entry
-            Mm[(size_t)(2 * ia + r) * ldm + 2 * ib + s] = v;
-            Mm[(size_t)(2 * ib + s) * ldm + 2 * ia + r] = v;
+            Mm[xk_gm<PACKED>(2 * ia + r, 2 * ib + s, ldm)] = v;
+            if constexpr (!PACKED) Mm[(size_t)(2 * ib + s) * ldm + 2 * ia + r] = v;
           }
       }
     }
@@ -701,9 +713,8 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
     const int row = tid >> 2, qd = tid & 3;
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     if (row < m2) {
-      const double *mr = Mm + (size_t)row * ldm;
       for (int j = qd; j < m2; j += 4) {
-        const double mv = mr[j];
+        const double mv = Mm[xk_gm<PACKED>(row, j, ldm)];
         y0 = fma(mv, V[j], y0);
         y1 = fma(mv, V[m2 + j], y1);
         y2 = fma(mv, V[2 * m2 + j], y2);
@@ -715,10 +726,9 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
     if (row < m2 && qd == 0) { Yv[row] = y0; Yv[m2 + row] = y1; Yv[2 * m2 + row] = y2; }
     // rows 64.. (tracks longer than 32): second sweep
     for (int row2 = row + 64; row2 < m2; row2 += 64) {
-      const double *mr = Mm + (size_t)row2 * ldm;
       double z0 = 0.0, z1 = 0.0, z2 = 0.0;
       for (int j = qd; j < m2; j += 4) {
-        const double mv = mr[j];
+        const double mv = Mm[xk_gm<PACKED>(row2, j, ldm)];
         z0 = fma(mv, V[j], z0);
         z1 = fma(mv, V[m2 + j], z1);
         z2 = fma(mv, V[2 * m2 + j], z2);
@@ -767,7 +777,7 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
   for (int idx = tid; idx < m2 * m2; idx += XK_FEAT_THREADS) {
     const int i = idx / m2, j = idx - i * m2;
     if (j > i || i < 3) continue;
-    Mm[(size_t)i * ldm + j] -= V[i] * Zv[j] + Zv[i] * V[j] + V[m2 + i] * Zv[m2 + j] + Zv[m2 + i] * V[m2 + j] +
+    Mm[xk_gm<PACKED>(i, j, ldm)] -= V[i] * Zv[j] + Zv[i] * V[j] + V[m2 + i] * Zv[m2 + j] + Zv[m2 + i] * V[m2 + j] +
                                V[2 * m2 + i] * Zv[2 * m2 + j] + Zv[2 * m2 + i] * V[2 * m2 + j];
   }
   __syncthreads();
@@ -812,17 +822,17 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
   // columns > k, so column k and the pivot stay valid through the step and ONE barrier per step
   // suffices; gamma accumulates S(d,k)^2 / S(k,k).  Threads form a fixed 16 x 16 grid over the
   // matrix (no index arithmetic in the loop).
-  for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)m2 * ldm + 3 + j] = res[3 + j];
+  for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[xk_gm<PACKED>(m2, 3 + j, ldm)] = res[3 + j];
   __syncthreads();
   if (d < 64) {
     // (the work area is read two doubles at a time: 16-byte aligned)
     double *work = scal + 32 + 12 * Lmax + 64;
     work += ((size_t)work >> 3) & 1;
-    if (tid < 64) xk_chol_gate_blocked(Mm, ldm, d, tid, scal, work);
+    if (tid < 64) xk_chol_gate_blocked<PACKED>(Mm, ldm, d, tid, scal, work);
     else if (a.A) tile_write(tid - 64, XK_FEAT_THREADS - 64);   // the other three waves write the tile meanwhile: a
                                                                  // rejected track's tile is masked by tile_rows = 0
   } else {
-    xk_chol_gate<8>(Mm, ldm, d, tid, scal);
+    xk_chol_gate<8, PACKED>(Mm, ldm, d, tid, scal);
   }
   __syncthreads();
   if (tid == 0) {
@@ -886,7 +896,11 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
 }
 
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
-  xk_msckf_feature_body(a_in);
+  xk_msckf_feature_body<false>(a_in);
+}
+// windows of 34..64 poses: the gate matrix as a packed triangle (two workgroups per CU instead of one)
+__global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature_packed(XkFeatArgs a_in) {
+  xk_msckf_feature_body<true>(a_in);
 }
 
 // ----------------------------------------------------------------------------
@@ -1009,6 +1023,6 @@ __global__ __launch_bounds__(64) void xk_slam_rows(XkSlamArgs a) { xk_slam_rows_
 // kinds are independent (vio_updater.cpp:279-346 builds them one after the other), and as two launches the 64-thread SLAM
 // kernel -- one serial lane per feature -- was 37 us behind the per-track kernel at BASELINE config 2.
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_build_rows(XkFeatArgs fa, XkSlamArgs sa) {
-  if ((int)blockIdx.x < fa.K) xk_msckf_feature_body(fa);
+  if ((int)blockIdx.x < fa.K) xk_msckf_feature_body<false>(fa);
   else xk_slam_rows_body(sa, (int)blockIdx.x - fa.K);
 }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(XK_FEAT_THREADS) void xk_msckf_slam_init(XkSlamInit
   }
   for (int j = tid; j < d; j += XK_FEAT_THREADS) Mm[(size_t)(3 + d) * ldm + 3 + j] = tile[(size_t)j * a.C1P + a.na];
   __syncthreads();
-  xk_chol_gate<8>(Mm, ldm, d, tid, scal);
+  xk_chol_gate<8, false>(Mm, ldm, d, tid, scal);
   __syncthreads();
   if (tid == 0) {
     const double g = scal[12];
