@@ -828,6 +828,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       return XK_OK;
     }
   }
+  // 128-row slots whose tallest tile has <= 104 rows: 26 rows per lane (two workgroups per CU), see xk_caqr_tile
+  const int tall26_env = env_int("XK_CAQR_TALL26", 1);
   auto tile_geom = [&](int c0, int &tsplit, int &tchalf, int &tthreads) {
     const int trail = std::max(0, h->C1 - c0 - 16);
     tsplit = std::max(1, (trail + (tile_cols - 16) - 1) / (tile_cols - 16));
@@ -841,6 +843,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
     if (h->DB == 64) {
       if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, false>), tgrid, tblock, 0, h->stream, t);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<16, true>), tgrid, tblock, 0, h->stream, t);
+    } else if (t.rows_max <= 104 && tall26_env) {
+      if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<26, false>), tgrid, tblock, 0, h->stream, t);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<26, true>), tgrid, tblock, 0, h->stream, t);
     } else {
       if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, false>), tgrid, tblock, 0, h->stream, t);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, true>), tgrid, tblock, 0, h->stream, t);
@@ -895,6 +900,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
         if (h->DB == 64) {
           if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<16, false>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<16, true>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
+        } else if (t.rows_max <= 104 && tall26_env) {
+          if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<26, false>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<26, true>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
         } else {
           if (tsplit == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<32, false>), grid, block, 0, h->stream, t, l, lsplit, tsplit);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_fused<32, true>), grid, block, 0, h->stream, t, l, lsplit, tsplit);

@@ -781,9 +781,10 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
   int prow = part * RPL;
   // the loads do not wait for the row count: rows past it are masked after they arrive
   int rlim = a.rows_max - part * RPL;         // rows of the slot past the tallest staged tile are never touched
+  int rlo = 0;                                // holed tiles: physical rows 0..31 are the pivot strip + the hole
   if (holed) {
     if (part == 0) { prow = a.lead_off; rlim = 16; }
-    else if (RPL == 16 && part == 1) rlim = 0;
+    else if (part * RPL < 32) rlo = 32 - part * RPL;
   }
   double *rowp = a.A + ((size_t)t * a.TS + prow) * a.C1P + col;
   double b[RPL];
@@ -791,7 +792,7 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
   const long long t0 = clock64();
 #endif
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) b[r] = (mine && r < rlim) ? rowp[(size_t)r * a.C1P] : 0.0;
+  for (int r = 0; r < RPL; ++r) b[r] = (mine && r < rlim && r >= rlo) ? rowp[(size_t)r * a.C1P] : 0.0;
   if (a.c0 == 0) {
     const int nvalid = a.tile_rows[t] - part * RPL;
 #pragma unroll
@@ -819,12 +820,15 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
   } else {
 #pragma unroll
     for (int r = 0; r < RPL; ++r)
-      if (r < rlim) xk_store_wt(rowp + (size_t)r * a.C1P, b[r], a.wt);
+      if (r < rlim && r >= rlo) xk_store_wt(rowp + (size_t)r * a.C1P, b[r], a.wt);
   }
 }
 
+// RPL = 26: 128-row slots whose tallest tile has <= 104 rows (windows of 34..53 poses).  b[26] + the reflector fit 128 VGPRs,
+// so TWO 8-wave workgroups share a CU and one's tile traffic hides behind the other's steps (RPL = 32 needs 168: one per CU).
+#define XK_TILE_WAVES_PER_EU(RPL) ((RPL) == 16 ? 6 : (RPL) == 26 ? 4 : 3)
 template <int RPL, bool CSPLIT>
-__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_tile(XkCaqrArgs a) {
+__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(XK_TILE_WAVES_PER_EU(RPL)))) void xk_caqr_tile(XkCaqrArgs a) {
   constexpr int NP = 4, RPLP = RPL + 2;
   __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RPLP];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
@@ -1292,7 +1296,7 @@ __device__ __forceinline__ void xk_caqr_last32_body(const XkCaqrArgs &a, int spl
 // and use the other 16 of their first 32 rows as the pivot strip.  The rows the last level leaves behind join
 // the first level of panel k+1 as a 21st (41st) dense strip.  Per panel: 2 dependent launches instead of 3.
 template <int RPL, bool CSPLIT>
-__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(RPL == 16 ? 6 : 3))) void xk_caqr_fused(XkCaqrArgs ta, XkCaqrArgs la, int n_last, int tsplit) {
+__global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(XK_TILE_WAVES_PER_EU(RPL)))) void xk_caqr_fused(XkCaqrArgs ta, XkCaqrArgs la, int n_last, int tsplit) {
   constexpr int LDS_T = 2 * 4 * (RPL + 2), LDS_L = (RPL == 16) ? 2 * 32 * (10 + 2) : 2 * 16 * (20 + 2);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_T > LDS_L ? LDS_T : LDS_L];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
