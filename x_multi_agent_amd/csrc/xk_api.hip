@@ -884,7 +884,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       const int msplit = std::max(1, (trail + mchalf - 1) / mchalf);
       m.c0 = c0; m.stride = 1; m.final_level = 0; m.pin = h->d_panel[0]; m.pout = h->d_panel[1]; m.chalf = mchalf;
       m.lead_off = lead_off; m.lead_all = 0; m.pend = (k > 0) ? 1 : 0;
-      if (arity1 == 40) launch_merge<42>(h, m, groups1, msplit);
+      static const int m32_env = env_int("XK_CAQR_M32", 1);
+      if (arity1 == 40 && m32_env) hipLaunchKernelGGL(xk_caqr_merge32, dim3(groups1, msplit), dim3(32 * (16 + mchalf)), 0, h->stream, m);
+      else if (arity1 == 40) launch_merge<42>(h, m, groups1, msplit);
       else launch_merge<22>(h, m, groups1, msplit);
       ++launches;
       XkCaqrArgs l = a;                            // last level: the leaders' pivot strips -> 16 rows of R

@@ -1174,7 +1174,9 @@ __global__ __launch_bounds__(RPL > 22 ? 512 : 1024) void xk_caqr_merge(XkCaqrArg
 // 2i+1 of the wave trade places: x + swap(x) is the sum over the row pair in both rows).
 // doubles per lane of the reflector broadcast buffer: RH + 2, bumped when that makes the lane stride a multiple of 128 B
 // (RH = 14: all 32 lanes of a column would sit on the same banks)
-#define XK_M32_STRIDE(RH) ((((RH) + 2) % 16 == 0) ? (RH) + 4 : (RH) + 2)
+// (RH = 22, the first level below: 26 doubles = 13 x 16 B, an odd number of 16-byte bank groups, so that the 32 lanes of a
+//  column read their segments conflict-free)
+#define XK_M32_STRIDE(RH) ((RH) == 22 ? 26 : (((RH) + 2) % 16 == 0) ? (RH) + 4 : (RH) + 2)
 __device__ __forceinline__ double xk_rowpair_sum(double x) {
   const long long q = __builtin_bit_cast(long long, x);
   const unsigned lo = (unsigned)q, hi = (unsigned)(q >> 32);
@@ -1287,6 +1289,66 @@ __device__ __forceinline__ void xk_caqr_last32_body(const XkCaqrArgs &a, int spl
     for (int r = 0; r < RH; ++r)
       if (r < nstrips) xk_store_wt(g0 + (size_t)r * strip_step, b[r], a.wt);
   }
+}
+
+// First merge level of the overlapped schedule at arity 40 in the 32-lane layout: lane (h, p) = row p of slots 22h .. 22h+21,
+// slot s < 40 = strip s of the group, slot 40 = the pending strip (the leader's hole rows), slots 41..43 empty.  22 rows and
+// 22 reflector entries per lane (the 16-lane xk_caqr_merge<42> holds 42 + 42 and its per-step instruction stream is twice as
+// long: 43 us per launch at config 3 against 2x us here), 16 waves per workgroup instead of 8.
+__device__ __forceinline__ double *xk_tile_opaque(double *p) { asm volatile("" : "+v"(p)); return p; }
+__device__ __forceinline__ void xk_caqr_first32_body(const XkCaqrArgs &a, int group, int split, double *ubuf, double *sc) {
+  constexpr int NP = 32, RH = 22, ARITY = 40, PR = ARITY - RH;     // PR = register of the pending strip in half 1
+  const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
+  const int p = part & 15, half = part >> 4;
+  // (16 panel columns x 32 lanes = 8 whole waves: `panel` is wave-uniform, and so are the strides that depend on it)
+  const bool panel = __builtin_amdgcn_readfirstlane((int)(cidx < 16)) != 0;
+  const int col = panel ? a.c0 + cidx : a.c0 + 16 + split * a.chalf + (cidx - 16);
+  const bool mine = col < a.C1 && (panel || cidx - 16 < a.chalf);
+  const int base = group * ARITY * a.stride;
+  const size_t lane_off = panel ? (size_t)p * 16 + cidx : (size_t)p * a.C1P + col;
+  const size_t strip_step = panel ? 256 : (size_t)a.stride * a.TS * a.C1P;
+  const size_t lead = panel ? 0 : (size_t)a.lead_off * a.C1P;
+  double *g0 = panel ? const_cast<double *>(a.pin) + (size_t)group * ARITY * 256 + lane_off
+                     : a.A + (size_t)base * a.TS * a.C1P + lane_off + (a.lead_all ? lead : 0);
+  double *g00 = g0 + (a.lead_all ? 0 : lead);                                      // strip 0: the leader's pivot strip
+  double *gp = a.A + ((size_t)base * a.TS + (16 - a.lead_off) + p) * a.C1P + col;   // pending strip (hole rows)
+  double *gh = g0 + (size_t)(RH * half) * strip_step;                              // slot RH * half
+  const int nstrips = min(ARITY, (a.ntiles - base + a.stride - 1) / a.stride) - RH * half;   // strips of this half that exist
+  double b[RH];
+#pragma unroll
+  for (int r = 0; r < RH; ++r) {
+    double *q = gh + (size_t)r * strip_step;
+    bool ok = mine && r < nstrips;
+    if (r == 0 && !half) q = g00;
+    if (r >= PR && half) { q = gp; ok = mine && r == PR && a.pend; }
+    b[r] = ok ? q[0] : 0.0;
+  }
+  const int nsteps = (a.C1 - a.c0 < 16) ? a.C1 - a.c0 : 16;
+#define XK_STEP(K) if (K < nsteps) xk_caqr_mstep32<K, RH>(b, cidx, mine, part, ubuf, sc);
+  XK_STEP(0) XK_STEP(1) XK_STEP(2) XK_STEP(3) XK_STEP(4) XK_STEP(5) XK_STEP(6) XK_STEP(7)
+  XK_STEP(8) XK_STEP(9) XK_STEP(10) XK_STEP(11) XK_STEP(12) XK_STEP(13) XK_STEP(14) XK_STEP(15)
+#undef XK_STEP
+  if (!mine) return;
+  if (panel) {
+    // the merged panel block = register 0 of half 0 across its 16 lanes; split 0 publishes it
+    if (split == 0 && !half) a.pout[(size_t)group * 256 + p * 16 + cidx] = (p > cidx) ? 0.0 : b[0];
+  } else {
+    gh = xk_tile_opaque(gh);                                 // (or 22 pointers stay live across the 16 steps)
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      double *q = gh + (size_t)r * strip_step;
+      bool ok = r < nstrips;
+      if (r == 0 && !half) q = g00;
+      if (r >= PR && half) { q = gp; ok = r == PR && a.pend; }
+      if (ok) xk_store_wt(q, b[r], a.wt);
+    }
+  }
+}
+__global__ __launch_bounds__(1024) void xk_caqr_merge32(XkCaqrArgs a) {
+  constexpr int NP = 32, RHP = XK_M32_STRIDE(22);
+  __shared__ __attribute__((aligned(16))) double ubuf[2 * NP * RHP];
+  __shared__ __attribute__((aligned(16))) double sc[2 * 4];
+  xk_caqr_first32_body(a, blockIdx.x, blockIdx.y, ubuf, sc);
 }
 
 // Overlapped schedule (two merge levels).  The last merge level of panel k only touches the pivot strips of
