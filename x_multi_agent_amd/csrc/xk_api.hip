@@ -755,6 +755,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   // overlapped schedule (xk_caqr_fused): exactly two merge levels, the second one a single 20-way group
   const bool overlap = overlap_env && (arity1 == 20 || arity1 == 40) && groups1 >= 2 && groups1 <= 20;
   a.hole_stride = 0; a.lead_off = 0; a.lead_all = 0; a.pend = 0;
+  static const int skip_env = env_int("XK_CAQR_SKIP_REJECTED", 1);
+  a.lead_stride = skip_env ? arity1 : 0;
   int launches = 0;
   // register-resident single launch (xk_caqr_pipe.hip.h): MSCKF tracks only, valid rows <= 184 fat tiles of 128
   const int resident_env = env_int("XK_CAQR_RESIDENT", 1);   // (read per call: tests switch it inside one process)

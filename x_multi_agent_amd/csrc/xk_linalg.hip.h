@@ -655,6 +655,8 @@ struct XkCaqrArgs {
   int pend;               // merge (first level): the group leader's hole rows join as strip number ARITY
   long long *dbg;         // optional: clock stamps of workgroup 0 (probe builds only)
   int wt;                 // experiment: write-through (sc1) stores for the rows a launch hands to the next one
+  int lead_stride;        // tile kernel: tiles t % lead_stride == 0 receive merged rows (first-level group leaders); the other
+                          // tiles of rejected tracks stay all-zero and are skipped (0 = skip nothing)
 };
 
 __device__ __forceinline__ void xk_store_wt(double *p, double v, int wt) {
@@ -778,6 +780,24 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
   const int col = (!CSPLIT || panel) ? a.c0 + cidx : a.c0 + 16 + ysplit * a.chalf + (cidx - 16);
   const bool mine = col < a.C1 && (!CSPLIT || panel || cidx - 16 < a.chalf);
   const bool holed = a.hole_stride > 0 && (t % a.hole_stride) == 0;
+  if (a.lead_stride > 0 && (t % a.lead_stride) != 0 && a.tile_rows[t] == 0) {
+    // a rejected track that leads no merge group: its rows are zero for the whole factorisation.  The merges read its pivot
+    // strip (rows 0..15) and its panel block, so those are zeroed -- the strip once (the feature kernel leaves a rejected
+    // track's slot as the previous update left it), the block every panel -- and nothing else is touched.
+    if (mine && part == 0) {
+      if (panel) {
+        if (!CSPLIT || ysplit == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a.pout[((size_t)t * 16 + r) * 16 + cidx] = 0.0;
+        }
+      } else if (a.c0 == 0) {
+        double *z = a.A + (size_t)t * a.TS * a.C1P + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xk_store_wt(z + (size_t)r * a.C1P, 0.0, a.wt);
+      }
+    }
+    return;
+  }
   int prow = part * RPL;
   // the loads do not wait for the row count: rows past it are masked after they arrive
   int rlim = a.rows_max - part * RPL;         // rows of the slot past the tallest staged tile are never touched
