@@ -5,9 +5,10 @@ sys.path.insert(0, '.')
 os.environ["XK_LIB_PATH"] = "tools/exp/bin/libxk_featprobe.so"
 import numpy as np
 from x_multi_agent_amd import engine, synth
-sc = synth.make_config(4)
-K = 400
-eng = engine.Engine(30, 0, K)
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+sc = synth.make_config(cfg)
+N, K, M = synth.CONFIGS[cfg]
+eng = engine.Engine(N, M, K)
 eng.stage(sc)
 res = eng.msckf_build(sc["sigma_img"])
 n = 12 * K
@@ -22,7 +23,7 @@ ph[~inl, 6] = 0   # rejected tracks return before the tile write
 st, en, hw = w[:, 8], w[:, 9], w[:, 10]
 t0 = st.min()
 dur = (en - st) / 100.0
-slow = dur > 100
+slow = dur > 1.5 * np.median(dur)
 print(f"{'phase (us)':14s} {'median':>8s} {'max':>8s} {'slow WGs mean':>14s}")
 for i, nme in enumerate(names[:7]):
     print(f"{nme:14s} {np.median(ph[:, i]):8.2f} {ph[:, i].max():8.2f} {ph[slow, i].mean() if slow.any() else 0:14.2f}")
@@ -34,4 +35,4 @@ hwid = hw & 0xFFFFFFFF
 key = xcc * 100000 + ((hwid >> 8) & 0xFFF)
 uniq, cnt = np.unique(key, return_counts=True)
 print(f"{len(uniq)} distinct CUs; WGs per CU: {dict(zip(*[x.tolist() for x in np.unique(cnt, return_counts=True)]))}")
-print("slow WG ids:", np.nonzero(slow)[0].tolist(), "xcc:", xcc[slow].tolist())
+print("slow WG ids:", np.nonzero(slow)[0].tolist()[:32], "xcc:", xcc[slow].tolist()[:32])

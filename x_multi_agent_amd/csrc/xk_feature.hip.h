@@ -368,6 +368,112 @@ __device__ __forceinline__ void xk_chol_gate_blocked(const double *Mm, int ldm, 
 #undef XK_S
 }
 
+// The blocked gate for 64 <= d <= 125 (windows of 34..64 poses) on the FOUR waves of the workgroup: 16 x 16 tiles as above,
+// tile column k -- tiles (i, k), i <= k -- in the registers of wave k % 4; the residual rides along as tile column nb.
+// Per block step j: the owner of column j factors and inverts the diagonal tile (xk_chol16_bcast), barrier, every wave turns
+// its tiles of row j into X_jk = L_jj^-1 S_jk and leaves them in LDS (C/D layout, 2 KB each -- in the gate matrix's own
+// storage, which is dead once the tiles are in registers), barrier, every wave updates its columns, S_ik -= X_ji^T X_jk, with
+// X_ji read back in the layout that makes a C/D register the A operand of X^T X.  ~8 block steps of (16-pivot chain + two
+// barriers + <= 9 tile updates per wave) instead of d barrier-separated rank-1 steps: 119 -> 25 us at d = 97.
+// NC = tile columns per wave: 2 covers nb <= 7 (d <= 111, residual column included), 3 the rest
+template <bool PACKED, int NC>
+__device__ __forceinline__ void xk_chol_gate_blocked4(double *Mm, int ldm, int d, int tid, double *scal, double *work) {
+#define XK_S(i, j) Mm[xk_gm<PACKED>(3 + (i), 3 + (j), ldm)]      // lower triangle valid; row d = the residual
+  constexpr int NB = 8;
+  const int nb = (d + 15) >> 4, lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  double *dbuf = work, *Ls = work + 256;
+  xk_d4 T[NC][NB];                                             // T[c][i] = tile (i, k), k = w + 4 c
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int k = w + 4 * c;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (c == 0 && i >= 4) continue;                         // (column k <= 3 has no tile below row 3)
+      xk_d4 t = {0, 0, 0, 0};
+      if (i <= k && i < nb && k <= nb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * i + lk + 4 * q, cc = 16 * k + li;
+          double v;
+          if (k < nb) {
+            v = (r == cc) ? 1.0 : 0.0;                        // identity padding past d
+            if (r < d && cc < d) v = (r >= cc) ? XK_S(r, cc) : XK_S(cc, r);
+          } else {
+            v = (li == 0 && r < d) ? XK_S(d, r) : 0.0;        // residual in column 0 of its tiles
+          }
+          t[q] = v;
+        }
+      }
+      T[c][i] = t;
+    }
+  }
+  __syncthreads();                                            // every tile is in registers: Mm becomes the exchange area
+  double *Xs = Mm + (((size_t)Mm >> 3) & 1);                  // [NB][256], 16-byte aligned
+  bool bad = false;
+  double g = 0.0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j < nb) {                                             // uniform
+      const int wj = j & 3, cj = j >> 2;
+      if (w == wj) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dbuf[64 * q + lane] = T[cj][j][q];   // C/D layout == row-major 16 x 16
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (xk_chol16_bcast(dbuf, Ls, lane)) bad = true;
+      }
+      __syncthreads();
+      double lv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lv[q] = Ls[li * 17 + 4 * q + lk];
+      // row j of this wave's columns
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (c == 0 && j >= 4) continue;
+        const int k = w + 4 * c;
+        if (k > j && k <= nb) {
+          xk_d4 x = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[q], T[c][j][q], x, 0, 0, 0);
+          T[c][j] = x;
+          if (k < nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xs[256 * k + 64 * q + lane] = x[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g = fma(x[q], x[q], g);   // only column 0 (lanes li == 0) is non-zero
+          }
+        }
+      }
+      __syncthreads();
+      // trailing tiles of this wave's columns
+#pragma unroll
+      for (int i = j + 1; i < NB; ++i) {
+        if (i < nb && i <= w + 4 * (NC - 1)) {
+          double xa[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xa[q] = -Xs[256 * i + 64 * q + lane];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            if (c == 0 && (i >= 4 || j >= 4)) continue;
+            const int k = w + 4 * c;
+            if (i <= k && k <= nb) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) T[c][i] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q], T[c][j][q], T[c][i], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (bad && lane == 0) scal[10] = 1.0;
+  if (w == (nb & 3)) {                                        // the owner of the residual column
+    g = xk_wave_sum(g);
+    if (lane == 0) scal[12] = g;
+  }
+#undef XK_S
+}
+
 // LDS size in bytes for n_poses window poses.
 static inline bool xk_feature_packed(int n_poses) { return n_poses > 33; }
 static inline size_t xk_feature_lds_bytes(int n_poses, bool packed = false) {
@@ -831,6 +937,11 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
     if (tid < 64) xk_chol_gate_blocked<PACKED>(Mm, ldm, d, tid, scal, work);
     else if (a.A) tile_write(tid - 64, XK_FEAT_THREADS - 64);   // the other three waves write the tile meanwhile: a
                                                                  // rejected track's tile is masked by tile_rows = 0
+  } else if (PACKED) {
+    double *work = scal + 32 + 12 * Lmax + 64;
+    work += ((size_t)work >> 3) & 1;
+    if (d <= 111) xk_chol_gate_blocked4<PACKED, 2>(Mm, ldm, d, tid, scal, work);
+    else xk_chol_gate_blocked4<PACKED, 3>(Mm, ldm, d, tid, scal, work);   // (34 spilled VGPRs, in this branch only)
   } else {
     xk_chol_gate<8, PACKED>(Mm, ldm, d, tid, scal);
   }
