@@ -70,6 +70,15 @@ CASES_VS_ORACLE = {
     "slam_heavy_m40": lambda: synth.make_scenario(6, 2, 40, seed=1203),
     "tile64_last_n33": lambda: synth.make_scenario(33, 30, 0, seed=1204),
     "tile128_first_n34": lambda: synth.make_scenario(34, 30, 0, seed=1205),
+    # windows above 33 poses: packed gate matrix, the gate's Cholesky on four waves (two / three tile columns per wave either
+    # side of d = 111) next to the one-wave gate of the short tracks, 26 / 32 rows per lane either side of 104-row tiles,
+    # rejected tracks skipped by the tile step, the 40-way first merge level in the 32-lane layout with its pending strip
+    "gate4_n40_ragged": lambda: synth.make_scenario(40, 60, 0, seed=1301, track_len=(2, 40)),
+    "gate4_two_columns_n57": lambda: synth.make_scenario(57, 40, 0, seed=1302),
+    "gate4_three_columns_n58": lambda: synth.make_scenario(58, 40, 0, seed=1303),
+    "tile26_last_n53": lambda: synth.make_scenario(53, 45, 0, seed=1304, outlier_frac=0.3),
+    "tile32_first_n54": lambda: synth.make_scenario(54, 45, 0, seed=1305, outlier_frac=0.3),
+    "merge32_n50_420_tiles": lambda: synth.make_scenario(50, 420, 0, seed=1306, outlier_frac=0.25),
 }
 
 
