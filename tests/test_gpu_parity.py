@@ -79,6 +79,7 @@ CASES_VS_ORACLE = {
     "tile26_last_n53": lambda: synth.make_scenario(53, 45, 0, seed=1304, outlier_frac=0.3),
     "tile32_first_n54": lambda: synth.make_scenario(54, 45, 0, seed=1305, outlier_frac=0.3),
     "merge32_n50_420_tiles": lambda: synth.make_scenario(50, 420, 0, seed=1306, outlier_frac=0.25),
+    "wide_window_with_slam_n40": lambda: synth.make_scenario(40, 50, 10, seed=1307),
 }
 
 

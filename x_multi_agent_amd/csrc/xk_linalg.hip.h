@@ -636,6 +636,10 @@ __global__ void xk_copy2d(XkCopyArgs a) {
 // that index is static.  The broadcast vector u has u[<kk] = 0 and u[kk] = v_pivot for the part-0
 // lane, so the update code is identical for every lane.
 // ----------------------------------------------------------------------------
+__device__ __forceinline__ double *xk_tile_opaque(double *p) { asm volatile("" : "+v"(p)); return p; }
+#ifndef XK_TILE32_WPE
+#define XK_TILE32_WPE 3          // waves per SIMD of the 32-rows-per-lane tile kernels: 3 (one workgroup per CU), 4 = two, reflector in halves
+#endif
 struct XkCaqrArgs {
   double *A;              // tiles [ntiles][tile_rows_max][C1P] row-major (in place)
   const int *tile_rows;   // valid rows per tile before panel 0 (0 = rejected track)
@@ -739,6 +743,42 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
   }
   __syncthreads();
   const double mtt = scp[0];
+#if XK_TILE32_WPE == 4
+  if constexpr (RPL == 32) {
+    // 128-VGPR budget (two 8-wave workgroups per CU): the reflector is fetched in halves, once for the dot product and once
+    // more for the update -- twice the LDS reads, but b[32] + 16 reflector entries fit where b[32] + 32 do not
+    if (rel > KK && live && mtt != 0.0) {
+      double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        xk_d2 u[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r] = useg[8 * h + r];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int q = 8 * h + r;
+          if (r & 1) { d2 = fma(u[r][0], b[2 * q], d2); d3 = fma(u[r][1], b[2 * q + 1], d3); }
+          else { d0 = fma(u[r][0], b[2 * q], d0); d1 = fma(u[r][1], b[2 * q + 1], d1); }
+        }
+      }
+      const double w = mtt * xk_group_sum<NP>((d0 + d1) + (d2 + d3));
+      const xk_d2 *useg2 = reinterpret_cast<const xk_d2 *>(xk_tile_opaque(reinterpret_cast<double *>(useg)));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        xk_d2 u[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r] = useg2[8 * h + r];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int q = 8 * h + r;
+          b[2 * q] = fma(w, u[r][0], b[2 * q]);
+          b[2 * q + 1] = fma(w, u[r][1], b[2 * q + 1]);
+        }
+      }
+    }
+    return;
+  }
+#endif
   if (rel > KK && live && mtt != 0.0) {
     // (finished columns do not fetch the reflector: a column is one quarter-wave, so its lanes' LDS passes vanish)
     xk_d2 u[RPL / 2];
@@ -846,7 +886,7 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
 
 // RPL = 26: 128-row slots whose tallest tile has <= 104 rows (windows of 34..53 poses).  b[26] + the reflector fit 128 VGPRs,
 // so TWO 8-wave workgroups share a CU and one's tile traffic hides behind the other's steps (RPL = 32 needs 168: one per CU).
-#define XK_TILE_WAVES_PER_EU(RPL) ((RPL) == 16 ? 6 : (RPL) == 26 ? 4 : 3)
+#define XK_TILE_WAVES_PER_EU(RPL) ((RPL) == 16 ? 6 : (RPL) == 26 ? 4 : XK_TILE32_WPE)
 template <int RPL, bool CSPLIT>
 __global__ __launch_bounds__(RPL == 16 ? 768 : 512) __attribute__((amdgpu_waves_per_eu(XK_TILE_WAVES_PER_EU(RPL)))) void xk_caqr_tile(XkCaqrArgs a) {
   constexpr int NP = 4, RPLP = RPL + 2;
@@ -1315,7 +1355,6 @@ __device__ __forceinline__ void xk_caqr_last32_body(const XkCaqrArgs &a, int spl
 // slot s < 40 = strip s of the group, slot 40 = the pending strip (the leader's hole rows), slots 41..43 empty.  22 rows and
 // 22 reflector entries per lane (the 16-lane xk_caqr_merge<42> holds 42 + 42 and its per-step instruction stream is twice as
 // long: 43 us per launch at config 3 against 2x us here), 16 waves per workgroup instead of 8.
-__device__ __forceinline__ double *xk_tile_opaque(double *p) { asm volatile("" : "+v"(p)); return p; }
 __device__ __forceinline__ void xk_caqr_first32_body(const XkCaqrArgs &a, int group, int split, double *ubuf, double *sc) {
   constexpr int NP = 32, RH = 22, ARITY = 40, PR = ARITY - RH;     // PR = register of the pending strip in half 1
   const int cidx = (int)threadIdx.x / NP, part = threadIdx.x & (NP - 1);
