@@ -100,6 +100,9 @@ void StateManager::manage(State &state, std::vector<unsigned int> del_feat_idx, 
   for (int k = 0; k < 3; ++k) pos(3 * n_poses_ + k) = cpe(k);                     // :134
   augmentCovariance(state, n_poses_, n);                                          // :137
   ++n_poses_;
+  // the window lists as they stand now are what constructUpdate stages next: handed over first, they travel with the
+  // congruence operand instead of in a host-to-device copy of their own (xk_stage_window keeps identical lists for free)
+  if (resident && n_poses_ >= 2) check(xk_, xk_stage_window(xk_, att.data(), pos.data(), n_poses_), "xk_stage_window");
   flush();
   if (!resident) check(xk_, xk_download_P(xk_, state.getCovarianceRef().data(), n, n), "xk_download_P");   // :145
   state.setOrientationArray(att);

@@ -71,6 +71,11 @@ struct xk_handle {
   // update workspace
   int CM, LDA;
   double *d_Maug, *d_X, *d_corr, *d_ct, *d_tmpH, *d_tmpS, *d_tmpP, *d_rdiag, *d_tmpz;
+  double *h_win;        // host copy of the staged window lists (7 doubles per pose), see flush_window
+  bool win_pending;     // ... which have not reached d_q / d_p yet
+  bool win_valid;       // h_win holds the lists of the window in use
+  unsigned *d_done_cnt;  // workgroup counter of the completion marker
+  unsigned long long done_seq, done_seen, flags_after_seq;   // completion markers (XK_SPIN_DONE): launched / seen / launched when the gate flags were queued
   int *d_status;        // status words; they live in PINNED HOST memory (h_out + n): kernels write them only on failure
   double *h_out;        // pinned host, device-visible: [n] correction of xk_apply_update + the status words
   // CI / payload
@@ -199,6 +204,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   // window lists in one allocation, observations + track offsets in another: a staging call is ONE host-to-device copy
   // (small copies run as copy kernels of ~5 us each on the update's critical path)
   HIPCHK(h, dalloc(&h->d_q, 7 * (size_t)n_poses_max));
+  HIPCHK(h, hipMalloc((void **)&h->d_done_cnt, sizeof(unsigned)));
+  HIPCHK(h, hipMemset(h->d_done_cnt, 0, sizeof(unsigned)));
+  h->h_win = (double *)calloc(7 * (size_t)n_poses_max, sizeof(double));
+  if (!h->h_win) return fail(h, XK_EDEVICE, "host allocation");
   h->d_p = h->d_q + 4 * (size_t)n_poses_max;
   HIPCHK(h, dalloc(&h->d_obs, 2 * h->obs_cap + ((size_t)k_max + 2) / 2 + 1));
   h->d_trk_off = (int *)(h->d_obs + 2 * h->obs_cap);
@@ -295,13 +304,13 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     h->h_trk2_off = (int *)calloc(m + 1, sizeof(int));
     if (!h->h_trk2_off) return fail(h, XK_ENOMEM, "host track offsets");
   }
-  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max + ((size_t)h->n + 2 + h->csr_cap) / 2 + 1));
+  HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max + 7 * (size_t)n_poses_max + ((size_t)h->n + 2 + h->csr_cap) / 2 + 1));
   h->d_csr_i = nullptr;   // (the integer part follows the values of each operand)
   h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 512)));
   h->stage_bytes = std::max({sizeof(double) * 2 * h->obs_cap + sizeof(int) * ((size_t)k_max + 1), sizeof(double) * 7 * (size_t)n_poses_max,
-                             (sizeof(int) + sizeof(double)) * h->csr_cap + sizeof(int) * ((size_t)h->n + 1) + sizeof(double) * (XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max),
+                             (sizeof(int) + sizeof(double)) * h->csr_cap + sizeof(int) * ((size_t)h->n + 1) + sizeof(double) * (XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max + 7 * (size_t)n_poses_max),
                              sizeof(double) * 8 * (size_t)std::max(n_feat_max, 1)}) + 256;
   for (auto &sp : h->h_stage) HIPCHK(h, hipHostMalloc((void **)&sp, h->stage_bytes));
 
@@ -344,6 +353,8 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->h_ci_w) hipHostFree(h->h_ci_w);
   free(h->h_trk_off);
   if (h->h_out) hipHostFree(h->h_out);
+  free(h->h_win);
+  if (h->d_done_cnt) hipFree(h->d_done_cnt);
   if (h->h_pin) hipHostFree(h->h_pin);
   if (h->h_pin_i) hipHostFree(h->h_pin_i);
   for (auto &sp : h->h_stage)
@@ -383,17 +394,35 @@ static char *stage_slot(xk_handle *h, size_t bytes) {
   return h->h_stage[s];
 }
 
+// Staged window lists that no kernel has carried to the device yet: one host-to-device copy through the pinned ring.
+static int flush_window(xk_handle *h) {
+  if (!h->win_pending) return XK_OK;
+  const size_t bytes = sizeof(double) * 7 * (size_t)h->n_poses;
+  double *st = (double *)stage_slot(h, bytes);
+  if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+  memcpy(st, h->h_win, bytes);
+  HIPCHK(h, hipMemcpyAsync(h->d_q, st, bytes, hipMemcpyHostToDevice, h->stream));
+  h->win_pending = false;
+  return XK_OK;
+}
+
 extern "C" int xk_stage_window(xk_handle *h, const double *C_q_G, const double *G_p_C, int n_poses) {
   if (!h || !C_q_G || !G_p_C) return XK_EINVAL;
   if (n_poses < 2 || n_poses > h->N) return fail(h, XK_ECAPACITY, "n_poses outside [2, n_poses_max]");
   HIPCHK(h, hipSetDevice(h->device));
-  double *st = (double *)stage_slot(h, sizeof(double) * 7 * n_poses);
-  if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
-  memcpy(st, C_q_G, sizeof(double) * 4 * n_poses);
-  memcpy(st + 4 * n_poses, G_p_C, sizeof(double) * 3 * n_poses);
-  h->d_p = h->d_q + 4 * (size_t)n_poses;                               // positions right behind the attitudes in use
-  HIPCHK(h, hipMemcpyAsync(h->d_q, st, sizeof(double) * 7 * n_poses, hipMemcpyHostToDevice, h->stream));
-  h->n_poses = n_poses;
+  // Kept on the host until the next consumer.  In a filter frame that is the congruence launch of manage(), whose operand copy
+  // carries the lists along (congruence()): a copy of their own runs as a ~5 us copy kernel on the frame's critical path.
+  // Everything else gets them by flush_window.  Staging the same lists again (manage() and constructUpdate both do) is free.
+  const bool same = h->win_valid && n_poses == h->n_poses && memcmp(h->h_win, C_q_G, sizeof(double) * 4 * n_poses) == 0 &&
+                    memcmp(h->h_win + 4 * n_poses, G_p_C, sizeof(double) * 3 * n_poses) == 0;
+  if (!same) {
+    memcpy(h->h_win, C_q_G, sizeof(double) * 4 * n_poses);
+    memcpy(h->h_win + 4 * n_poses, G_p_C, sizeof(double) * 3 * n_poses);
+    h->d_p = h->d_q + 4 * (size_t)n_poses;                             // positions right behind the attitudes in use
+    h->win_pending = true;
+    h->win_valid = true;
+    h->n_poses = n_poses;
+  }
   h->have_rows = h->have_R = false;
   h->ms_built = false;
   return XK_OK;
@@ -659,6 +688,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
   XkFeatArgs fa;
   memset(&fa, 0, sizeof(fa));
   size_t feat_lds = 0;
+  { int rcw = flush_window(h); if (rcw != XK_OK) return rcw; }   // (normally carried by the frame's congruence launch already)
   if (h->K > 0) {
     XkFeatArgs &a = fa;
     a.q = h->d_q; a.p = h->d_p; a.n_poses = h->n_poses; a.n_poses_max = h->N;
@@ -718,6 +748,8 @@ static int launch_build(xk_handle *h, double sigma_img) {
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "build launch", e);
   return XK_OK;
 }
+
+__global__ void xk_mark_done(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 template <int RPL>
 static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
@@ -972,6 +1004,8 @@ struct UpdateSpec {
   const double *ct;   // device corr_total or null
   int cov_update;
   double *corr;       // where the correction goes: null -> h->d_corr (device); xk_apply_update passes pinned host memory
+  unsigned long long *done_flag;   // optional completion marker (pinned host memory) written by the last launch ...
+  unsigned long long done_seq;     // ... with this value
 };
 
 // Kalman algebra on the device (updater.cpp:117-141 / :144-161).  ev (optional)
@@ -1054,11 +1088,13 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     g.M = n; g.N = n + 1; g.K = c; g.alpha = -1.0; g.beta = 1.0; g.mode = 2;
     // extra column: corr = X^T (L^-1 z') - corr_tot   (K z' - corr_tot, updater.cpp:126)
     g.xcol = 1; g.bx = h->d_X + c + n; g.sbx = LDA; g.ex = u.ct; g.cx = u.corr ? u.corr : h->d_corr; g.scx = 1;
+    if (u.done_flag) { g.done_cnt = h->d_done_cnt; g.done_flag = u.done_flag; g.done_seq = u.done_seq; }
     gemm(h, g);
   } else {
     if (u.Pout != u.Pin) hipMemcpyAsync(u.Pout, u.Pin, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream);
     XkCorrArgs cr{h->d_X, LDA, c, n, c, c + n, u.ct, u.corr ? u.corr : h->d_corr};
     hipLaunchKernelGGL(xk_corr, dim3((n + 63) / 64), dim3(64), 0, h->stream, cr);
+    if (u.done_flag) hipLaunchKernelGGL(xk_mark_done, dim3(1), dim3(1), 0, h->stream, u.done_flag, u.done_seq);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "update launch", e);
@@ -1169,6 +1205,7 @@ static int cache_flags(xk_handle *h) {
     HIPCHK(h, hipEventRecord(h->ev_flags_done, h->copy_stream));
   }
   h->flags_cached = true;
+  h->flags_after_seq = h->done_seq;
   return XK_OK;
 }
 
@@ -1195,7 +1232,8 @@ extern "C" int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msc
   }
   // the MSCKF results were written by the per-feature kernel: valid once the stream has passed it (after xk_apply_update
   // it has; otherwise this waits)
-  if (h->K > 0 && hipStreamQuery(h->stream) != hipSuccess) {
+  // (a completion marker seen after the build was queued says the same without asking the runtime)
+  if (h->K > 0 && !(h->done_seen > h->flags_after_seq) && hipStreamQuery(h->stream) != hipSuccess) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
@@ -1232,10 +1270,20 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     }
     UpdateSpec u = compressed_spec(h, dct, cov_update);
     u.corr = h->h_out;
+    // The kernels write the correction and (on failure) the status words into pinned host memory; the last workgroup of the
+    // last launch then writes a sequence number next to them, which the host polls: the results are there ~5 us before the
+    // runtime's completion signal says so (XK_SPIN_DONE=0: wait for that signal instead).  One wait per update, no copy.
+    static const int spin_env = env_int("XK_SPIN_DONE", 1);
+    volatile unsigned long long *done = reinterpret_cast<volatile unsigned long long *>(h->h_out + h->n + 2);
+    if (spin_env) { u.done_flag = const_cast<unsigned long long *>(done); u.done_seq = ++h->done_seq; }
     rc = launch_update(h, u);
     if (rc != XK_OK) return rc;
-    // the kernels wrote the correction and (on failure) the status words into pinned host memory: one synchronisation, no copy
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    bool seen = false;
+    if (spin_env) {
+      for (long spins = 0; spins < 40000000L && !(seen = (*done == u.done_seq)); ++spins) __builtin_ia32_pause();   // (~1 s, then the signal)
+      if (seen) h->done_seen = u.done_seq;
+    }
+    if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
     stage_stream_idle(h);
     rc = eval_status(h, h->d_status[0], h->d_status[1], async && attempt == 0);
     if (rc != XK_RETRY_CLASSIC) break;
@@ -1796,20 +1844,25 @@ static int congruence(xk_handle *h, const int *row_ptr, const int *col_idx, cons
   HIPCHK(h, hipSetDevice(h->device));
   // the operand goes through the pinned ring: nothing here waits for the device (a frame applies two or three of these
   // back to back -- IMU steps, manage() -- before the update's one synchronisation)
-  const size_t vb = sizeof(double) * ((size_t)nnz + (q ? (size_t)qdim * qdim : 0)), ib = sizeof(int) * ((size_t)n + 1 + nnz);
+  // (+ the window lists staged since the last launch that needed them: they ride in this copy and the kernel leaves them in d_q)
+  const int wn = h->win_pending ? 7 * h->n_poses : 0;
+  const size_t vb = sizeof(double) * ((size_t)nnz + (q ? (size_t)qdim * qdim : 0) + wn), ib = sizeof(int) * ((size_t)n + 1 + nnz);
   char *st = stage_slot(h, vb + ib);
   if (!st) return fail(h, XK_ECAPACITY, "sparse operand exceeds the staging slot");
   double *sv = (double *)st;
   int *si = (int *)(st + vb);
   if (nnz) memcpy(sv, val, sizeof(double) * nnz);
   if (q) memcpy(sv + nnz, q, sizeof(double) * (size_t)qdim * qdim);
+  const size_t woff = (size_t)nnz + (q ? (size_t)qdim * qdim : 0);
+  if (wn) memcpy(sv + woff, h->h_win, sizeof(double) * wn);
   memcpy(si, row_ptr, sizeof(int) * (n + 1));
   if (nnz) memcpy(si + n + 1, col_idx, sizeof(int) * nnz);
   // [values | additive block | row pointers | column indices] in one copy
   HIPCHK(h, hipMemcpyAsync(h->d_csr_v, st, vb + ib, hipMemcpyHostToDevice, h->stream));
   double *dq = q ? h->d_csr_v + nnz : nullptr;
   const int *d_rp = (const int *)((const char *)h->d_csr_v + vb);
-  XkCongArgs a{h->d_P, h->d_Pout, n, d_rp, d_rp + n + 1, h->d_csr_v, dq, qdim, qoff};
+  XkCongArgs a{h->d_P, h->d_Pout, n, d_rp, d_rp + n + 1, h->d_csr_v, dq, qdim, qoff, wn ? h->d_csr_v + woff : nullptr, h->d_q, wn};
+  h->win_pending = false;
   hipLaunchKernelGGL(xk_congruence, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "congruence launch", e);
@@ -1898,6 +1951,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   const size_t o_pos = 24, o_att = o_pos + 3 * (size_t)N, o_cov = o_att + 4 * (size_t)N + 4 * (size_t)h->Mmax;
   const size_t trk_stride = 1 + 2 * (size_t)N;
   const double w0 = 1.0 - (double)k * ci_msckf_w, var_img = sigma_img * sigma_img;
+  { int rcw = flush_window(h); if (rcw != XK_OK) return rcw; }
   int fused = 0;
   int trk_L0[8], trk_dof[8];
   for (int j = 0; j < n_tracks; ++j) {
@@ -2038,6 +2092,7 @@ extern "C" int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, 
   if (!h || !dyn16) return XK_EINVAL;
   double *dst = d_dst ? d_dst : h->d_payload;
   HIPCHK(h, hipSetDevice(h->device));
+  { int rcw = flush_window(h); if (rcw != XK_OK) return rcw; }
   double *hd = h->h_pin;
   hd[0] = agent_id; hd[1] = timestamp; hd[2] = h->N; hd[3] = h->Mmax; hd[4] = h->n; hd[5] = h->n_poses;
   hd[6] = 0.0; hd[7] = 0.0;

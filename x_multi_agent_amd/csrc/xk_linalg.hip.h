@@ -58,6 +58,12 @@ struct XkGemmArgs {
   long sbx, sdx;
   double *cx;
   long scx;
+  // optional completion marker: the LAST workgroup to finish (counted in *done_cnt, device memory, left at zero) writes
+  // done_seq into *done_flag (pinned host memory) -- a host that polls it sees the launch's host-visible results without
+  // waiting for the runtime's completion signal
+  unsigned *done_cnt;
+  unsigned long long *done_flag;
+  unsigned long long done_seq;
 };
 
 #ifndef XK_GEMM_WAVES
@@ -115,11 +121,10 @@ __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] += red[w][r][lane];
   const int col = tn * 16 + li;
-  if (col >= g.N) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = tm * 16 + lk + 4 * r;
-    if (row >= g.M) continue;
+    if (row >= g.M || col >= g.N) continue;
     if (xc) {
       g.cx[(long)row * g.scx] = acc[r] + (g.dx ? g.dx[(long)row * g.sdx] : 0.0) - (g.ex ? g.ex[row] : 0.0);
       continue;
@@ -134,6 +139,13 @@ __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) 
       if (g.mode == 1 && row == col) v += g.diag ? g.diag[row] : g.diag_scalar;
     }
     g.C[(long)row * g.scr + (long)col * g.scc] = v;
+  }
+  if (g.done_flag) {
+    if (g.xcol && tn == tiles_n - 1) __threadfence_system();   // the extra column may be host memory: its stores first
+    if (lane == 0 && atomicAdd(g.done_cnt, 1u) == gridDim.x - 1) {
+      *g.done_cnt = 0;
+      __hip_atomic_store(g.done_flag, g.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -516,9 +528,13 @@ struct XkCongArgs {
   const double *v;      // values
   const double *Q;      // optional: qdim x qdim block (column-major) added at rows/cols [qoff, qoff + qdim)
   int qdim, qoff;
+  const double *win_src;   // optional: the frame's window lists, delivered by the operand's copy ...
+  double *win_dst;         // ... and left where the per-feature kernels read them
+  int win_n;
 };
 __global__ __launch_bounds__(256) void xk_congruence(XkCongArgs a) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < a.win_n) a.win_dst[idx] = a.win_src[idx];
   if (idx >= (long)a.n * a.n) return;
   const int r = (int)(idx % a.n), c = (int)(idx / a.n);
   const int r0 = a.rp[r], r1 = a.rp[r + 1], c0 = a.rp[c], c1 = a.rp[c + 1];
