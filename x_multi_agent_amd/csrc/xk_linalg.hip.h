@@ -690,6 +690,11 @@ __device__ __forceinline__ void xk_store_wt(double *p, double v, int wt) {
 //   Un-normalised reflectors  H = I - tt v v^T,  v = [c0 - beta; x_below],  tt = 1/(|beta|(|beta|+|c0|))
 //   = y^2 / (1 + |c0| y) with y = 1/|beta| from ONE rsq + Newton.
 //
+// The reciprocal square root and the reciprocal of the scalar chain take ONE Newton step each after v_rsq_f64 / v_rcp_f64
+// (raw: 2^-24; one step: <= 18 ulp = 4e-15; two: <= 1 ulp -- tools/exp/rcp_rsq_probe.hip).  A reflector scale that is off by
+// 4e-15 perturbs the product like the rounding of its own 64..128-term dot products does; parity against the oracle is
+// unchanged to two digits on the headline, config 2 and priors scaled by 1e2 / 1e4 (tools/exp/ab_parity.sh), and a step's
+// dependent chain is four operations shorter: QR stage - 1.3 %.  -DXK_NEWTON2 restores the second step.
 // Cost model (measured, tools/exp/clock_probe.hip): a wave issues at most one instruction every 4
 // clocks, so a step costs (instructions on the owner's path + instructions on a consumer's path) x 4
 // clocks plus two LDS round trips -- neither FMA throughput nor LDS bandwidth.  Hence:
@@ -732,7 +737,9 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
         const double n2 = fma(c0v, c0v, tail);
         double y = __builtin_amdgcn_rsq(n2);             // ~ 1/|beta|
         y = y * fma(-0.5 * n2 * y, y, 1.5);
+#ifdef XK_NEWTON2
         y = y * fma(-0.5 * n2 * y, y, 1.5);
+#endif
         const double ab = n2 * y;                        // |beta|
         beta = (c0v >= 0) ? -ab : ab;
         vp = c0v - beta;
@@ -743,7 +750,9 @@ __device__ __forceinline__ void xk_caqr_step(double (&b)[RPL], int rel, bool liv
       // (one wave64 instruction per 4 clocks in total), so per-lane redundant scalar work is not free
       double rt = __builtin_amdgcn_rcp(tden);
       rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#ifdef XK_NEWTON2
       rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#endif
       const double mtt = -(y2 * rt);
       // entries 0..KK of the reflector: rows above the pivot do not take part, the pivot entry is vp
 #pragma unroll
@@ -954,7 +963,9 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
         const double n2 = fma(c0v, c0v, tail);
         double y = __builtin_amdgcn_rsq(n2);             // ~ 1/|beta|
         y = y * fma(-0.5 * n2 * y, y, 1.5);
+#ifdef XK_NEWTON2
         y = y * fma(-0.5 * n2 * y, y, 1.5);
+#endif
         const double ab = n2 * y;                        // |beta|
         beta = (c0v >= 0) ? -ab : ab;
         vp = c0v - beta;
@@ -965,7 +976,9 @@ __device__ __forceinline__ void xk_caqr_mstep(double (&b)[RPL], int rel, bool li
       // (one wave64 instruction per 4 clocks in total), so per-lane redundant scalar work is not free
       double rt = __builtin_amdgcn_rcp(tden);
       rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#ifdef XK_NEWTON2
       rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#endif
       const double mtt = -(y2 * rt);
       ubuf[(pb * NP + part) * RPLP] = vp;                // the pivot entry of the reflector
       scp[0] = mtt;
@@ -1035,7 +1048,9 @@ __device__ __forceinline__ void xk_caqr_form(double (&b)[RPL], int rel, int part
       const double n2 = fma(c0v, c0v, tail);
       double y = __builtin_amdgcn_rsq(n2);
       y = y * fma(-0.5 * n2 * y, y, 1.5);
+#ifdef XK_NEWTON2
       y = y * fma(-0.5 * n2 * y, y, 1.5);
+#endif
       const double ab = n2 * y;
       beta = (c0v >= 0) ? -ab : ab;
       vp = c0v - beta;
@@ -1044,7 +1059,9 @@ __device__ __forceinline__ void xk_caqr_form(double (&b)[RPL], int rel, int part
     }
     double rt = __builtin_amdgcn_rcp(tden);
     rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#ifdef XK_NEWTON2
     rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#endif
     const double mtt = -(y2 * rt);
     ubuf[(pb * NP + part) * RPLP + KK] = vp;             // the pivot entry of the reflector
     scp[0] = mtt;
@@ -1125,7 +1142,9 @@ __device__ __forceinline__ void xk_caqr_mform(double (&b)[RPL], int rel, int par
       const double n2 = fma(c0v, c0v, tail);
       double y = __builtin_amdgcn_rsq(n2);
       y = y * fma(-0.5 * n2 * y, y, 1.5);
+#ifdef XK_NEWTON2
       y = y * fma(-0.5 * n2 * y, y, 1.5);
+#endif
       const double ab = n2 * y;
       beta = (c0v >= 0) ? -ab : ab;
       vp = c0v - beta;
@@ -1134,7 +1153,9 @@ __device__ __forceinline__ void xk_caqr_mform(double (&b)[RPL], int rel, int par
     }
     double rt = __builtin_amdgcn_rcp(tden);
     rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#ifdef XK_NEWTON2
     rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#endif
     const double mtt = -(y2 * rt);
     ubuf[(pb * NP + part) * RPLP] = vp;
     scp[0] = mtt;
@@ -1294,7 +1315,9 @@ __device__ __forceinline__ void xk_caqr_mstep32(double (&b)[RH], int rel, bool l
         const double n2 = fma(c0v, c0v, tail);
         double y = __builtin_amdgcn_rsq(n2);
         y = y * fma(-0.5 * n2 * y, y, 1.5);
+#ifdef XK_NEWTON2
         y = y * fma(-0.5 * n2 * y, y, 1.5);
+#endif
         const double ab = n2 * y;
         beta = (c0v >= 0) ? -ab : ab;
         vp = c0v - beta;
@@ -1303,7 +1326,9 @@ __device__ __forceinline__ void xk_caqr_mstep32(double (&b)[RH], int rel, bool l
       }
       double rt = __builtin_amdgcn_rcp(tden);
       rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#ifdef XK_NEWTON2
       rt = fma(rt, fma(-tden, rt, 1.0), rt);
+#endif
       const double mtt = -(y2 * rt);
       ubuf[(pb * NP + part) * RHP] = vp;                 // the pivot entry of the reflector
       scp[0] = mtt;
