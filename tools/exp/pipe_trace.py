@@ -34,7 +34,8 @@ if mode == "pipe":
         print(f"{k:3d}  " + " ".join(f"{us(ph[i+1]-ph[i]):5.2f}" for i in range(len(ph) - 1)) + f" | {us(r[5]-ph[-1]):5.2f} {us(r[6]-r[5]):5.2f} {us(r[7]-r[6]):5.2f} || {us(nxt-r[0]):6.2f} | {us(nxt-t0):7.2f} | shader clock {(r[9]-r[8])/max(1,(r[10]-r[0]))/10:.2f} GHz")
     print("first level (XCD 0, item 0), us after the tile step of the panel started: per phase (rows seen, steps done + published) ... | strips stored + arrived")
     for k in range(npan):
-        print(f"{k:3d}  " + "  ".join(f"{us(M[k,i]-T[k,0]):6.2f}" for i in range(9) if M[k, i] > 0))
+        print(f"{k:3d}  " + "  ".join(f"{us(M[k,i]-T[k,0]):6.2f}" for i in range(9) if M[k, i] > 0) +
+              ("   | rows landed (probe build): " + "  ".join(f"{us(M[k,i]-T[k,0]):6.2f}" for i in range(10, 14) if M[k, i] > 0) if M[k, 10] > 0 else ""))
     print("last level (workgroup 0), us after the tile step of the panel started: per phase (roots seen, steps done) ... | out")
     for k in range(npan):
         print(f"{k:3d}  " + "  ".join(f"{us(L[k,i]-T[k,0]):6.2f}" for i in range(9) if L[k, i] > 0))

@@ -61,13 +61,21 @@ using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM fe
 #ifndef XK_PIPE_ARRD
 #define XK_PIPE_ARRD 1              // a phase's rows are counted in at the barrier ARRD steps after their stores were issued
 #endif
+#ifndef XK_PIPE_PF
+#define XK_PIPE_PF 0                // 1: first level: a phase's rows of the tiles' strips come in as three 16-bytes-per-lane loads per
+#endif                              // wave through LDS instead of 23 eight-byte loads per lane (measured: the loads of a phase land
+                                    // in 0.76 instead of 1.44 us, the QR stage does not get shorter -- DESIGN 6.0)
 #ifndef XK_PIPE_LOCALLD
 #define XK_PIPE_LOCALLD 0           // 1: XCD-local strip loads as workgroup-scope loads behind an L1 invalidate (buffer_inv sc1):
                                     // correct, and 0.32 -> 0.59 ms -- the invalidate costs far more than the fabric round trips it saves
 #endif
 #if XK_PIPE_LOCALLD
 #define XK_LD_LOC(p) xk_ld_grp(p)
+#ifdef XK_PIPE_NOINV
+#define XK_INV_LOC()
+#else
 #define XK_INV_LOC() xk_inv_l1()
+#endif
 #else
 #define XK_LD_LOC(p) xk_ld_sc1(p)
 #define XK_INV_LOC()
@@ -368,9 +376,11 @@ __device__ __forceinline__ void xk_pipe_apply2(double (&b)[RPL], double (*b2)[RP
   }
   xk_pipe_apply<LPC, K, RPL>(b, rel, live, part, ubuf, sc);
 }
-template <int LPC, int K, int K1, int KH, int RPL, typename Hook>
+// `every` is called by all threads behind the barrier of every step (the first level's look-out for the next phase's rows)
+struct XkNoStepHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int LPC, int K, int K1, int KH, int RPL, typename Hook, typename Every>
 __device__ __forceinline__ void xk_pipe_range_it(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, int nsteps,
-                                                 double *ubuf, double *sc, bool hook_on, Hook hook) {
+                                                 double *ubuf, double *sc, bool hook_on, Hook hook, Every every) {
   if constexpr (K < K1) {
     if (K < nsteps) {
       xk_pipe_apply2<LPC, K - 1, RPL>(b, b2, rel, live, live2, part, ubuf, sc);
@@ -378,21 +388,28 @@ __device__ __forceinline__ void xk_pipe_range_it(double (&b)[RPL], double (*b2)[
       if (K == KH && hook_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (K == KH && hook_on && threadIdx.x == 0) hook();
+      every(K);
     } else if (K == nsteps) {
       xk_pipe_apply2<LPC, K - 1, RPL>(b, b2, rel, live, live2, part, ubuf, sc);
     }
-    xk_pipe_range_it<LPC, K + 1, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook);
+    xk_pipe_range_it<LPC, K + 1, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook, every);
   }
 }
-template <int LPC, int K0, int K1, int KH, int RPL, typename Hook>
+template <int LPC, int K0, int K1, int KH, int RPL, typename Hook, typename Every>
 __device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, int nsteps,
-                                              double *ubuf, double *sc, bool hook_on, Hook hook) {
+                                              double *ubuf, double *sc, bool hook_on, Hook hook, Every every) {
   if (K0 < nsteps) xk_pipe_form<LPC, K0, RPL>(b, rel, part, ubuf, sc);
   if (KH == K0 && hook_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (KH == K0 && hook_on && threadIdx.x == 0) hook();
-  xk_pipe_range_it<LPC, K0 + 1, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook);
+  every(K0);
+  xk_pipe_range_it<LPC, K0 + 1, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook, every);
   if (nsteps >= K1) xk_pipe_apply2<LPC, K1 - 1, RPL>(b, b2, rel, live, live2, part, ubuf, sc);
+}
+template <int LPC, int K0, int K1, int KH, int RPL, typename Hook>
+__device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], double (*b2)[RPL], int rel, bool live, bool live2, int part, int nsteps,
+                                              double *ubuf, double *sc, bool hook_on, Hook hook) {
+  xk_pipe_range<LPC, K0, K1, KH, RPL>(b, b2, rel, live, live2, part, nsteps, ubuf, sc, hook_on, hook, XkNoStepHook());
 }
 
 // ---- role T: one fat tile in registers for the whole factorisation
@@ -504,11 +521,18 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
   return true;
 }
 
+// 16 bytes per lane from global memory straight into LDS (lane l lands at lds_byte + 16 l): device-scope load, no VGPR
+// destination, so nothing in the step code waits for it.  Written in assembly on purpose: the compiler would put a vmcnt(0) in
+// front of the next LDS read of ANY array; here the one wait is placed by hand where the rows are taken out.
+__device__ __forceinline__ void xk_lds_dma16(const double *src, unsigned lds_byte) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(src), "s"(lds_byte) : "memory", "m0");
+}
+
 // ---- role M: the first merge level of this XCD's NT strips (+ the pending strip), 16 panel + <= 32 trailing columns per workgroup
 // 16 lanes per column: lane p = row p of every strip, register 0 = the pending strip = the pivot strip, register 1 + t = tile t
 // (register RM - 1 stays zero when NT is even)
 template <class G>
-__device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok) {
+__device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok, double *pfbuf) {
   constexpr int NT = G::NT, NM = G::NM, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NCM = G::NCM;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
@@ -560,18 +584,59 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     const bool x1_mine = mine && (!panel || item == 0);
     bool ok = true;
     int loaded = 0;                                        // phases of the tiles' strips that are in registers
+    // Wide strip loads (XK_PIPE_PF).  Rows 4 q .. 4 q + 3 of one strip over the four columns of a wave are ONE 128-byte line
+    // (xk_blk), and only a quarter of the lanes hold rows of the phase: as 23 eight-byte loads per lane a phase costs the
+    // workgroup 12 x 23 vector-memory instructions that move 128 bytes each -- ~16 clocks apiece in the CU's one address
+    // unit, 1.5 us per phase, four times per panel, on the chain of both dependency loops.  Instead every wave asks for its 23
+    // lines with THREE 16-bytes-per-lane loads that land straight in LDS (lane l: strip 8 j + l / 8, piece l % 8), and the
+    // lanes of the phase pick their 23 values up from there.
+    constexpr bool PF = XK_PIPE_PF && NCM == 1 && NPH == 4 && NT <= 24;
+    const int ln = tid & 63, cid4 = cidx & ~3;
+    const int wcol = panel ? c0 + cid4 : c0 + 16 + item * mch + (cid4 - 16);
+    const bool wv_ok = active && (panel || cid4 - 16 < mh) && wcol < a.C1;
+    double *pfw = pfbuf + (size_t)(tid >> 6) * (24 * 16);
+    const unsigned pfw_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)pfw);   // (LDS offset = low half of the flat address)
+    const double *pfsrc = (panel ? a.PB + (size_t)base * 256 + xk_blk(cid4, 0) : a.S + (size_t)base * SS + xk_blk(wcol, 0)) +
+                          (size_t)(ln >> 3) * strip_step + (ln & 7) * 2;
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (!ok) return;
       if (loaded <= q) {
+#ifdef XK_PIPE_PROBE_M1ALL
+        // TIMING PROBE ONLY (wrong results): every phase's rows are fetched with phase 0's -- what the first level would cost if
+        // the load latency of phases 1..3 were hidden
+        int av = xk_pipe_wait_phases(sync + (XP_TQ_CNT + xcc) * 16, 8 * 16, q, NPH, (unsigned)NT * epoch, ab, 6u, s_ok);
+        if (av != 0) av = NPH;
+#else
         const int av = xk_pipe_wait_phases(sync + (XP_TQ_CNT + xcc) * 16, 8 * 16, q, NPH, (unsigned)NT * epoch, ab, 6u, s_ok);
+#endif
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
         XK_INV_LOC();
-        if (active && mine && part >= loaded * GS && part < av * GS) {
-          double *g = xk_opaque(g0);
+        if constexpr (PF) {
+          // (a first level that runs behind finds several phases complete: one round per phase, the LDS area holds one)
+          for (int p = loaded; p < av; ++p) {
+            if (wv_ok) {                                     // wave-uniform
+              const double *src = pfsrc + (size_t)p * 16;
 #pragma unroll
-          for (int s = 1; s <= NT; ++s) b[s] = XK_LD_LOC(g + (size_t)(s - 1) * strip_step);
+              for (int j = 0; j < 3; ++j)
+                if (8 * j + (ln >> 3) < NT) xk_lds_dma16(src + (size_t)(8 * j) * strip_step, pfw_lds + (unsigned)j * 1024u);
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (mine && part >= p * GS && part < (p + 1) * GS) {
+                typedef const __attribute__((address_space(3))) double xk_lds_cd;
+                xk_lds_cd *pl = (xk_lds_cd *)(pfw + (part - p * GS) * 4 + (cidx & 3));
+#pragma unroll
+                for (int s = 1; s <= NT; ++s) b[s] = pl[(s - 1) * 16];
+              }
+              if (p + 1 < av) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the area is rewritten by the next round
+            }
+          }
+        } else {
+          if (active && mine && part >= loaded * GS && part < av * GS) {
+            double *g = xk_opaque(g0);
+#pragma unroll
+            for (int s = 1; s <= NT; ++s) b[s] = XK_LD_LOC(g + (size_t)(s - 1) * strip_step);
+          }
         }
         if constexpr (NCM > 1) {
           if (mine2 && part >= loaded * GS && part < av * GS) {
@@ -581,6 +646,11 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
           }
         }
         loaded = av;
+#ifdef XK_PIPE_M1PROBE
+        // timing probe: when have the strips' rows landed?  (the wait sits on the chain: not a production build)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stamp && q < 4) a.dbg[512 + 16 * k + 10 + q] = wall_clock64();
+#endif
       }
       if (!active) return;
       if (panel) __builtin_amdgcn_s_setprio(3);
@@ -739,6 +809,8 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
   __shared__ unsigned s_slot, s_ok;
+  // landing area of the first level's load-to-LDS prefetch: per wave (4 columns) 24 strips x 4 rows x 4 columns
+  __shared__ __attribute__((aligned(16))) double pfbuf[XK_PIPE_PF ? (XK_PIPE_THREADS / 64) * 24 * 16 : 2];
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const XkPipeArgsPtr ap = (XkPipeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned xcc = xk_xcc_id();
@@ -760,7 +832,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   if (a.test_stall && xcc == 3 && slot == 5) return;
   bool ok;
   if (slot < NT) ok = xk_pipe_tile<G>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok);
-  else if (slot < NT + NM) ok = xk_pipe_first<G>(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok);
+  else if (slot < NT + NM) ok = xk_pipe_first<G>(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok, pfbuf);
   else {
     // nothing to do until the first roots arrive: leave the other set of sync words zeroed for the next launch
     for (int i = (int)xcc * XK_PIPE_THREADS + threadIdx.x; i < XP_WORDS * 16; i += 8 * XK_PIPE_THREADS) a.sync_next[i] = 0u;
