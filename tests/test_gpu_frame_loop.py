@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 PKG = os.path.join(os.path.dirname(__file__), "..", "x_multi_agent_amd")
 
 
-def run_frame_loop(tmp_path, sc, frames, imu_per_frame, mode):
+def run_frame_loop(tmp_path, sc, frames, imu_per_frame, mode, extra_env=None):
     exe = os.path.join(PKG, "xk_frame_loop_example")
     if not os.path.exists(exe):
         from x_multi_agent_amd import build
@@ -28,6 +28,7 @@ def run_frame_loop(tmp_path, sc, frames, imu_per_frame, mode):
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / f"out{mode}.bin")
     np.concatenate(parts).astype("<f8").tofile(fin)
     env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.update(extra_env or {})
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     out = np.fromfile(fout, dtype="<f8")
@@ -84,3 +85,16 @@ def test_resident_and_state_owned_covariance_agree_at_the_headline_size(tmp_path
     a = run_frame_loop(tmp_path, sc, 2, 7, 0)
     b = run_frame_loop(tmp_path, sc, 2, 7, 1)
     assert rel(b["P"], a["P"]) <= 1e-10 and rel(b["core"], a["core"]) <= 1e-9
+
+
+def test_frame_with_the_runtime_wait_instead_of_the_completion_marker(tmp_path):
+    """XK_SPIN_DONE=0: xk_apply_update waits for the stream instead of polling the marker its last workgroup writes; and
+    with the marker, ten frames in a row (the marker's sequence number and the window lists carried by manage()'s congruence)."""
+    sc = synth.make_scenario(8, 24, 0, seed=0x5EED6001)
+    ref = oracle_frame(sc, 3)
+    a = run_frame_loop(tmp_path, sc, 2, 3, 1, {"XK_SPIN_DONE": "0"})
+    b = run_frame_loop(tmp_path, sc, 10, 3, 1)
+    for got in (a, b):
+        assert f"inliers={ref['inliers']} " in got["log"]
+        assert rel(got["P"], ref["P"]) <= 1e-9 and rel(got["core"], ref["core"]) <= 1e-8
+    assert np.array_equal(a["P"], b["P"])
