@@ -601,6 +601,13 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (!ok) return;
+#ifdef XK_PIPE_PROBE_M1PACE
+      // TIMING PROBE ONLY (wrong results): all rows were fetched with phase 0, but every phase still WAITS for the tiles' rows
+      // of its own -- separates what the waits (the tiles' pace) cost from what the loads cost
+      if (q > 0 && loaded > q) {
+        if (xk_pipe_wait_phases(sync + (XP_TQ_CNT + xcc) * 16, 8 * 16, q, NPH, (unsigned)NT * epoch, ab, 6u, s_ok) == 0) { ok = false; return; }
+      }
+#endif
       if (loaded <= q) {
 #ifdef XK_PIPE_PROBE_M1ALL
         // TIMING PROBE ONLY (wrong results): every phase's rows are fetched with phase 0's -- what the first level would cost if
