@@ -102,3 +102,46 @@ def test_hundred_headline_updates_on_one_handle(xk, oracle_c):
     st = eng.caqr_status()
     assert st["schedule"] == 2 and st["giveups"] == 0 and st["armed"], st
     eng.close()
+
+
+def test_random_wide_windows_against_the_oracle(xk, oracle_c):
+    """Windows of 34..64 poses take the multi-launch schedule with this round's kernels: packed gate matrix and the four-wave
+    gate (two or three tile columns per wave), 26 or 32 rows per lane in the tile step, rejected tracks skipped, the 32-lane
+    first merge level above 400 tiles.  Twelve random shapes (ragged tracks, partial windows, heavy rejection, a few SLAM
+    features) against the C oracle, two updates per handle."""
+    rng = np.random.default_rng(20260930)
+    worst, bad, ran = 0.0, [], 0
+    while ran < 12:
+        N = int(rng.integers(34, 65))
+        K = int(rng.choice([20, 60, 150, 420, 450]))
+        M = int(rng.choice([0, 0, 0, 6]))
+        if N * K > 16000:                                   # (keeps the oracle's dense QR within a few seconds)
+            K = max(12, 16000 // N)
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), outlier_frac=float(rng.choice([0.0, 0.05, 0.3, 0.8])),
+                  prior_scale=float(rng.choice([0.1, 1.0, 30.0])))
+        if rng.random() < 0.5:
+            kw["track_len"] = (2, N)
+        if rng.random() < 0.25:
+            kw["n_poses"] = int(rng.integers(34, N + 1))
+            if "track_len" in kw:
+                kw["track_len"] = (2, kw["n_poses"])
+        try:
+            sc = synth.make_scenario(N, K, M, **kw)
+        except Exception:
+            continue
+        ran += 1
+        ref = oracle_c.visual_update(sc)
+        eng = xk.Engine(N, M, K)
+        for rep in range(2):
+            eng.stage(sc)
+            got = eng.visual_update_staged(sc["sigma_img"])
+            rp = rel(eng.download_P(), ref["P"])
+            worst = max(worst, rp)
+            fin = np.isfinite(ref["gamma"])
+            if (not np.array_equal(got["inlier"], ref["inlier"]) or not np.array_equal(got["inlier_slam"], ref["inlier_slam"])
+                    or not (rp <= 1e-8) or not (rel(got["gamma"][fin], ref["gamma"][fin]) <= 1e-8)):
+                bad.append((N, K, M, kw, rep, rp))
+        assert eng.caqr_status()["schedule"] == 0
+        eng.close()
+    assert not bad, bad
+    print(f"soak: 12 wide windows, worst rel dP {worst:.2e}")
