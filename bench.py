@@ -247,12 +247,28 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame-loop", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    # First-contact insurance for the multi-GPU run (no multi-GPU node is available to the builder): ONE process walks rank
+    # --dry-run-rank of a fleet of --dry-run-ranks agents -- rank-indexed scenario, payload sizes, ring pattern, device-side
+    # pack into the RCCL send buffer, the collective itself on a ONE-RANK nccl communicator (its own slot really travels
+    # through RCCL), the CI round on the receive buffer against the other agents' payloads, which are packed into that
+    # buffer in HBM beforehand.  Prints a short JSON report instead of the bench line.
+    ap.add_argument("--dry-run-ranks", type=int, default=0)
+    ap.add_argument("--dry-run-rank", type=int, default=0)
+    ap.add_argument("--dump-posterior", default=None, help="rank 0 / the dry-run rank: save the resident covariance after the run (.npy)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dry = args.dry_run_ranks >= 2
+    if dry and world != 1:
+        raise SystemExit("--dry-run-ranks is a single-process mode")
+    real_world = world
+    if dry:
+        world, rank = args.dry_run_ranks, args.dry_run_rank
+        if not 0 <= rank < world:
+            raise SystemExit("--dry-run-rank outside the fleet")
 
     import torch
     from x_multi_agent_amd import engine, fleet, synth
@@ -265,7 +281,15 @@ def main():
     dev = int(os.environ.get("XK_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if dry:
+        import socket
+        import torch.distributed as dist
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        kw = dict(device_id=torch.device("cuda", dev)) if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
+    elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -283,15 +307,33 @@ def main():
 
     # CI payload exchange (torch owns the buffers so RCCL sends/receives them in place)
     pay_n = eng.payload_doubles()
-    ex = fleet.Exchange(dist, world, rank, pay_n, xdev)
+    ex = fleet.Exchange(dist, world, rank, pay_n, xdev, real_world=real_world)
     pay_dev = torch.zeros(pay_n, dtype=torch.float64, device=f"cuda:{dev}")
     dyn16 = np.zeros(16)
     dyn16[9] = 1.0
 
     # observations of the shared tracks travel next to the SimpleState payload
-    tex = fleet.Exchange(dist, world, rank, CI_TRACKS * (1 + 2 * N), xdev)
+    tex = fleet.Exchange(dist, world, rank, CI_TRACKS * (1 + 2 * N), xdev, real_world=real_world)
     tex.send.copy_(torch.from_numpy(fleet.pack_tracks(sc, CI_TRACKS, N).ravel()))
     ci_stats = {"rounds": 0, "fused": 0}
+    if dry:
+        # the other agents of the virtual fleet: their scenarios (rank-indexed, as their own processes would build them), their
+        # SimpleState payloads packed ON THE DEVICE by an engine of their own, straight into their slots of the receive buffers
+        for v in range(world):
+            if v == rank:
+                continue
+            scv = fleet.shared_scenario(synth, args.config, v)
+            ev = engine.Engine(N, M, K, device=dev)
+            ev.stage(scv)
+            slot = ex.recv.view(world, pay_n)[v]
+            if slot.is_cuda:
+                ev.pack_payload_into(v, 0.0, dyn16, slot.data_ptr())
+            else:
+                tmp = torch.zeros(pay_n, dtype=torch.float64, device=f"cuda:{dev}")
+                ev.pack_payload_into(v, 0.0, dyn16, tmp.data_ptr())
+                slot.copy_(tmp)
+            tex.recv.view(world, tex.n)[v].copy_(torch.from_numpy(fleet.pack_tracks(scv, CI_TRACKS, N).ravel()))
+            ev.close()
     if args.config == 5 and world > 1:
         # keyframe database + request filter on the device (place.Database = x::Database, reference vocabulary)
         from x_multi_agent_amd import place
@@ -299,10 +341,35 @@ def main():
         kdb = place.Database(eng, place.load_vocabulary("visual"), PR_SCORE_THR, payload_doubles=pay_n, tracks_doubles=trk_n,
                              max_desc=256)
         pr_scene = synth.make_descriptors(96, 32, seed=0x5EED)        # the place every agent of the fleet looks at
-        vex = fleet.Exchange(dist, world, rank, kdb.vlad_bytes, xdev, dtype=torch.uint8)
-        rex = fleet.Exchange(dist, world, rank, 2 + pay_n + trk_n, xdev)
+        vex = fleet.Exchange(dist, world, rank, kdb.vlad_bytes, xdev, dtype=torch.uint8, real_world=real_world)
+        rex = fleet.Exchange(dist, world, rank, 2 + pay_n + trk_n, xdev, real_world=real_world)
         resp_dev = torch.zeros(2 + pay_n + trk_n, dtype=torch.float64, device=f"cuda:{dev}")
         trk_dev = torch.zeros(trk_n, dtype=torch.float64, device=f"cuda:{dev}")
+        if dry:
+            # virtual partners of the request/response tick: the requester that asks ME sends the VLAD of what it sees; the
+            # responder I ask keeps a keyframe database of its own (its payload slot + tracks + descriptors), searches it with
+            # MY VLAD and answers in the response layout
+            vdbs, dry_tick = {}, [0]
+
+            def peer_vlad(requester):
+                return torch.from_numpy(kdb.compute_vlad(synth.observe_descriptors(pr_scene, 4, seed=104729 * requester + dry_tick[0])).ravel()).to(xdev)
+
+            def peer_response(rsp):
+                if rsp not in vdbs:
+                    vdbs[rsp] = place.Database(eng, place.load_vocabulary("visual"), PR_SCORE_THR, payload_doubles=pay_n,
+                                               tracks_doubles=trk_n, max_desc=256)
+                pv = ex.recv.view(world, pay_n)[rsp].cuda(dev).contiguous()
+                tv = tex.recv.view(world, tex.n)[rsp].cuda(dev).contiguous()
+                vdbs[rsp].add_keyframe(synth.observe_descriptors(pr_scene, 4, seed=7919 * rsp + dry_tick[0]), pv.data_ptr(), tv.data_ptr(),
+                                       tag=dry_tick[0])
+                out = torch.zeros(2 + pay_n + trk_n, dtype=torch.float64, device=f"cuda:{dev}")
+                idx, _score, tag = vdbs[rsp].find_candidate(int(rank), vex.send.cpu().numpy())
+                if idx >= 0:
+                    vdbs[rsp].copy_keyframe(idx, out.data_ptr() + 16, out.data_ptr() + 8 * (2 + pay_n))
+                    out[0], out[1] = 1.0, float(tag)
+                return out.to(xdev)
+
+            vex.peer_answer, rex.peer_answer = peer_vlad, peer_response
 
     def exchange(step):
         """CI round: all-gather the snapshots over RCCL, then fuse the shared tracks against them on the device."""
@@ -318,6 +385,8 @@ def main():
             # (snapshot + tracks + descriptors, all resident in HBM), sends the binary VLAD of what it sees to one
             # responder, and fuses against the keyframe that comes back -- if the responder's database has one
             tick = step // ci_every
+            if dry:
+                dry_tick[0] = tick
             trk_dev.copy_(tex.send)
             kdb.add_keyframe(synth.observe_descriptors(pr_scene, 4, seed=7919 * rank + tick), pay_dev.data_ptr(),
                              trk_dev.data_ptr(), tag=step)
@@ -353,7 +422,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if real_world > 1 or dry:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -371,11 +440,24 @@ def main():
             exchange(done)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if real_world > 1 or dry:
         tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if args.dump_posterior and (dry or rank == 0):
+        np.save(args.dump_posterior, eng.download_P())
+    if dry:
+        rep = {"dry_run": True, "fleet": world, "rank": rank, "config": args.config, "backend": backend,
+               "real_ranks_in_the_communicator": real_world, "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,
+               "payload_bytes": 8 * pay_n, "ci_every": ci_every, "ci_rounds": ci_stats["rounds"], "ci_fused": ci_stats["fused"],
+               "keyframes_received": ci_stats.get("keyframes_received"),
+               "ring_partner_per_tick": [fleet.ring_requests(world, t)[rank][1] for t in range(min(4, world))] if args.config == 5 else None,
+               "send_buffer_device": str(ex.send.device), "receive_buffer_doubles": int(ex.recv.numel())}
+        print(json.dumps(rep), flush=True)
+        eng.close()
+        dist.destroy_process_group()
+        return
     if rank == 0:
         # per-stage HIP-event timing of the same staged update (untimed region)
         tm = eng.bench_staged(sigma, 2, min(20, max(5, args.steps)))

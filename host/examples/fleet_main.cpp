@@ -19,6 +19,13 @@
 //   xk_fleet_example case.bin out.bin 2 <rank> <idfile>    TWO RANKS over RCCL (one GPU each; rank 0 writes the 128-byte unique
 //                                                          id to <idfile>, rank 1 waits for it): both agents request, answer
 //                                                          and fuse symmetrically; rank r writes out.bin.<r>.
+//   xk_fleet_example case.bin out.bin dry <N> <rank> <idfile>   DRY RUN of rank <rank> in a ring of N agents (first-contact insurance:
+//                                                          no multi-GPU node is available to the builder).  One process walks
+//                                                          the multi-rank branch -- unique-id file written AND read back,
+//                                                          device = rank mod visible devices, rank-indexed scenario, ring partners
+//                                                          (rank asks rank+1, answers rank-1), message sizes -- with every
+//                                                          send/recv on a ONE-rank communicator and the partners' messages produced
+//                                                          by an in-process agent whose buffers are already in HBM.
 //   in : N K n_shared sigma_img ci_msckf_w pr_score_thr | vocabulary: k L n_nodes kmax desc_bytes n_words, node_desc, children,
 //        word_of_node, node_of_word | per agent (2): q[4N] p[3N] P[n*n] L_k[K] obs[2 sum L] n_kf_desc kf_desc[..] n_q_desc q_desc[..]
 //   out: found tag n_fused | correction[n] | P_post[n*n]        (of the requester: agent 0 in loop-back mode)
@@ -188,8 +195,8 @@ static void writeOut(const std::string &path, const std::vector<double> &v) {
 }
 
 int main(int argc, char **argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s case.bin out.bin [2 rank idfile]\n", argv[0]); return 2; }
-  const int world = argc > 3 ? atoi(argv[3]) : 1, rank = argc > 4 ? atoi(argv[4]) : 0;
+  if (argc < 3) { fprintf(stderr, "usage: %s case.bin out.bin [2 rank idfile | dry N rank idfile]\n", argv[0]); return 2; }
+  const int world = argc > 3 ? (std::string(argv[3]) == "dry" ? -1 : atoi(argv[3])) : 1, rank = argc > 4 ? atoi(argv[4]) : 0;
   const std::vector<double> in = slurp(argv[1]);
   size_t at = 0;
   const int N = (int)in[at++], K = (int)in[at++], n_shared = (int)in[at++];
@@ -247,38 +254,71 @@ int main(int argc, char **argv) {
       a.destroy();
       b.destroy();
     } else {
-      // ---- two ranks over RCCL: symmetric -- each agent requests from, answers to and fuses against its peer
-      if (world != 2 || argc < 6) throw std::runtime_error("two-rank mode: case.bin out.bin 2 <rank> <idfile>");
-      const std::string idfile = argv[5];
-      if (rank == 0) {
+      // ---- several ranks over RCCL (two real ones, or a dry run of one rank of a ring): each agent requests from its right-hand
+      //      neighbour, answers its left-hand neighbour and fuses against the keyframe that comes back
+      const bool dry = std::string(argv[3]) == "dry";
+      const int fleet = dry ? atoi(argv[4]) : world, me_rank = dry ? atoi(argv[5]) : rank;
+      if ((!dry && (world != 2 || argc < 6)) || (dry && (argc < 7 || fleet < 2 || me_rank < 0 || me_rank >= fleet)))
+        throw std::runtime_error("multi-rank mode: case.bin out.bin 2 <rank> <idfile> | case.bin out.bin dry <N> <rank> <idfile>");
+      const std::string idfile = dry ? argv[6] : argv[5];
+      const int ask = (me_rank + 1) % fleet, asked_by = (me_rank + fleet - 1) % fleet;       // the ring
+      if (me_rank == 0 || dry) {
         xkok(nullptr, xk_fleet_unique_id(uid), "xk_fleet_unique_id");
         FILE *f = fopen((idfile + ".tmp").c_str(), "wb");
-        fwrite(uid, 1, sizeof(uid), f);
+        if (!f || fwrite(uid, 1, sizeof(uid), f) != sizeof(uid)) throw std::runtime_error("cannot write the unique id file");
         fclose(f);
         rename((idfile + ".tmp").c_str(), idfile.c_str());
-      } else {
+      }
+      if (me_rank != 0 || dry) {
+        unsigned char got[XK_FLEET_ID_BYTES];
         FILE *f = nullptr;
         for (int i = 0; i < 6000 && !(f = fopen(idfile.c_str(), "rb")); ++i) std::this_thread::sleep_for(std::chrono::milliseconds(10));
-        if (!f || fread(uid, 1, sizeof(uid), f) != sizeof(uid)) throw std::runtime_error("no unique id from rank 0");
+        if (!f || fread(got, 1, sizeof(got), f) != sizeof(got)) throw std::runtime_error("no unique id from rank 0");
         fclose(f);
+        if (dry && memcmp(got, uid, sizeof(uid)) != 0) throw std::runtime_error("unique id file does not read back");
+        memcpy(uid, got, sizeof(uid));
       }
-      HIPOK(hipSetDevice(rank));
-      Agent me;
-      const int peer = 1 - rank;
-      me.create(rank, N, K, n_shared, sc[rank], voc, thr, 2, rank, uid);
-      me.storeKeyframe(100 * (rank + 1));
-      me.prepareRequest();
-      xkok(me.h, xk_fleet_send_recv(me.f, me.d_vlad_out, me.vlad_n, peer, me.d_vlad_in, me.vlad_n, peer), "request");
-      xkok(me.h, xk_fleet_wait(me.f), "wait");
-      me.answer(peer, me.d_vlad_in);
+      int ndev = 0;
+      HIPOK(hipGetDeviceCount(&ndev));
+      if (!dry && me_rank >= ndev) throw std::runtime_error("fewer devices than ranks");
+      HIPOK(hipSetDevice(dry ? me_rank % ndev : me_rank));
+      Agent me, partner;                    // (partner: dry run only -- the neighbours' messages, produced in this process)
+      const int comm_world = dry ? 1 : fleet, comm_rank = dry ? 0 : me_rank;
+      me.create(me_rank, N, K, n_shared, sc[me_rank % 2], voc, thr, comm_world, comm_rank, uid);
       const long rn = 2 + me.pay_n + me.trk_n;
-      xkok(me.h, xk_fleet_send_recv(me.f, me.d_resp_out, rn, peer, me.d_resp_in, rn, peer), "response");
-      xkok(me.h, xk_fleet_wait(me.f), "wait");
+      me.storeKeyframe(100 * (me_rank + 1));
+      me.prepareRequest();
+      if (dry) {
+        unsigned char uid2[XK_FLEET_ID_BYTES];
+        xkok(nullptr, xk_fleet_unique_id(uid2), "xk_fleet_unique_id");
+        partner.create(ask, N, K, n_shared, sc[ask % 2], voc, thr, 1, 0, uid2);
+        if (partner.pay_n != me.pay_n || partner.trk_n != me.trk_n || partner.vlad_n != me.vlad_n) throw std::runtime_error("message sizes differ between ranks");
+        partner.storeKeyframe(100 * (ask + 1));
+        partner.prepareRequest();
+        HIPOK(hipStreamSynchronize(partner.stream));
+        // my request leaves through RCCL (to myself: the one real rank) ...; the left-hand neighbour's request lands in MY receive buffer
+        xkok(me.h, xk_fleet_send_recv(me.f, me.d_vlad_out, me.vlad_n, 0, partner.d_vlad_in, me.vlad_n, 0), "request");
+        xkok(me.h, xk_fleet_wait(me.f), "wait");
+        HIPOK(hipMemcpy(me.d_vlad_in, partner.d_vlad_out, sizeof(double) * me.vlad_n, hipMemcpyDeviceToDevice));
+        me.answer(asked_by, me.d_vlad_in);                                        // my responder half (answer discarded: the asker is virtual)
+        partner.answer(me_rank, partner.d_vlad_in);                                // the right-hand neighbour answers MY request
+        xkok(me.h, xk_fleet_send_recv(me.f, partner.d_resp_out, rn, 0, me.d_resp_in, rn, 0), "response");
+        xkok(me.h, xk_fleet_wait(me.f), "wait");
+      } else {
+        xkok(me.h, xk_fleet_send_recv(me.f, me.d_vlad_out, me.vlad_n, ask, me.d_vlad_in, me.vlad_n, asked_by), "request");
+        xkok(me.h, xk_fleet_wait(me.f), "wait");
+        me.answer(asked_by, me.d_vlad_in);
+        xkok(me.h, xk_fleet_send_recv(me.f, me.d_resp_out, rn, asked_by, me.d_resp_in, rn, ask), "response");
+        xkok(me.h, xk_fleet_wait(me.f), "wait");
+      }
       std::vector<double> out;
       me.fuseAndUpdate(me.d_resp_in, sigma_img, ci_w, out);
-      writeOut(std::string(argv[2]) + "." + std::to_string(rank), out);
-      printf("ok rank %d: keyframe %s (tag %ld), %d shared tracks fused\n", rank, out[0] != 0.0 ? "received" : "refused", (long)out[1], (int)out[2]);
+      writeOut(std::string(argv[2]) + "." + std::to_string(me_rank), out);
+      printf("ok %srank %d of %d (asks %d, answers %d; device %d of %d; %ld-byte responses): keyframe %s (tag %ld), %d shared tracks fused\n",
+             dry ? "dry-run " : "", me_rank, fleet, ask, asked_by, dry ? me_rank % ndev : me_rank, ndev, 8 * rn,
+             out[0] != 0.0 ? "received" : "refused", (long)out[1], (int)out[2]);
       me.destroy();
+      if (dry) partner.destroy();
     }
   } catch (const std::exception &e) {
     fprintf(stderr, "error: %s\n", e.what());

@@ -3,10 +3,13 @@
 // oldest state (state_buffer.cpp); the mirror does the same and moves the device covariance one slot on first.  Checked
 // against the same IMU stream through the reference-semantics mode (every State owns its covariance):
 //   usage: xk_ring_wrap_example [n_steps] [buffer_sz]      prints "OK <max rel diff>" or "FAIL ..."
+//          xk_ring_wrap_example during_update [buffer_sz]  the ring wraps onto the resident covariance WHILE an update is in
+//                                                           flight on it (the IMU thread outruns a slow update): must throw
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <string>
 
 #include "x/ekf/ekf.h"
 #include "x/vio/vio_updater.h"
@@ -46,7 +49,60 @@ static Matrix tail_cov(bool resident, int n_steps, int bsz, int N, bool *old_idx
   return ekf.covarianceAt(-1);
 }
 
+// An updater whose update is "slow": while it runs (preProcess is the first thing Updater::update calls, without the Ekf's
+// mutex) the IMU callback delivers a whole ring of samples.
+struct SlowUpdater : VioUpdater {
+  using VioUpdater::VioUpdater;
+  Ekf *ekf = nullptr;
+  int burst = 0;
+  double t0 = 0;
+  void preProcess(const State &) override {
+    for (int k = 1; k <= burst; ++k) ekf->processImu(t0 + 0.005 * k, 1000u + k, Vector3(0.1, 0, 0), Vector3(0, 0.1, 9.81));
+  }
+};
+
+static int wrap_during_update(int bsz) {
+  const int N = 4;
+  SlowUpdater updater(0, N, 0, 8, 1e-3);
+  Propagator prop(Vector3(0, 0, -9.81), ImuNoise());
+  Propagator::acknowledgeModelProcessNoise();
+  prop.setEngine(updater.engine());
+  Ekf ekf(updater);
+  ekf.set(bsz, State(N, 0), &prop, 0.0025);
+  ekf.setResident(true);
+  State s0(N, 0);
+  const int n = s0.nErrorStates();
+  s0.cov_.resize(n, n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) s0.cov_(i, j) = i == j ? 1e-2 : 0.0;
+  s0.time_ = 1.0;
+  ekf.initializeFromState(s0);
+  for (int k = 0; k <= 2; ++k) ekf.processImu(1.0 + 0.005 * k, (unsigned)k, Vector3(0.1, 0, 0), Vector3(0, 0.1, 9.81));
+  VioMeasurement meas;
+  meas.timestamp = 1.0 + 0.005 * 2;
+  Track t;
+  t.emplace_back(0.01, 0.02); t.emplace_back(0.011, 0.021);
+  meas.msckf_tracks.push_back(t);
+  updater.setWindow(2, {});
+  updater.setMeasurement(meas);
+  updater.ekf = &ekf; updater.burst = bsz + 1; updater.t0 = meas.timestamp;
+  try {
+    (void)ekf.processUpdateMeasurement();
+  } catch (const std::runtime_error &e) {
+    printf("OK threw: %s\n", e.what());
+    // the guard is released with the exception: the IMU stream goes on
+    ekf.processImu(meas.timestamp + 0.005 * (bsz + 2), 5000u, Vector3(0.1, 0, 0), Vector3(0, 0.1, 9.81));
+    return 0;
+  }
+  printf("FAIL no exception: the covariance was propagated under a running update\n");
+  return 1;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]) == "during_update") {
+    try { return wrap_during_update(argc > 2 ? atoi(argv[2]) : 6); }
+    catch (const std::exception &e) { printf("FAIL exception outside the update: %s\n", e.what()); return 1; }
+  }
   const int n_steps = argc > 1 ? atoi(argv[1]) : 23, bsz = argc > 2 ? atoi(argv[2]) : 6, N = 4;
   try {
     bool refused = false;

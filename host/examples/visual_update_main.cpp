@@ -5,6 +5,9 @@
 //        optionally followed by  K2 M_used | L2_k[K2] | obs2[2*sum L2]:  K2 MSCKF-SLAM tracks (features initialised in
 //        postUpdate) and the number of feature slots in use (M is then the capacity)
 //   out: P_post[n*n] | p_array[3N] q_array[4N] f_array[3M] | inlier_msckf[K]
+// Optional arguments: iekf_iter (Updater::update's IEKF loop, updater.cpp:99-110; default 1), resident (1: the covariance
+// stays on the device, Ekf::setResident), core.bin (16 doubles p v q[xyzw] b_w b_a: the core state the update corrects
+// through the cross-covariances).  With any of them the output is followed by the 16 dynamic states of the posterior.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -27,7 +30,9 @@ static std::vector<double> slurp(const char *path) {
 }
 
 int main(int argc, char **argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 2; }
+  if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin [iekf_iter [resident [core.bin]]]\n", argv[0]); return 2; }
+  const int iekf_iter = argc > 3 ? atoi(argv[3]) : 1;
+  const bool resident = argc > 4 && atoi(argv[4]) != 0;
   const std::vector<double> in = slurp(argv[1]);
   size_t at = 0;
   const int N = (int)in[at++], M = (int)in[at++], K = (int)in[at++], n_poses = (int)in[at++];
@@ -35,6 +40,12 @@ int main(int argc, char **argv) {
   const int n = kSizeCoreErr + 6 * N + 3 * M;
   State s(N, M);
   s.setTime(1.0);
+  if (argc > 5) {
+    const std::vector<double> core = slurp(argv[5]);
+    if (core.size() != 16) { fprintf(stderr, "core.bin: 16 doubles expected\n"); return 2; }
+    for (int i = 0; i < 3; ++i) { s.p_(i) = core[i]; s.v_(i) = core[3 + i]; s.b_w_(i) = core[10 + i]; s.b_a_(i) = core[13 + i]; }
+    s.q_ = Quaternion(core[9], core[6], core[7], core[8]);
+  }
   for (int i = 0; i < 4 * N; ++i) s.q_array_(i) = in[at + i];
   at += 4 * N;
   for (int i = 0; i < 3 * N; ++i) s.p_array_(i) = in[at + i];
@@ -75,23 +86,30 @@ int main(int argc, char **argv) {
     anchors.resize(M_used);
   }
 
-  VioUpdater updater(0, N, M, K > 0 ? K : 1, sigma_img);
+  VioUpdater updater(0, N, M, K > 0 ? K : 1, sigma_img, 0.1, 0.4, iekf_iter);
   updater.setWindow(n_poses, anchors);
   updater.setMeasurement(meas);
   Ekf ekf(updater);
   ekf.set(4, State(N, M), nullptr, 0.02);
+  ekf.setResident(resident);
   ekf.initializeFromState(s);
   ekf.processImu(1.0, 0, Vector3(0, 0, 0), Vector3(0, 0, 9.81));   // first IMU message: stand-by -> initialised (ekf.cpp:82-93)
   std::optional<State> post = ekf.processUpdateMeasurement();
   if (!post) { fprintf(stderr, "no update applied\n"); return 3; }
 
+  const Matrix P = resident ? ekf.covarianceAt(-1) : post->cov_;
   FILE *f = fopen(argv[2], "wb");
-  fwrite(post->cov_.data(), sizeof(double), (size_t)n * n, f);
+  fwrite(P.data(), sizeof(double), (size_t)n * n, f);
   fwrite(post->p_array_.data(), sizeof(double), 3 * N, f);
   fwrite(post->q_array_.data(), sizeof(double), 4 * N, f);
   fwrite(post->f_array_.data(), sizeof(double), 3 * M, f);
   for (int k = 0; k < K; ++k) { double v = updater.getMsckfInlierFlags()[k]; fwrite(&v, sizeof(double), 1, f); }
+  if (argc > 3) {
+    double dyn[16];
+    post->getDynamicStates(dyn);
+    fwrite(dyn, sizeof(double), 16, f);
+  }
   fclose(f);
-  printf("ok n=%d K=%d M=%d\n", n, K, M);
+  printf("ok n=%d K=%d M=%d iekf_iter=%d resident=%d\n", n, K, M, iekf_iter, (int)resident);
   return 0;
 }

@@ -54,5 +54,6 @@ class Ekf {
   std::mutex mutex_;
   InitStatus init_status_ = kNotInitialized;
   bool resident_ = false, compose_steps_ = true;
+  bool update_in_flight_ = false;          // resident: updater_.update() is running on the device covariance (guarded by mutex_)
 };
 }  // namespace x

@@ -107,6 +107,14 @@ std::optional<State> Ekf::processImu(double timestamp, unsigned int seq, const V
   // The ring wraps onto the slot whose covariance is resident on the device (buffer_sz - 1 IMU steps without a vision update:
   // before the first frame, during a tracking dropout).  The reference's enqueueInPlace() just overwrites the oldest state;
   // so does this, after moving the device covariance one slot on (it then belongs to the oldest state that survives).
+  // ... unless an update is in flight on that very covariance (updater_.update() runs WITHOUT the mutex, ekf.cpp:186-205, on the
+  // same engine handle and stream): propagating it now would rewrite the prior under the update's feet, from a second thread
+  // inside a handle that is not thread-safe.  It takes buffer_sz - 1 IMU samples during ONE update to get here; the reference
+  // would discard that update (the slot's time no longer matches, ekf.cpp:229-239) with every State still owning a covariance,
+  // which a single resident covariance cannot reproduce -- so this is an error, loudly, not silent corruption.
+  if (resident_ && next == cov_idx_ && update_in_flight_)
+    throw std::runtime_error("Ekf::processImu: the state ring wrapped onto the resident covariance while an update is in flight "
+                             "(state_buffer_sz too small for the update latency)");
   if (resident_ && next == cov_idx_ && !advanceDeviceCovariance((cov_idx_ + 1) % (int)buffer_.size()))
     throw std::runtime_error("Ekf: cannot advance the resident covariance past the slot the ring overwrites");
   State &next_state = buffer_[next];
@@ -205,11 +213,18 @@ std::optional<State> Ekf::processUpdateMeasurement() {                       // 
   if (resident_) {
     std::lock_guard<std::mutex> g(mutex_);
     if (!advanceDeviceCovariance(idx)) return std::nullopt;                  // measurement older than the last update
+    update_in_flight_ = true;
   }
   State update_state = buffer_[idx];        // copy, not under the lock (as the reference); no covariance when resident
-  updater_.update(update_state);            // <- plugin call; the mutex is NOT held
+  try {
+    updater_.update(update_state);          // <- plugin call; the mutex is NOT held
+  } catch (...) {
+    std::lock_guard<std::mutex> g(mutex_);
+    update_in_flight_ = false;
+    throw;
+  }
   bool ok;
-  { std::lock_guard<std::mutex> g(mutex_); ok = repropagateFromStateAtIdx(update_state, idx); }
+  { std::lock_guard<std::mutex> g(mutex_); update_in_flight_ = false; ok = repropagateFromStateAtIdx(update_state, idx); }
   if (ok) return update_state;
   return std::nullopt;
 }
@@ -222,11 +237,18 @@ std::optional<State> Ekf::processOthersMeasurement(double timestamp) {       // 
   if (resident_) {
     std::lock_guard<std::mutex> g(mutex_);
     if (!advanceDeviceCovariance(idx)) return std::nullopt;
+    update_in_flight_ = true;
   }
   State update_state = buffer_[idx];
-  updater_.collaborativeUpdate(update_state);
+  try {
+    updater_.collaborativeUpdate(update_state);
+  } catch (...) {
+    std::lock_guard<std::mutex> g(mutex_);
+    update_in_flight_ = false;
+    throw;
+  }
   bool ok;
-  { std::lock_guard<std::mutex> g(mutex_); ok = repropagateFromStateAtIdx(update_state, idx); }
+  { std::lock_guard<std::mutex> g(mutex_); update_in_flight_ = false; ok = repropagateFromStateAtIdx(update_state, idx); }
   if (ok) return update_state;
   return std::nullopt;
 }

@@ -355,6 +355,13 @@ int xk_run_steps(xk_handle *h, double sigma_img, int steps);
  * xk_last_error() carries the same information as text.  Any pointer may be NULL. */
 int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason);
 
+/* Experiment switches / test hooks of the compression on a live handle.  Their defaults are read from the environment ONCE, at
+ * xk_create (XK_CAQR_RESIDENT, XK_CAQR_RESIDENT_POISON, XK_CAQR_TEST_STALL, XK_CAQR_TALL26, XK_CAQR_REARM) -- the per-update path
+ * calls no getenv.  Names: "caqr_resident" (0: multi-launch schedule everywhere), "caqr_poison" (1: raise the abort word before
+ * every single launch -- it gives up, the host redoes the update), "caqr_test_stall" (1: one workgroup of the single launch
+ * never shows up), "caqr_tall26", "caqr_rearm".  Unknown name: XK_EINVAL.  No counterpart in the reference. */
+int xk_set_option(xk_handle *h, const char *name, int value);
+
 /* Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST_DBG=1), for tools/exp/pipe_trace.py: per panel k,
  * out[16k ..] = one tile workgroup, out[512 + 16k ..] = one first-level workgroup, out[1024 + 16k ..] = one last-level
  * workgroup (phase by phase), out[1536 ..] = start-up and exit.  n_out <= 256 + 64 * 256. */

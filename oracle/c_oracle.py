@@ -228,6 +228,44 @@ def visual_update(sc, library=None):
                 inlier_slam=inls[:M], gamma_slam=gams[:M], did_qr=bool(did.value))
 
 
+def visual_update_iekf(sc, state, iekf_iter, library=None):
+    """The IEKF loop of Updater::update (updater.cpp:99-110) on a scenario + full state dict (p, v, q, b_w, b_a,
+    p_array 3N, q_array 4N xyzw, f_array 3M_cap).  Returns dict(P, correction (= correction_total), state, inlier,
+    gamma, inlier_slam, gamma_slam); flags are the last iteration's."""
+    L = library or lib()
+    K = len(sc["trk_off"]) - 1
+    n = sc["P"].shape[0]
+    M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+    N = sc["n_poses_max"]
+    s = {k: np.array(v, dtype=np.float64, copy=True) for k, v in state.items()}
+    Mcap = (n - 15 - 6 * N) // 3
+    assert s["p_array"].size == 3 * N and s["q_array"].size == 4 * N and s["f_array"].size == 3 * Mcap
+    fa = s["f_array"] if Mcap else np.zeros(1)
+    to, top = _i(sc["trk_off"])
+    ob, obp = _d(sc["obs_xy"])
+    Pf = np.array(sc["P"], dtype=np.float64, order="F", copy=True)
+    ctot = np.zeros(n)
+    inl = np.zeros(max(K, 1), dtype=np.int32)
+    gam = np.zeros(max(K, 1))
+    inls = np.zeros(max(M, 1), dtype=np.int32)
+    gams = np.zeros(max(M, 1))
+    if M:
+        a, ap = _i(sc["slam_anchor_idxs"])
+        ts, tsp = _i(sc["slam_track_sizes"])
+        z, zp = _d(sc["slam_z_last"])
+    else:
+        zp = c_dp()
+        ap = tsp = c_ip()
+    _chk(L.xo_visual_update_iekf(*(s[k].ctypes.data_as(c_dp) for k in ("p", "v", "q", "b_w", "b_a", "p_array", "q_array")),
+                                 fa.ctypes.data_as(c_dp), C.c_int(len(sc["G_p_C"])), top, obp, C.c_int(K), ap, tsp, zp,
+                                 C.c_int(M), Pf.ctypes.data_as(c_dp), C.c_int(n), C.c_int(N), C.c_double(sc["sigma_img"]),
+                                 C.c_int(iekf_iter), ctot.ctypes.data_as(c_dp), inl.ctypes.data_as(c_ip),
+                                 gam.ctypes.data_as(c_dp), inls.ctypes.data_as(c_ip), gams.ctypes.data_as(c_dp)),
+         "xo_visual_update_iekf")
+    return dict(P=np.ascontiguousarray(Pf), correction=ctot, state=s, inlier=inl[:K], gamma=gam[:K],
+                inlier_slam=inls[:M], gamma_slam=gams[:M])
+
+
 def fuse_ci_slam(Pa, Ha, Pb, Hb, w):
     m = Ha.shape[0]
     Paf, Pap = _f(Pa)

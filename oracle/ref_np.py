@@ -392,7 +392,7 @@ def state_correct(state, corr):
 
 def visual_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img, slam=None, msckf_slam_tracks=None):
     """constructUpdate + applyUpdate for MSCKF (+ optional MSCKF-SLAM and SLAM) rows,
-    vio_updater.cpp:267-423 + updater.cpp:99-110 with iekf_iter = 1.
+    vio_updater.cpp:267-423 + updater.cpp:99-110 with iekf_iter = 1 (visual_update_iekf below runs the loop).
 
     slam: None or dict(track_sizes, z_last, feat, anchor_idxs).
     msckf_slam_tracks: None or list of observation arrays (tracks whose feature becomes persistent);
@@ -424,6 +424,49 @@ def visual_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img, slam=None, ms
         Pn, corr = P.copy(), np.zeros(P.shape[0])
     out.update(P=Pn, correction=corr)
     return out
+
+
+def visual_update_iekf(state, tracks, n_poses, P, n_poses_max, sigma_img, iekf_iter, slam=None):
+    """The IEKF loop of Updater::update, updater.cpp:99-110 (single-agent build; MULTI_UAV has no loop, Q9).
+
+    for i in range(iekf_iter):
+        constructUpdate(state, h, res, r)   -- vio_updater.cpp:267-423: window lists re-read from the state as
+                                               corrected so far (state_manager.cpp:539-584), rows built and gated
+                                               against state.getCovariance(), which is the PRIOR until the last pass
+        if h.size() > 0: applyUpdate(state, h, res, r, correction, is_last_iter)   -- updater.cpp:117-141:
+            corr = K (res + H correction_total) - correction_total; covariance only when is_last_iter;
+            state.correct(corr); correction_total += corr
+
+    state: dict p, v, q, b_w, b_a, p_array (3 n_poses_max), q_array (4 n_poses_max, xyzw), f_array (3 M_cap).
+    slam: None or dict(track_sizes, z_last, anchor_idxs) -- the feature states are read from state["f_array"].
+    Returns dict(P, correction (= correction_total, what postUpdate receives), state, inlier (last pass), passes)."""
+    n = P.shape[0]
+    st = {k: np.array(v, dtype=np.float64, copy=True) for k, v in state.items()}
+    ctot = np.zeros(n)
+    Pn = P.copy()
+    passes = []
+    last = None
+    for it in range(iekf_iter):
+        is_last = it == iekf_iter - 1
+        C_q_G = st["q_array"].reshape(-1, 4)[:n_poses].copy()
+        G_p_C = st["p_array"].reshape(-1, 3)[:n_poses].copy()
+        jac, res, cov, info = msckf_update(tracks, C_q_G, G_p_C, P, n_poses_max, sigma_img)
+        sinfo = None
+        if slam is not None:
+            js, rs, cs, sinfo = slam_update(slam["track_sizes"], slam["z_last"], C_q_G, G_p_C, st["f_array"],
+                                            slam["anchor_idxs"], P, n_poses_max, sigma_img)
+            jac = np.vstack([jac, js])
+            res = np.concatenate([res, rs])
+            cov = np.concatenate([cov, cs])
+        h, r, cv, _ = apply_qr_decomposition(jac, res, cov, sigma_img)
+        last = dict(msckf=info, slam=sinfo)
+        if h.size > 0:
+            Pn, corr = apply_update(P, h, r, cv, ctot, is_last)
+            st = state_correct(st, corr)
+            ctot = ctot + corr
+            passes.append(corr)
+    return dict(P=Pn, correction=ctot, state=st, inlier=last["msckf"]["inlier"],
+                inlier_slam=None if last["slam"] is None else last["slam"]["inlier"], passes=passes)
 
 
 # ----------------------------------------------------------------------------

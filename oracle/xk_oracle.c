@@ -887,16 +887,19 @@ int xo_state_correct(double *p, double *v, double *q, double *b_w, double *b_a, 
 }
 
 /* ------------------------------------------------------------------------ */
-/* Full visual update = constructUpdate + applyUpdate (iekf_iter = 1)        */
-/* vio_updater.cpp:267-423, updater.cpp:99-110.  This is what the CPU        */
-/* baseline times.  P is updated in place; correction (n) is written.       */
-/* M may be 0.                                                               */
+/* One pass of the IEKF loop body: constructUpdate + applyUpdate             */
+/* vio_updater.cpp:267-423, updater.cpp:103-109.  Rows are linearised at the */
+/* lists handed in and gated against P as it is (the prior until the last    */
+/* iteration); ctot is correction_total (updater.cpp:126,140: read by the    */
+/* gain step, then += correction); cov_update = is_last_iter.  P is updated  */
+/* in place when cov_update; correction (n) is this pass's. M may be 0.      */
 /* ------------------------------------------------------------------------ */
-int xo_visual_update(const double *C_q_G, const double *G_p_C, int n_poses, const int *trk_off,
+static int visual_update_pass(const double *C_q_G, const double *G_p_C, int n_poses, const int *trk_off,
                      const double *obs_xy, int K, const double *feat, const int *anchor_idxs,
                      const int *track_sizes, const double *z_last, int M, double *P, int n,
-                     int n_poses_max, double sigma_img, double *correction, int *inlier_msckf,
-                     double *gamma_msckf, int *inlier_slam, double *gamma_slam, int *did_qr_out) {
+                     int n_poses_max, double sigma_img, double *ctot, int cov_update, double *correction,
+                     int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam,
+                     int *did_qr_out) {
   int n_obs = trk_off[K] - trk_off[0];
   int rows_m = 2 * n_obs - 3 * K, rows_s = 2 * M, rows = rows_m + rows_s;
   int rc = XO_OK, did = 0;
@@ -911,8 +914,7 @@ int xo_visual_update(const double *C_q_G, const double *G_p_C, int n_poses, cons
   double *r = malloc(sizeof(double) * (size_t)(rows > 0 ? rows : 1));
   double *cv = malloc(sizeof(double) * (size_t)(rows > 0 ? rows : 1));
   double *hq = malloc(sizeof(double) * (size_t)n * n), *rq = malloc(sizeof(double) * n), *cq = malloc(sizeof(double) * n);
-  double *ctot = calloc((size_t)n, sizeof(double));
-  if (!Pc || !jm || !rm || !cm || !js || !rs || !cs || !h || !r || !cv || !hq || !rq || !cq || !ctot) { rc = XO_ENOMEM; goto done; }
+  if (!Pc || !jm || !rm || !cm || !js || !rs || !cs || !h || !r || !cv || !hq || !rq || !cq) { rc = XO_ENOMEM; goto done; }
   memcpy(Pc, P, sizeof(double) * (size_t)n * n);
   for (int i = 0; i < n; ++i) correction[i] = 0.0;
   if (K > 0) {
@@ -937,13 +939,62 @@ int xo_visual_update(const double *C_q_G, const double *G_p_C, int n_poses, cons
   if (rows > 0) {
     rc = xo_qr_compress(h, rows, n, r, sigma_img, hq, rq, cq, &did);
     if (rc != XO_OK) goto done;
-    if (did) rc = xo_apply_update(P, n, hq, n, rq, cq, ctot, 1, correction);
-    else rc = xo_apply_update(P, n, h, rows, r, cv, ctot, 1, correction);
+    if (did) rc = xo_apply_update(P, n, hq, n, rq, cq, ctot, cov_update, correction);
+    else rc = xo_apply_update(P, n, h, rows, r, cv, ctot, cov_update, correction);
   }
   if (did_qr_out) *did_qr_out = did;
 done:
   free(Pc); free(jm); free(rm); free(cm); free(js); free(rs); free(cs); free(h); free(r); free(cv);
-  free(hq); free(rq); free(cq); free(ctot);
+  free(hq); free(rq); free(cq);
+  return rc;
+}
+
+/* Full visual update with iekf_iter = 1 (updater.cpp:99-110).  This is what the CPU baseline times.
+ * P is updated in place; correction (n) is written. */
+int xo_visual_update(const double *C_q_G, const double *G_p_C, int n_poses, const int *trk_off,
+                     const double *obs_xy, int K, const double *feat, const int *anchor_idxs,
+                     const int *track_sizes, const double *z_last, int M, double *P, int n,
+                     int n_poses_max, double sigma_img, double *correction, int *inlier_msckf,
+                     double *gamma_msckf, int *inlier_slam, double *gamma_slam, int *did_qr_out) {
+  double *ctot = calloc((size_t)n, sizeof(double));
+  if (!ctot) return XO_ENOMEM;
+  int rc = visual_update_pass(C_q_G, G_p_C, n_poses, trk_off, obs_xy, K, feat, anchor_idxs, track_sizes, z_last, M,
+                              P, n, n_poses_max, sigma_img, ctot, 1, correction, inlier_msckf, gamma_msckf,
+                              inlier_slam, gamma_slam, did_qr_out);
+  free(ctot);
+  return rc;
+}
+
+/* The IEKF loop of Updater::update, updater.cpp:99-110, on a whole state:
+ *   for i < iekf_iter: constructUpdate(state) -- window lists re-read from the CORRECTED state
+ *   (state_manager.cpp:539-584: the first n_poses slots of p_array / q_array), rows gated against the prior,
+ *   which stays untouched until the last iteration -- then applyUpdate(..., correction_total, is_last_iter):
+ *   corr = K (res + H ctot) - ctot (:126), covariance only when is_last_iter (:130-134), state.correct(corr)
+ *   (:137), ctot += corr (:140).
+ * State in/out: core p[3] v[3] q[4 xyzw] b_w[3] b_a[3]; p_array[3N] q_array[4N] f_array[3M] (N = n_poses_max).
+ * correction_total (n) is what postUpdate receives; inlier flags / gammas are the LAST iteration's.
+ * A pass whose stacked h is empty applies nothing (updater.cpp:106). */
+int xo_visual_update_iekf(double *p, double *v, double *q, double *b_w, double *b_a, double *p_array,
+                          double *q_array, double *f_array, int n_poses, const int *trk_off,
+                          const double *obs_xy, int K, const int *anchor_idxs, const int *track_sizes,
+                          const double *z_last, int M, double *P, int n, int n_poses_max, double sigma_img,
+                          int iekf_iter, double *correction_total, int *inlier_msckf, double *gamma_msckf,
+                          int *inlier_slam, double *gamma_slam) {
+  double *corr = calloc((size_t)n, sizeof(double));
+  if (!corr) return XO_ENOMEM;
+  int rc = XO_OK;
+  for (int i = 0; i < n; ++i) correction_total[i] = 0.0;          /* :82 */
+  for (int it = 0; it < iekf_iter && rc == XO_OK; ++it) {
+    const int last = it == iekf_iter - 1;
+    int n_obs = trk_off[K] - trk_off[0];
+    if (2 * n_obs - 3 * K + 2 * M <= 0) break;                     /* h.size() == 0 */
+    rc = visual_update_pass(q_array, p_array, n_poses, trk_off, obs_xy, K, f_array, anchor_idxs, track_sizes,
+                            z_last, M, P, n, n_poses_max, sigma_img, correction_total, last, corr, inlier_msckf,
+                            gamma_msckf, inlier_slam, gamma_slam, NULL);
+    if (rc != XO_OK) break;
+    xo_state_correct(p, v, q, b_w, b_a, p_array, q_array, f_array, n_poses_max, (n - K_CORE - 6 * n_poses_max) / 3, corr);
+  }
+  free(corr);
   return rc;
 }
 

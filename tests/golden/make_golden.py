@@ -139,6 +139,44 @@ def msckf_slam_case():
     print("msckf_slam_n8", out["msckf_slam"], "new features", np.round(st1["f_array"][9:], 4))
 
 
+def iekf_state(sc, seed):
+    """Full filter state around a scenario's window (core p, v, q, b_w, b_a are seeded values: the visual update
+    corrects them through the cross-covariances)."""
+    rng = np.random.default_rng(seed)
+    N, n = sc["n_poses_max"], sc["P"].shape[0]
+    Mcap = (n - 15 - 6 * N) // 3
+    npz = len(sc["G_p_C"])
+    q = np.zeros((N, 4)); q[:, 3] = 1.0; q[:npz] = sc["C_q_G"]
+    p = np.zeros((N, 3)); p[:npz] = sc["G_p_C"]
+    qc = rng.standard_normal(4); qc /= np.linalg.norm(qc)
+    f = np.zeros(3 * Mcap)
+    if "slam_feat" in sc:
+        f[:len(sc["slam_feat"])] = sc["slam_feat"]
+    return dict(p=rng.standard_normal(3), v=rng.standard_normal(3), q=qc, b_w=0.01 * rng.standard_normal(3),
+                b_a=0.1 * rng.standard_normal(3), p_array=p.ravel(), q_array=q.ravel(), f_array=f)
+
+
+def iekf_case(name, sc, iters=(2, 3)):
+    """Updater::update with iekf_iter > 1 (updater.cpp:99-110): posterior, total correction and corrected state."""
+    st = iekf_state(sc, 1234)
+    slam = None
+    if "slam_feat" in sc:
+        slam = dict(track_sizes=sc["slam_track_sizes"], z_last=sc["slam_z_last"], anchor_idxs=sc["slam_anchor_idxs"])
+    d = {k: sc[k] for k in INPUT_KEYS if k in sc}
+    d.update(n_poses_max=sc["n_poses_max"], sigma_img=sc["sigma_img"], iters=np.array(iters))
+    d.update({"st_" + k: v for k, v in st.items()})
+    for it in iters:
+        out = ref_np.visual_update_iekf(st, synth.tracks_as_list(sc), len(sc["G_p_C"]), sc["P"], sc["n_poses_max"],
+                                        sc["sigma_img"], it, slam=slam)
+        d[f"exp{it}_P"], d[f"exp{it}_correction"], d[f"exp{it}_inlier"] = out["P"], out["correction"], out["inlier"]
+        if out["inlier_slam"] is not None:
+            d[f"exp{it}_inlier_slam"] = out["inlier_slam"]
+        for k, v in out["state"].items():
+            d[f"exp{it}_st_{k}"] = v
+        print(name, "iekf_iter", it, "inliers", int(out["inlier"].sum()), "|corr passes|", [float(np.linalg.norm(c)) for c in out["passes"]])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+
+
 if __name__ == "__main__":
     visual_case("cfg1_n10_k50", synth.make_config(1))
     visual_case("slam_n8_k30_m6", synth.make_scenario(8, 30, 6, seed=77))
@@ -147,6 +185,8 @@ if __name__ == "__main__":
     visual_case("few_rows_n10_k3", synth.make_scenario(10, 3, 0, seed=80))   # rows <= cols+1: no-QR branch
     visual_case("stress_prior_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress", prior_scale=0.01))
     visual_case("all_outliers_n8_k25", synth.make_scenario(8, 25, 0, seed=81, prior_kind="stress"))
+    iekf_case("iekf_n8_k30_m6", synth.make_scenario(8, 30, 6, seed=77))
+    iekf_case("iekf_n10_k50", synth.make_config(1))
     ci_cases()
     manage_cases()
     msckf_slam_case()

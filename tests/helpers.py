@@ -6,7 +6,7 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 VISUAL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith(("ci_", "manage_", "msckf_slam_", "vocab_", "multi_uav_", "propagator_")))
+                      if not os.path.basename(p).startswith(("ci_", "manage_", "msckf_slam_", "vocab_", "multi_uav_", "propagator_", "iekf_")))
 
 # north_star tolerance: <= 1e-6 relative Frobenius on P (BASELINE.json).  The two
 # restatements and the GPU path agree far tighter than that; the tests assert the
@@ -45,3 +45,19 @@ def check_visual(got, exp, tol=TOL_TIGHT):
     assert rp <= tol, f"posterior covariance rel error {rp}"
     assert rc <= max(tol, 1e-8), f"correction rel error {rc}"
     return rp, rc
+
+
+def load_iekf_case(name):
+    """-> (scenario dict, state dict, {iekf_iter: expected dict})"""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    sc = {k: z[k] for k in z.files if not k.startswith(("exp", "st_", "iters"))}
+    sc["n_poses_max"] = int(sc["n_poses_max"])
+    sc["sigma_img"] = float(sc["sigma_img"])
+    st = {k[3:]: z[k] for k in z.files if k.startswith("st_")}
+    exp = {}
+    for it in z["iters"]:
+        pre = f"exp{int(it)}_"
+        e = {k[len(pre):]: z[k] for k in z.files if k.startswith(pre) and not k.startswith(pre + "st_")}
+        e["state"] = {k[len(pre) + 3:]: z[k] for k in z.files if k.startswith(pre + "st_")}
+        exp[int(it)] = e
+    return sc, st, exp

@@ -46,6 +46,33 @@ def test_stage_by_stage_matches_golden(xk, name):
     eng.close()
 
 
+@pytest.mark.parametrize("cfg", [2, 4, 3])
+def test_compression_keeps_the_gram_matrix_to_rounding(xk, oracle_c, cfg):
+    """the reflector scalar chain runs ONE Newton step after v_rsq_f64 / v_rcp_f64 (~4e-15 per reflector, not
+    1 ulp).  What that may cost is orthogonality of the accumulated Q, i.e. R^T R drifting from A^T A over the several hundred
+    reflectors a column sees in three tree levels.  Pinned on the widest systems -- config 2 (331 columns, single launch, wide
+    geometry), the headline (narrow geometry), config 3 (316 columns, 39 launches): ||T^T T - H^T H|| / ||H^T H|| with H the
+    C oracle's stacked rows (its own rounding included) stays at a few 1e-14."""
+    sc = synth.make_config(cfg)
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+    eng = xk.Engine(N, M, K)
+    eng.stage(sc)
+    b = eng.msckf_build(sc["sigma_img"])
+    T, z = eng.qr_compress()
+    eng.close()
+    jac, res, _, info = oracle_c.msckf_update(sc)
+    assert np.array_equal(b["inlier"], info["inlier"])
+    if M:
+        js, rs, _, _ = oracle_c.slam_update(sc["C_q_G"], sc["G_p_C"], sc["slam_feat"], sc["slam_anchor_idxs"], sc["slam_track_sizes"],
+                                            sc["slam_z_last"], sc["P"], N, sc["sigma_img"])
+        jac, res = np.vstack([jac, js]), np.concatenate([res, rs])
+    G = jac.T @ jac
+    eg, ez = rel(T.T @ T, G), rel(T.T @ z, jac.T @ res)
+    print(f"config {cfg}: rel |T^T T - H^T H| = {eg:.2e}, rel |T^T z - H^T r| = {ez:.2e}")
+    assert eg <= 5e-13 and ez <= 5e-12, (eg, ez)
+
+
 CASES_VS_ORACLE = {
     "cfg1": lambda: synth.make_config(1),
     "cfg2_msckf_slam": lambda: synth.make_config(2),

@@ -59,6 +59,15 @@ def test_ring_wraps_onto_the_resident_covariance(xk, n_steps, bsz):
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
 
 
+def test_ring_wrapping_during_an_update_is_an_error_not_silent_corruption(xk):
+    """buffer_sz - 1 IMU samples arrive WHILE an update runs on the resident covariance (the update runs
+    without the Ekf's mutex, ekf.cpp:186-205): the mirror must not propagate the covariance under the update -- it throws."""
+    exe = os.path.join(PKG, "xk_ring_wrap_example")
+    env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, "during_update", "6"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK threw"), r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("resident", [0, 1])
 def test_dense_apply_update_with_a_resident_covariance(xk, resident):
     """Updater::applyUpdate (updater.cpp:117-141) handed a DENSE h by a subclass that bypasses the device-resident construction:

@@ -105,12 +105,10 @@ def test_resident_launch_that_gives_up_is_redone_by_the_multi_launch_schedule(xk
     ref = oracle_c.visual_update(sc)
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     eng = xk.Engine(N, 0, K)
-    os.environ["XK_CAQR_RESIDENT_POISON"] = "1"
-    try:
-        eng.stage(sc)
-        r = eng.visual_update_staged(sc["sigma_img"])
-    finally:
-        os.environ.pop("XK_CAQR_RESIDENT_POISON", None)
+    eng.set_option("caqr_poison", 1)
+    eng.stage(sc)
+    r = eng.visual_update_staged(sc["sigma_img"])
+    eng.set_option("caqr_poison", 0)
     assert np.array_equal(r["inlier"], ref["inlier"])
     assert rel(eng.download_P(), ref["P"]) <= 1e-8
     assert rel(r["correction"], ref["correction"]) <= 1e-6
@@ -139,13 +137,10 @@ def test_fast_path_is_rearmed_after_clean_updates(xk, oracle_c):
         os.environ.pop("XK_CAQR_REARM", None)
     sched = []
     for i in range(8):
-        if i in (0, 6):
-            os.environ["XK_CAQR_RESIDENT_POISON"] = "1"
-        try:
-            eng.stage(sc)
-            r = eng.visual_update_staged(sc["sigma_img"])
-        finally:
-            os.environ.pop("XK_CAQR_RESIDENT_POISON", None)
+        eng.set_option("caqr_poison", int(i in (0, 6)))
+        eng.stage(sc)
+        r = eng.visual_update_staged(sc["sigma_img"])
+        eng.set_option("caqr_poison", 0)
         assert np.array_equal(r["inlier"], ref["inlier"])
         assert rel(eng.download_P(), ref["P"]) <= 1e-8 and rel(r["correction"], ref["correction"]) <= 1e-6, i
         sched.append(eng.caqr_status()["schedule"])

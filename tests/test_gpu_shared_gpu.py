@@ -58,14 +58,12 @@ def test_missing_workgroup_costs_one_bounded_retry(xk, oracle_c):
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     eng = xk.Engine(N, 0, K)
     eng.stage(sc); eng.visual_update_staged(sc["sigma_img"])
-    os.environ["XK_CAQR_TEST_STALL"] = "1"
-    try:
-        eng.stage(sc)
-        t0 = time.perf_counter()
-        r = eng.visual_update_staged(sc["sigma_img"])
-        dt = time.perf_counter() - t0
-    finally:
-        os.environ.pop("XK_CAQR_TEST_STALL", None)
+    eng.set_option("caqr_test_stall", 1)
+    eng.stage(sc)
+    t0 = time.perf_counter()
+    r = eng.visual_update_staged(sc["sigma_img"])
+    dt = time.perf_counter() - t0
+    eng.set_option("caqr_test_stall", 0)
     st = eng.caqr_status()
     assert st["giveups"] == 1 and st["schedule"] == 0 and not st["armed"], st
     assert np.array_equal(r["inlier"], ref["inlier"]) and rel(eng.download_P(), ref["P"]) <= 1e-8

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from helpers import VISUAL_CASES, check_visual, load_case, rel
+from helpers import VISUAL_CASES, check_visual, load_case, load_iekf_case, rel
 from oracle import ref_np
 from x_multi_agent_amd import synth
 
@@ -33,6 +33,24 @@ def test_c_oracle_stage_outputs_match_golden(oracle_c, name):
     assert did == bool(exp["did_qr"])
     assert rel(T.T @ T, exp["TtT"]) <= 1e-10
     assert rel(T.T @ z, exp["Ttz"]) <= 1e-10
+
+
+@pytest.mark.parametrize("name", ["iekf_n8_k30_m6", "iekf_n10_k50"])
+def test_c_oracle_iekf_loop_matches_golden(oracle_c, name):
+    """Updater::update with iekf_iter = 2, 3 (updater.cpp:99-110): the C restatement of the loop against the NumPy one --
+    posterior, correction_total, corrected state; and the loop with one iteration IS the plain update."""
+    sc, st, exp = load_iekf_case(name)
+    for it, e in exp.items():
+        got = oracle_c.visual_update_iekf(sc, st, it)
+        assert np.array_equal(got["inlier"], e["inlier"])
+        assert rel(got["P"], e["P"]) <= 1e-10 and rel(got["correction"], e["correction"]) <= 1e-9
+        for k, v in e["state"].items():
+            assert rel(got["state"][k], v) <= 1e-10, k
+    one = oracle_c.visual_update_iekf(sc, st, 1)
+    plain = oracle_c.visual_update(sc)
+    assert np.array_equal(one["P"], plain["P"]) and np.array_equal(one["correction"], plain["correction"])
+    # later passes re-linearise: the posterior differs from the single-pass one well above the parity bars
+    assert rel(exp[2]["P"], plain["P"]) > 1e-6
 
 
 def test_numpy_restatement_regenerates_golden():

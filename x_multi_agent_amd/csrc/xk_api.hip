@@ -65,6 +65,9 @@ struct xk_handle {
   bool fast_capable;    // decided at xk_create: 256 CUs, one 768-thread workgroup of the single-launch kernels fits a CU
   int fast_giveups, fast_reason;   // launches that gave up so far / why the last one did (xk_caqr_status)
   int clean_classic, rearm_after;  // multi-launch updates since the last give-up / how many of them re-arm the fast path
+  // experiment switches and test hooks of the compression, read from the environment ONCE at xk_create (the per-update path
+  // calls no getenv); xk_set_option changes them on a live handle (tests do)
+  int opt_resident, opt_poison, opt_test_stall, opt_tall26;
   bool xsync_dirty;     // a pipelined launch gave up: its counters are mid-count, clear both sets before the next one
   bool have_rows, have_R;
   double sigma_img;
@@ -251,6 +254,18 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     }
     h->fast_capable = h->persist_ok;
     h->rearm_after = env_int("XK_CAQR_REARM", 64);
+    h->opt_resident = env_int("XK_CAQR_RESIDENT", 1);
+    h->opt_poison = env_int("XK_CAQR_RESIDENT_POISON", 0);
+    h->opt_test_stall = env_int("XK_CAQR_TEST_STALL", 0);
+    h->opt_tall26 = env_int("XK_CAQR_TALL26", 1);
+    if (!h->fast_capable && h->DB == 64 && h->C1 <= XkPipeWide::COLS) {
+      // Say so once, where an operator sees it: every update of this handle takes the multi-launch schedule (~1.6x slower).
+      snprintf(h->err, sizeof(h->err), "single-launch CAQR unavailable on device %d: %s; the multi-launch schedule serves every update",
+               device, h->n_cu != 256 ? "the process does not see 256 compute units (partition mode or CU mask)"
+                                      : "a 768-thread workgroup of the kernel does not fit a compute unit");
+      static const int quiet = env_int("XK_QUIET", 0);
+      if (!quiet) fprintf(stderr, "xk: %s (n_cu = %d)\n", h->err, h->n_cu);
+    }
     if (h->persist_ok) {
       const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * 8 * 16;
       HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
@@ -386,7 +401,8 @@ static void stage_stream_idle(xk_handle *h) { h->stage_since_sync = 0; }
 static char *stage_slot(xk_handle *h, size_t bytes) {
   if (bytes > h->stage_bytes) return nullptr;
   if (++h->stage_since_sync >= XK_STAGE_SLOTS) {
-    hipStreamSynchronize(h->stream);
+    // about to wrap onto a slot whose copy may still be queued: wait; if the wait itself fails the slot is not handed out
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { --h->stage_since_sync; return nullptr; }
     h->stage_since_sync = 1;
   }
   const int s = h->stage_next;
@@ -791,7 +807,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
   a.lead_stride = skip_env ? arity1 : 0;
   int launches = 0;
   // register-resident single launch (xk_caqr_pipe.hip.h): MSCKF tracks only, valid rows <= 184 fat tiles of 128
-  const int resident_env = env_int("XK_CAQR_RESIDENT", 1);   // (read per call: tests switch it inside one process)
+  const int resident_env = h->opt_resident;
   const bool fast_shape = h->K + h->K2 > 0 || h->M > 0;
   if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && fast_shape && ++h->clean_classic > h->rearm_after) {
     h->persist_ok = true;                         // (the sync words of a launch that gave up are cleared below)
@@ -819,6 +835,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       h->rowmap_R = -1;
       if (R <= rows_cap && (size_t)R * sizeof(int) <= h->stage_bytes) {
         int *st = (int *)stage_slot(h, sizeof(int) * (size_t)R);
+        if (!st) return fail(h, XK_EDEVICE, "row map staging");
         int g = 0;
         for (int k = 0; k < h->K; ++k)
           for (int i = 0; i < 2 * key[k] - 3; ++i) st[g++] = k * 64 + i;
@@ -844,15 +861,15 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       h->xsync_phase ^= 1;
       // test hook: raise the abort word before the launch -- every workgroup gives up at its first spin, exactly what an
       // uneven placement or a missing workgroup leads to, and the host has to redo the update with the multi-launch schedule
-      if (env_int("XK_CAQR_RESIDENT_POISON", 0)) {
+      if (h->opt_poison) {
         const unsigned seven = 7u;
         if (hipMemcpyAsync(pa.sync + XP_ABORT * 16, &seven, sizeof(unsigned), hipMemcpyHostToDevice, h->stream) != hipSuccess)
           return fail(h, XK_EDEVICE, "poison");
-        hipStreamSynchronize(h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "poison");
       }
       static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
       pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
-      pa.test_stall = env_int("XK_CAQR_TEST_STALL", 0);
+      pa.test_stall = h->opt_test_stall;
       if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeWide>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       if (mid) hipEventRecord(mid, h->stream);
@@ -863,7 +880,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
     }
   }
   // 128-row slots whose tallest tile has <= 104 rows: 26 rows per lane (two workgroups per CU), see xk_caqr_tile
-  const int tall26_env = env_int("XK_CAQR_TALL26", 1);
+  const int tall26_env = h->opt_tall26;
   auto tile_geom = [&](int c0, int &tsplit, int &tchalf, int &tthreads) {
     const int trail = std::max(0, h->C1 - c0 - 16);
     tsplit = std::max(1, (trail + (tile_cols - 16) - 1) / (tile_cols - 16));
@@ -1274,13 +1291,19 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     // last launch then writes a sequence number next to them, which the host polls: the results are there ~5 us before the
     // runtime's completion signal says so (XK_SPIN_DONE=0: wait for that signal instead).  One wait per update, no copy.
     static const int spin_env = env_int("XK_SPIN_DONE", 1);
-    volatile unsigned long long *done = reinterpret_cast<volatile unsigned long long *>(h->h_out + h->n + 2);
-    if (spin_env) { u.done_flag = const_cast<unsigned long long *>(done); u.done_seq = ++h->done_seq; }
+    unsigned long long *done = reinterpret_cast<unsigned long long *>(h->h_out + h->n + 2);
+    if (spin_env) { u.done_flag = done; u.done_seq = ++h->done_seq; }
     rc = launch_update(h, u);
     if (rc != XK_OK) return rc;
     bool seen = false;
     if (spin_env) {
-      for (long spins = 0; spins < 40000000L && !(seen = (*done == u.done_seq)); ++spins) __builtin_ia32_pause();   // (~1 s, then the signal)
+      // Acquire load: the correction and the status words read below are ordered after the marker.  The marker is the LAST
+      // store of the update -- a system-scope release by the last workgroup of the last kernel, after every workgroup of that
+      // kernel has been counted in (done_cnt) -- and the kernels before it on the stream (whose failure paths write the status
+      // words into the same pinned allocation) had completed, their stores released to system scope at their kernel
+      // boundaries, before that kernel started: whatever they wrote is visible by the time the marker is.
+      for (long spins = 0; spins < 40000000L && !(seen = (__atomic_load_n(done, __ATOMIC_ACQUIRE) == u.done_seq)); ++spins)
+        __builtin_ia32_pause();   // (~1 s, then the signal)
       if (seen) h->done_seen = u.done_seq;
     }
     if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2200,6 +2223,17 @@ extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
 }
 
 // Which schedule compressed the last update, and how the fast path has fared on this handle (include/xk.h).
+extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
+  if (!h || !name) return XK_EINVAL;
+  if (!strcmp(name, "caqr_resident")) h->opt_resident = value;
+  else if (!strcmp(name, "caqr_poison")) h->opt_poison = value;
+  else if (!strcmp(name, "caqr_test_stall")) h->opt_test_stall = value;
+  else if (!strcmp(name, "caqr_tall26")) h->opt_tall26 = value;
+  else if (!strcmp(name, "caqr_rearm")) h->rearm_after = value;
+  else return fail(h, XK_EINVAL, "xk_set_option: unknown option");
+  return XK_OK;
+}
+
 extern "C" int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason) {
   if (!h) return XK_EINVAL;
   if (schedule) *schedule = !h->last_resident ? 0 : (h->last_pipe ? 2 : 1);

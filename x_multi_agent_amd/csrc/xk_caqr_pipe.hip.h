@@ -435,7 +435,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     int pr[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) pr[r] = a.rowmap[min(g0 + r, last)];
-    const double *Ac = a.A + cabs;                          // (cabs < C1P: inside the row whether or not the column exists)
+    const double *Ac = a.A + min(cabs, a.C1P - 1);          // (the wide geometry's column slots run to 383, past C1P = 256 / 320: clamped into the row)
 #pragma unroll
     for (int h0 = 0; h0 < RPL; h0 += 16) {
       int tr[16];

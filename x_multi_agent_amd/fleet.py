@@ -72,19 +72,43 @@ def unpack_payload(buf, N, M):
 
 
 class Exchange:
-    """CI message exchange over torch.distributed (RCCL on GPUs, gloo on CPU)."""
+    """CI message exchange over torch.distributed (RCCL on GPUs, gloo on CPU).
 
-    def __init__(self, dist, world, rank, payload_doubles, device, dtype=None):
+    `world` is the size of the fleet the buffers are laid out for, `real_world` the number of ranks the process group really
+    has.  They differ in a DRY RUN (bench.py --dry-run-ranks N: one process walks rank `rank` of a fleet of N whose other
+    agents' messages are already in the receive buffers): every collective then runs on the real one-rank communicator --
+    this rank's own slot still travels through RCCL (all_gather_into_tensor with one rank) -- and `peer_answer` stands in for
+    the point-to-point partner."""
+
+    def __init__(self, dist, world, rank, payload_doubles, device, dtype=None, real_world=None):
         import torch
         self.dist, self.world, self.rank, self.n = dist, world, rank, payload_doubles
+        self.real_world = world if real_world is None else real_world
+        self.dry = self.real_world != world
         self.torch = torch
         dtype = dtype or torch.float64           # torch.uint8 for the binary VLAD of a request
         self.send = torch.zeros(payload_doubles, dtype=dtype, device=device)
         self.recv = torch.zeros(payload_doubles * max(world, 1), dtype=dtype, device=device)
+        self.peer_answer = None                  # dry run: callable(responder) -> tensor the virtual responder sends back
+
+    def wire(self, t):
+        """Dry run: pass a message through the real (one-rank) communicator and hand back what arrived."""
+        out = self.torch.empty_like(t)
+        if self.dist is not None:
+            self.dist.all_gather_into_tensor(out, t.contiguous())
+        else:
+            out.copy_(t)
+        return out
 
     def all_gather(self):
         """Broadcast mode: every agent receives every agent's payload (config 4)."""
-        if self.world == 1:
+        if self.dry:
+            mine = self.recv.view(self.world, self.n)[self.rank]     # the other slots hold the virtual agents' payloads
+            if self.dist is not None:
+                self.dist.all_gather_into_tensor(mine, self.send)
+            else:
+                mine.copy_(self.send)
+        elif self.world == 1:
             self.recv.copy_(self.send)
         else:
             self.dist.all_gather_into_tensor(self.recv, self.send)
@@ -98,6 +122,10 @@ class Exchange:
         ops = []
         for req, rsp in requests:
             if req == rsp:
+                continue
+            if self.dry:
+                if self.rank == req and self.peer_answer is not None:
+                    got[rsp] = self.wire(self.peer_answer(rsp))
                 continue
             if self.rank == rsp:
                 ops.append(self.dist.P2POp(self.dist.isend, self.send, req))
