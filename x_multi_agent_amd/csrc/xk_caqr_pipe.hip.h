@@ -84,6 +84,9 @@ using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM fe
 #define XK_PIPE_TRI 0               // 1: merge steps skip the reflector in the rows where the strips' triangular structure makes it zero
                                     // (measured: the divergent halves cost more than the LDS traffic they save, QR 0.319 -> 0.332 ms)
 #endif
+#ifndef XK_PIPE_NLW
+#define XK_PIPE_NLW 7               // last-level workgroups that share a panel's trailing columns (of the 8, one per XCD); the eighth
+#endif                              // (XCD 7's) is free for the Kalman role (xk_pipe_kalman)
 #ifndef XK_PIPE_CHUNK
 #define XK_PIPE_CHUNK 0             // 1: tile steps fetch the reflector in two halves (no spills; measured 2 % slower than the spills)
 #endif
@@ -141,6 +144,15 @@ __device__ __forceinline__ int xk_launder(int v) {
 // the merge layout (4 columns x 16 rows) then moves one contiguous 512-byte block per strip; row-major strips cost it sixteen
 // 32-byte pieces per instruction, and the strip loads / stores of a first-level workgroup were 4.6 + 4.5 us of its panel.
 __device__ __forceinline__ size_t xk_blk(int c, int r) { return (size_t)(c >> 2) * 64 + (size_t)r * 4 + (size_t)(c & 3); }
+// How the last level cuts a panel's `trail` trailing columns: chunks of lchalf columns (whole quarter-waves, <= 32), one per
+// workgroup while XK_PIPE_NLW of them cover the range, else (NCL = 2, the first panels of a wide system) two chunks per workgroup --
+// x and x + XK_PIPE_NLW; lsplit = chunks in use.  The first level needs the same numbers for the panel before its own (how many
+// last-level workgroups send pending strips down).
+__device__ __forceinline__ void xk_pipe_lastcut(int trail, int NCL, int &ncl, int &lchalf, int &lsplit) {
+  ncl = (NCL > 1 && trail > 32 * XK_PIPE_NLW) ? NCL : 1;
+  lchalf = max(4, 4 * ((trail + 4 * XK_PIPE_NLW * ncl - 1) / (4 * XK_PIPE_NLW * ncl)));
+  lsplit = max(1, (trail + lchalf - 1) / lchalf);
+}
 // thread 0 polls, everybody learns the verdict
 __device__ __forceinline__ bool xk_pipe_wait(unsigned *word, unsigned target, unsigned *ab, unsigned reason, unsigned *s_ok) {
   if (threadIdx.x == 0) *s_ok = xk_spin_ge(word, target, ab, reason) ? 1u : 0u;
@@ -561,9 +573,9 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     double b[RM], b2[NCM > 1 ? RM : 2];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
-    const int trail_prev = a.C1 - c0, ncl_prev = (NCL > 1 && trail_prev > 256) ? NCL : 1;
-    const int lchalf_prev = max(4, 4 * ((trail_prev + 32 * ncl_prev - 1) / (32 * ncl_prev)));
-    const int lsplit_prev = min(8, max(1, (trail_prev + lchalf_prev - 1) / lchalf_prev));   // last-level workgroups of panel k - 1
+    int ncl_prev, lchalf_prev, lsplit_prev;                 // last-level workgroups of panel k - 1
+    xk_pipe_lastcut(a.C1 - c0, NCL, ncl_prev, lchalf_prev, lsplit_prev);
+    lsplit_prev = min(XK_PIPE_NLW, lsplit_prev);
     if (k >= 1 && xcc != 0) {
       if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
       if (mine) b[0] = xk_ld_sc1(a.X2 + ((size_t)(k - 1) * 8 + xcc) * SS + xk_blk(col, part));
@@ -717,7 +729,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 // level -> first level -> last level -- but with the first level on CUs of its own it is shorter than the tiles' loop:
 // the last rows of the roots leave the first level together with the tiles' strips, a few steps later the pending strips
 // are out, and the next first level does not start before its tiles have published the first rows of their strips.)
-// Wide systems (NCL = 2): a trailing thread holds TWO columns, 8 lchalf apart -- the second set only takes reflectors.
+// Wide systems (NCL = 2): a trailing thread holds TWO columns, XK_PIPE_NLW lchalf apart -- the second set only takes reflectors.
 template <class G>
 __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ubuf, double *sc, unsigned *s_ok) {
   constexpr int NP = 16, RL = 8, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NM = G::NM;
@@ -733,13 +745,12 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     const int c0 = 16 * k, trail = max(0, a.C1 - c0 - 16);
     // trailing columns per chunk: 8 chunks of <= 32 columns when they cover the range (one column per lane), else 8 NCL chunks
     // (workgroup x takes chunks x and x + 8: two columns per lane, slower steps -- only the first panels of a wide system)
-    const int ncl = (NCL > 1 && trail > 256) ? NCL : 1;
-    const int lchalf = max(4, 4 * ((trail + 32 * ncl - 1) / (32 * ncl)));
-    const int lsplit = max(1, (trail + lchalf - 1) / lchalf);               // chunks in use
-    if (lidx >= lsplit) continue;
+    int ncl, lchalf, lsplit;                                                // chunks in use
+    xk_pipe_lastcut(trail, NCL, ncl, lchalf, lsplit);
+    if (lidx >= lsplit || lidx >= XK_PIPE_NLW) continue;
     const int cidx = xk_launder(cidx_), part = xk_launder(part_);
     const int col = panel ? c0 + cidx : c0 + 16 + lidx * lchalf + (cidx - 16);
-    const int col2 = col + 8 * lchalf;
+    const int col2 = col + XK_PIPE_NLW * lchalf;
     const bool mine = col < a.C1 && (panel || cidx - 16 < lchalf);
     const bool mine2 = ncl > 1 && !panel && cidx - 16 < lchalf && col2 < a.C1;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
