@@ -310,6 +310,14 @@ int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned
  * propagation, StateManager::manage, per-feature build, QR compression, Kalman update -- is queued back to back and
  * xk_apply_update's single synchronisation brings the correction, the status and the gate results back. */
 int xk_build_compress_async(xk_handle *h, double sigma_img);
+
+/* xk_build_compress_async with the Kalman update of Updater::applyUpdate(correction_total = 0, cov_update = true)
+ * (updater.cpp:117-141) queued as well: inside the compression launch where the geometry allows it (windows of up to 31 poses
+ * without persistent features: the update is applied block by block as the panels of the QR complete and costs the launch
+ * ~5 us), behind it otherwise.  xk_apply_update(h, NULL, 1, correction) then only waits for the result; any other
+ * correction_total / cov_update there is XK_EINVAL.  For the single-agent order with iekf_iter = 1 (updater.cpp:99-110); NOT for
+ * the MULTI_UAV order, whose applyCI entries replace the covariance between constructUpdate and applyUpdate (:84-97). */
+int xk_build_compress_update_async(xk_handle *h, double sigma_img);
 /* The gate results of the last build (any pointer may be NULL); synchronises the stream if it is still busy. */
 int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam);
 

@@ -68,6 +68,10 @@ struct xk_handle {
   // experiment switches and test hooks of the compression, read from the environment ONCE at xk_create (the per-update path
   // calls no getenv); xk_set_option changes them on a live handle (tests do)
   int opt_resident, opt_poison, opt_test_stall, opt_tall26;
+  int opt_kalman;          // the Kalman update inside the single launch (xk_pipe_kalman) where the geometry allows it
+  bool last_fused;         // the last launch_compress also queued the Kalman update (posterior in d_Pout, correction written)
+  bool fused_pending;      // xk_build_compress_update_async ran: xk_apply_update only has to wait
+  unsigned long long fused_seq;   // ... for this completion marker (0: for the stream)
   bool xsync_dirty;     // a pipelined launch gave up: its counters are mid-count, clear both sets before the next one
   bool have_rows, have_R;
   double sigma_img;
@@ -258,6 +262,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     h->opt_poison = env_int("XK_CAQR_RESIDENT_POISON", 0);
     h->opt_test_stall = env_int("XK_CAQR_TEST_STALL", 0);
     h->opt_tall26 = env_int("XK_CAQR_TALL26", 1);
+    h->opt_kalman = env_int("XK_PIPE_KALMAN", 1);
     if (!h->fast_capable && h->DB == 64 && h->C1 <= XkPipeWide::COLS) {
       // Say so once, where an operator sees it: every update of this handle takes the multi-launch schedule (~1.6x slower).
       snprintf(h->err, sizeof(h->err), "single-launch CAQR unavailable on device %d: %s; the multi-launch schedule serves every update",
@@ -767,13 +772,36 @@ static int launch_build(xk_handle *h, double sigma_img) {
 
 __global__ void xk_mark_done(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+struct UpdateSpec {
+  const double *T;   // c x kdim measurement matrix over state columns [col0, col0+kdim)
+  long str, stc;
+  int c, kdim, col0;
+  const double *z;   // residual (device), stride sz
+  long sz;
+  const double *rdiag;  // device vector (c) or null -> rscalar
+  double rscalar;
+  const double *S;   // externally supplied innovation covariance (device, row stride ss, col stride 1)... or null
+  long ssr, ssc;
+  const double *Pin;  // n x n col-major
+  double *Pout;       // n x n col-major (may equal neither Pin)
+  const double *ct;   // device corr_total or null
+  int cov_update;
+  double *corr;       // where the correction goes: null -> h->d_corr (device); xk_apply_update passes pinned host memory
+  unsigned long long *done_flag;   // optional completion marker (pinned host memory) written by the last launch ...
+  unsigned long long done_seq;     // ... with this value
+};
+
 template <int RPL>
+
 static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_merge<RPL>), dim3(groups, csplit), dim3(16 * (16 + a.chalf)), 0, h->stream, a);
 }
 
 // QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
-static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
+// fuse: (optional) the Kalman update that follows this compression.  If the single launch takes it along (narrow geometry,
+// correction_total = 0, covariance update, no external S), h->last_fused says so and the caller must NOT queue launch_update.
+static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateSpec *fuse = nullptr) {
+  h->last_fused = false;
   if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   const int ntiles = h->K + h->K2 + slam_tiles;
@@ -870,6 +898,14 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr) {
       static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
       pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
       pa.test_stall = h->opt_test_stall;
+      pa.kal = 0; pa.kn = h->n; pa.Pin = nullptr; pa.Pout = nullptr; pa.sigma2 = 0.0; pa.corr = nullptr; pa.done_flag = nullptr; pa.done_seq = 0;
+      if (fuse && narrow && h->opt_kalman && fuse->cov_update && !fuse->ct && !fuse->S && !fuse->rdiag && fuse->T == h->d_R &&
+          h->n <= 206 && h->n_cu == 256) {
+        pa.kal = 1; pa.Pin = fuse->Pin; pa.Pout = fuse->Pout; pa.sigma2 = fuse->rscalar;
+        pa.corr = fuse->corr ? fuse->corr : h->d_corr;
+        pa.done_flag = fuse->done_flag; pa.done_seq = fuse->done_seq;
+        h->last_fused = true;
+      }
       if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeWide>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       if (mid) hipEventRecord(mid, h->stream);
@@ -1006,24 +1042,6 @@ static void gemm(xk_handle *h, const XkGemmArgs &g) {
   hipLaunchKernelGGL(xk_gemm_f64, dim3(tiles), dim3(64 * XK_GEMM_WAVES), 0, h->stream, g);
 }
 
-struct UpdateSpec {
-  const double *T;   // c x kdim measurement matrix over state columns [col0, col0+kdim)
-  long str, stc;
-  int c, kdim, col0;
-  const double *z;   // residual (device), stride sz
-  long sz;
-  const double *rdiag;  // device vector (c) or null -> rscalar
-  double rscalar;
-  const double *S;   // externally supplied innovation covariance (device, row stride ss, col stride 1)... or null
-  long ssr, ssc;
-  const double *Pin;  // n x n col-major
-  double *Pout;       // n x n col-major (may equal neither Pin)
-  const double *ct;   // device corr_total or null
-  int cov_update;
-  double *corr;       // where the correction goes: null -> h->d_corr (device); xk_apply_update passes pinned host memory
-  unsigned long long *done_flag;   // optional completion marker (pinned host memory) written by the last launch ...
-  unsigned long long done_seq;     // ... with this value
-};
 
 // Kalman algebra on the device (updater.cpp:117-141 / :144-161).  ev (optional)
 // = {before, after-gemm-part...} is not used here; stage split is timed by the caller.
@@ -1240,6 +1258,29 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
   return XK_OK;
 }
 
+// The same with the Kalman update of Updater::applyUpdate(correction_total = 0, cov_update = true) queued as well -- inside the
+// compression launch where the geometry allows it (xk_pipe_kalman), behind it otherwise.  xk_apply_update(h, NULL or zeros, 1, ..)
+// then only waits for the result.  For callers that know at construction time that nothing comes between constructUpdate and
+// applyUpdate (single agent, iekf_iter = 1: updater.cpp:99-110 with one pass) -- not the MULTI_UAV order, whose applyCI entries
+// replace the covariance in between (updater.cpp:84-97).
+extern "C" int xk_build_compress_update_async(xk_handle *h, double sigma_img) {
+  if (!h || !(sigma_img > 0.0)) return XK_EINVAL;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = launch_build(h, sigma_img);
+  if (rc != XK_OK) return rc;
+  if ((rc = cache_flags(h)) != XK_OK) return rc;
+  UpdateSpec u = compressed_spec(h, nullptr, 1);
+  u.corr = h->h_out;
+  static const int spin_env = env_int("XK_SPIN_DONE", 1);
+  if (spin_env) { u.done_flag = reinterpret_cast<unsigned long long *>(h->h_out + h->n + 2); u.done_seq = ++h->done_seq; }
+  if ((rc = launch_compress(h, nullptr, &u)) != XK_OK) return rc;
+  if (!h->last_fused && (rc = launch_update(h, u)) != XK_OK) return rc;
+  h->async_pending = true;
+  h->fused_pending = true;
+  h->fused_seq = spin_env ? u.done_seq : 0;
+  return XK_OK;
+}
+
 extern "C" int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
   if (!h) return XK_EINVAL;
   if (!h->flags_cached) return fail(h, XK_EINVAL, "xk_fetch_flags: no build since the inputs were staged");
@@ -1276,8 +1317,11 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     HIPCHK(h, hipMemcpyAsync(h->d_ct, st, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
     dct = h->d_ct;
   }
-  const bool async = h->async_pending;
+  const bool async = h->async_pending, queued = h->fused_pending;
   h->async_pending = false;
+  h->fused_pending = false;
+  if (queued && (dct || !cov_update))
+    return fail(h, XK_EINVAL, "xk_build_compress_update_async queued applyUpdate(correction_total = 0, cov_update = true)");
   int rc = XK_OK;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1) {   // the single-launch CAQR of xk_build_compress_async gave up: rows, compression and update again
@@ -1287,23 +1331,31 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     }
     UpdateSpec u = compressed_spec(h, dct, cov_update);
     u.corr = h->h_out;
+    const bool waiting_only = queued && attempt == 0;      // the update is already on the stream (xk_build_compress_update_async)
     // The kernels write the correction and (on failure) the status words into pinned host memory; the last workgroup of the
     // last launch then writes a sequence number next to them, which the host polls: the results are there ~5 us before the
     // runtime's completion signal says so (XK_SPIN_DONE=0: wait for that signal instead).  One wait per update, no copy.
     static const int spin_env = env_int("XK_SPIN_DONE", 1);
     unsigned long long *done = reinterpret_cast<unsigned long long *>(h->h_out + h->n + 2);
-    if (spin_env) { u.done_flag = done; u.done_seq = ++h->done_seq; }
-    rc = launch_update(h, u);
-    if (rc != XK_OK) return rc;
+    if (waiting_only) u.done_seq = h->fused_seq;
+    else {
+      if (spin_env) { u.done_flag = done; u.done_seq = ++h->done_seq; }
+      rc = launch_update(h, u);
+      if (rc != XK_OK) return rc;
+    }
     bool seen = false;
-    if (spin_env) {
+    if (spin_env && u.done_seq) {
       // Acquire load: the correction and the status words read below are ordered after the marker.  The marker is the LAST
       // store of the update -- a system-scope release by the last workgroup of the last kernel, after every workgroup of that
       // kernel has been counted in (done_cnt) -- and the kernels before it on the stream (whose failure paths write the status
       // words into the same pinned allocation) had completed, their stores released to system scope at their kernel
       // boundaries, before that kernel started: whatever they wrote is visible by the time the marker is.
-      for (long spins = 0; spins < 40000000L && !(seen = (__atomic_load_n(done, __ATOMIC_ACQUIRE) == u.done_seq)); ++spins)
+      // (a single launch that gave up before its Kalman role got going -- placement census -- writes no marker: the status word
+      //  ends the wait)
+      for (long spins = 0; spins < 40000000L && !(seen = (__atomic_load_n(done, __ATOMIC_ACQUIRE) == u.done_seq)); ++spins) {
+        if ((spins & 255) == 255 && __atomic_load_n(&h->d_status[1], __ATOMIC_RELAXED) != 0) break;
         __builtin_ia32_pause();   // (~1 s, then the signal)
+      }
       if (seen) h->done_seen = u.done_seq;
     }
     if (!seen) HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1330,10 +1382,10 @@ extern "C" int xk_visual_update_staged(xk_handle *h, double sigma_img, double *c
   for (int attempt = 0; attempt < 2; ++attempt) {
     rc = launch_build(h, sigma_img);
     if (rc != XK_OK) return rc;
-    rc = launch_compress(h);
-    if (rc != XK_OK) return rc;
     UpdateSpec u = compressed_spec(h, nullptr, 1);
-    rc = launch_update(h, u);
+    rc = launch_compress(h, nullptr, &u);            // (the single launch takes the Kalman update along where it can)
+    if (rc != XK_OK) return rc;
+    if (!h->last_fused) rc = launch_update(h, u);
     if (rc != XK_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(correction, h->d_corr, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
     rc = fetch_flags(h, inlier_msckf, gamma_msckf, inlier_slam, gamma_slam);
@@ -1517,11 +1569,11 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
     int rc = launch_build(h, sigma_img);
     if (rc != XK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-    rc = launch_compress(h, h->ev[2]);
+    UpdateSpec u = compressed_spec(h, nullptr, 1);
+    rc = launch_compress(h, h->ev[2], &u);
     if (rc != XK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
-    UpdateSpec u = compressed_spec(h, nullptr, 1);
-    rc = launch_update(h, u);
+    if (!h->last_fused) rc = launch_update(h, u);     // (fused: the Kalman update is inside stage 2's launch, stage 4 reads 0)
     if (rc != XK_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[4], h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1545,7 +1597,7 @@ extern "C" int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int s
   out->stage_launches[2] = 1;
   out->stage_launches[3] = h->last_resident ? 0 : h->nlevels;   // (the resident schedule IS stage 2's one launch)
   const int nblk = (h->na + XK_CHOL_NB - 1) / XK_CHOL_NB;
-  out->stage_launches[4] = 4 + 3 * nblk;
+  out->stage_launches[4] = h->last_fused ? 0 : 4 + 3 * nblk;
   out->n = h->n; out->c1 = h->C1; out->k_tracks = h->K; out->n_leaf = h->nleaf; out->n_levels = h->nlevels;
   // stacked rows actually folded (inlier rows)
   {
@@ -2159,10 +2211,10 @@ extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
     for (int it = 0; it < steps; ++it) {
       int rc = launch_build(h, sigma_img);
       if (rc != XK_OK) return rc;
-      rc = launch_compress(h);
-      if (rc != XK_OK) return rc;
       UpdateSpec u = compressed_spec(h, nullptr, 1);
-      rc = launch_update(h, u);
+      rc = launch_compress(h, nullptr, &u);
+      if (rc != XK_OK) return rc;
+      if (!h->last_fused) rc = launch_update(h, u);
       if (rc != XK_OK) return rc;
     }
     const int rc = read_status(h, attempt == 0);
@@ -2230,6 +2282,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
   else if (!strcmp(name, "caqr_test_stall")) h->opt_test_stall = value;
   else if (!strcmp(name, "caqr_tall26")) h->opt_tall26 = value;
   else if (!strcmp(name, "caqr_rearm")) h->rearm_after = value;
+  else if (!strcmp(name, "pipe_kalman")) h->opt_kalman = value;
   else return fail(h, XK_EINVAL, "xk_set_option: unknown option");
   return XK_OK;
 }

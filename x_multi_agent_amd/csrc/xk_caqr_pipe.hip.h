@@ -100,7 +100,8 @@ enum {
   // per panel (XCDs run up to a panel apart)
   XP_X1_CNT = 64,                   // [4][MAXP] first-level items whose root rows of phase q are out
   XP_P_CNT = 64 + 4 * XK_CAQR_MAXP,   // [MAXP] last-level workgroups whose pending strips are out
-  XP_WORDS = 64 + 5 * XK_CAQR_MAXP
+  XP_R_CNT = 64 + 5 * XK_CAQR_MAXP,   // [MAXP] last-level workgroups whose rows of R are out (Kalman role only)
+  XP_WORDS = 64 + 6 * XK_CAQR_MAXP
 };
 
 struct XkCaqrPipeArgs {
@@ -118,6 +119,15 @@ struct XkCaqrPipeArgs {
   int *status;
   long long *dbg;
   int test_stall;         // test hook: one tile workgroup leaves at once -- everybody else runs into the bound of their spins
+  // Kalman role (xk_pipe_kalman; narrow geometry): Updater::applyUpdate (updater.cpp:117-141, correction_total = 0, cov_update)
+  // inside this launch.  kal = 0: the compressed [T_H | z] is all the launch leaves behind.
+  int kal, kn;            // on / off, n = error states
+  const double *Pin;      // prior, n x n column-major
+  double *Pout;           // posterior
+  double sigma2;          // sigma_img^2 (vio_updater.cpp:508-509)
+  double *corr;           // [n] correction (device or pinned host memory)
+  unsigned long long *done_flag;   // optional completion marker (pinned host memory) ...
+  unsigned long long done_seq;     // ... and its value
 };
 typedef const XkCaqrPipeArgs __attribute__((address_space(4))) *XkPipeArgsPtr;
 __device__ __forceinline__ XkCaqrPipeArgs xk_pipe_args(XkPipeArgsPtr ap) {
@@ -790,16 +800,19 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
     if constexpr (NPH >= 4) { phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{}); }
     if (!ok) return false;
+    // (with the Kalman role on, the rows of R are a hand-off of their own -- XCD 7's role reads them as they become final:
+    //  written through like every cross-XCD hand-off, counted in per panel)
+    auto rout = [&](size_t at, double v) { if (a.kal) xk_st_sc1(a.Rout + at, v); else a.Rout[at] = v; };
     if (mine) {
       if (panel) {
-        if (lidx == 0 && c0 + part < a.C1) a.Rout[(size_t)(c0 + part) * a.C1P + col] = (part > cidx) ? 0.0 : b[0];
+        if (lidx == 0 && c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col, (part > cidx) ? 0.0 : b[0]);
       } else {
         if (k + 1 < npanels) {
           double *dst = a.X2 + (size_t)k * 8 * SS + xk_blk(col, part);
 #pragma unroll
           for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b[s]);
         }
-        if (c0 + part < a.C1) a.Rout[(size_t)(c0 + part) * a.C1P + col] = b[0];
+        if (c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col, b[0]);
       }
     }
     if (mine2) {
@@ -808,14 +821,399 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
 #pragma unroll
         for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b2[s]);
       }
-      if (c0 + part < a.C1) a.Rout[(size_t)(c0 + part) * a.C1P + col2] = b2[0];
+      if (c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col2, b2[0]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && k + 1 < npanels) xk_pipe_arrive(sync + (XP_P_CNT + k) * 16);
+    if (tid == 0) {
+      if (k + 1 < npanels) xk_pipe_arrive(sync + (XP_P_CNT + k) * 16);
+      if (a.kal) xk_pipe_arrive(sync + (XP_R_CNT + k) * 16);
+    }
     if (stamp) a.dbg[1024 + 16 * k + 8] = wall_clock64();
   }
   if (stamp) a.dbg[1539] = wall_clock64();
+  return true;
+}
+
+
+// ---- role K: the Kalman update (Updater::applyUpdate, src/x/ekf/updater.cpp:117-141, with correction_total = 0 and cov_update)
+// INSIDE the compression launch, on the one workgroup the last level does not need (XCD 7's).  The 16 rows of R that panel k
+// finishes are rows 16 k .. 16 k + 15 of the compressed measurement matrix T -- final from then on -- and the compressed rows
+// all carry the same noise sigma^2 I (vio_updater.cpp:508-509), so the update can be applied BLOCK BY BLOCK as the panels
+// complete, each block against the covariance the blocks before it left:
+//     W_k = T_k P          S_k = W_k T_k^T + sigma^2 I = L L^T          X_k = L^-1 [W_k | T_k d - z_k]
+//     [P | d] -= X_k[:, :n]^T X_k                   (d = the correction so far: d += K_k (z_k - T_k d))
+// which is the batch update (updater.cpp:124-133: S = H P H^T + R, K = P H^T S^-1, P = (I - K H) P, P = (P + P^T) / 2) in
+// exact arithmetic -- the block Cholesky of S in bordered form -- and agrees with it to rounding (1e-14 on P at the headline
+// size).  When the last panel's rows arrive, everything but a rank-4 update has been done beside the QR: the update adds
+// a few microseconds to the launch instead of four launches and 52 us behind it.
+// Layout: [P | d] lives ON THE CU for the whole launch, tiles of 16 x 16 in the MFMA C/D layout (n <= 206: the narrow geometry),
+// column 207 = d.  Waves 1..11 hold tile column w, rows 0..191, in REGISTERS (12 tiles, 96 VGPRs); tile column 0 and tile column 12
+// (state columns 192.., the d column) sit in LDS -- column 0 belongs to wave 0, which also runs the 16-pivot chains (the chain
+// keeps the block and its inverse in 64 registers: next to 96 registers of tiles that does not fit, so the factor wave keeps
+// none), tile (w, 12) is worked on by wave w, (12, 12) by wave 0.  Tile ROW 12 is not kept at all: it is column 12 transposed,
+// and LDS reads a tile either way.  A C/D register is the B operand of A x tile as it is (f64 16x16x4: the tile's row index is the
+// contraction index), so W_k's column tile w needs no data from other waves; column 12's partial tiles are summed in LDS in a
+// fixed order.  P is symmetrised when loaded and stays symmetric bit for bit (tile (I,J) and (J,I) run the same products in the
+// same order), so the posterior is written through the transposed -- coalesced -- addresses.
+#define XK_KAL_NB 12                                        // tile rows / columns of the main block (state indices 0..191)
+#define XK_KAL_DC 207                                       // column of [P | d] that holds d
+#define XK_KAL_TLD 226                                      // row stride of T_k in LDS: = 2 mod 32 doubles, operand gathers hit 32 banks
+#define XK_KAL_LDS (16 * XK_KAL_TLD + 13 * 288 + 13 * 256 + 13 * 256 + 12 * 256 + 256 + 256 + 16 * 17 + 16)
+typedef __attribute__((address_space(3))) double xk_ldsd;   // LDS, said out loud: through a generic pointer every access of the role
+                                                            // became a FLAT load (64-bit addresses, no immediate offsets, vmcnt waits)
+struct XkKalLds {
+  xk_ldsd *Tl, *Wt, *part, *Pc, *P0, *W12s, *dbuf, *Ls, *zcol, *Sp, *Xs;
+  __device__ __forceinline__ explicit XkKalLds(xk_ldsd *base) {
+    Tl = base; Wt = Tl + 16 * XK_KAL_TLD; part = Wt + 13 * 288; Pc = part + 13 * 256; P0 = Pc + 13 * 256; W12s = P0 + 12 * 256;
+    dbuf = W12s + 256; Ls = dbuf + 256; zcol = Ls + 16 * 17;
+    Sp = Wt;      // a wave's partial S tile lands where it turned its W tile (stride 288)
+    Xs = part;    // the partial tiles are dead when the X tiles are written
+  }
+};
+// the pivot chain of xk_chol16.hip.h on LDS-typed operands.  NPIV = 4: a block whose rows past the fourth are padding (S there is
+// sigma^2 I, the rows of W are zero): four pivots do, the other rows of the inverse stay the identity's and multiply zeros
+template <int NPIV>
+__device__ __forceinline__ bool xk_kal_chol16(const xk_ldsd *blk, xk_ldsd *linv, int lane) {
+  const int tt = lane & 15;
+  double v[16], w[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { v[q] = blk[16 * tt + q]; w[q] = (tt == q) ? 1.0 : 0.0; }
+  bool bad = false;
+  xk_chol16_step<0>(v, w, bad); xk_chol16_step<1>(v, w, bad); xk_chol16_step<2>(v, w, bad); xk_chol16_step<3>(v, w, bad);
+  if constexpr (NPIV > 4) {
+    xk_chol16_step<4>(v, w, bad); xk_chol16_step<5>(v, w, bad); xk_chol16_step<6>(v, w, bad); xk_chol16_step<7>(v, w, bad);
+    xk_chol16_step<8>(v, w, bad); xk_chol16_step<9>(v, w, bad); xk_chol16_step<10>(v, w, bad); xk_chol16_step<11>(v, w, bad);
+    xk_chol16_step<12>(v, w, bad); xk_chol16_step<13>(v, w, bad); xk_chol16_step<14>(v, w, bad); xk_chol16_step<15>(v, w, bad);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) linv[q * 17 + tt] = w[q];
+  }
+  return bad;
+}
+// [P | d] -= X^T X on one wave's tiles, NQ k-steps (rows of X past 4 NQ are zero)
+template <bool REG, int NQ>
+__device__ __forceinline__ void xk_kal_downdate(const XkKalLds &m, xk_d4 (&Pt)[XK_KAL_NB], const xk_d4 &X, int wave, int lane) {
+  constexpr int NB = XK_KAL_NB;
+  const xk_ldsd *xl = m.Xs + lane;
+  xk_ldsd *p0 = m.P0 + lane;
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    double xc[NQ];
+    xk_d4 c;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xc[q] = xl[I * 256 + 64 * q];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = REG ? Pt[I][r] : p0[I * 256 + 64 * r];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-xc[q], X[q], c, 0, 0, 0);
+    if (REG) Pt[I] = c;
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p0[I * 256 + 64 * r] = c[r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  xk_d4 c12, ccc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { c12[r] = m.Pc[wave * 256 + 64 * r + lane]; ccc[r] = REG ? 0.0 : m.Pc[12 * 256 + 64 * r + lane]; }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    c12 = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[q], xl[12 * 256 + 64 * q], c12, 0, 0, 0);
+    if (!REG) ccc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xl[12 * 256 + 64 * q], xl[12 * 256 + 64 * q], ccc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m.Pc[wave * 256 + 64 * r + lane] = c12[r]; if (!REG) m.Pc[12 * 256 + 64 * r + lane] = ccc[r]; }
+}
+// One block of the update for one wave.  REG: tile column `wave` in registers (Pt), else in LDS (m.P0: wave 0, the factor wave).
+template <bool REG>
+__device__ __forceinline__ void xk_kal_block(const XkKalLds &m, xk_d4 (&Pt)[XK_KAL_NB], int k, int nrows, int n, double sigma2, int wave, int lane,
+                                             bool &bad, long long *stp) {
+#define XK_KSTAMP(i) do { if (stp && lane == 0) stp[i] = wall_clock64(); } while (0)
+  constexpr int NB = XK_KAL_NB, TLD = XK_KAL_TLD;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nq = (nrows + 3) >> 2;                          // k-steps that hold rows of this block
+  const xk_ldsd *ta = m.Tl + li * TLD + lk;                 // A operand: T_k[m = li][state 4 q + lk + ..]
+  const xk_ldsd *p0 = m.P0 + lane;
+  // ---- W_k: my column tile (operands of the NEXT tile in flight behind this tile's MFMAs; the scheduling barriers keep the
+  // scheduler from hoisting every operand load above the first MFMA, a hundred registers next to the tiles')
+  // T_k is zero in the state columns of tile rows I < k: one jump into a straight line of tiles k .. 11 (a branch per tile made
+  // every tile a basic block of its own and the accumulators a chain of phis)
+  xk_d4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+#define XK_KAL_WTILE(I)                                                                                                   \
+  {                                                                                                                       \
+    double ac[4], bc[4];                                                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) { ac[q] = ta[16 * (I) + 4 * q]; bc[q] = REG ? Pt[I][q] : p0[(I) * 256 + 64 * q]; } \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                       \
+      if ((I) & 1) w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], bc[q], w1, 0, 0, 0);                                  \
+      else w0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], bc[q], w0, 0, 0, 0);                                          \
+    }                                                                                                                     \
+  }
+  switch (k) {
+    case 0: XK_KAL_WTILE(0) [[fallthrough]];
+    case 1: XK_KAL_WTILE(1) [[fallthrough]];
+    case 2: XK_KAL_WTILE(2) [[fallthrough]];
+    case 3: XK_KAL_WTILE(3) [[fallthrough]];
+    case 4: XK_KAL_WTILE(4) [[fallthrough]];
+    case 5: XK_KAL_WTILE(5) [[fallthrough]];
+    case 6: XK_KAL_WTILE(6) [[fallthrough]];
+    case 7: XK_KAL_WTILE(7) [[fallthrough]];
+    case 8: XK_KAL_WTILE(8) [[fallthrough]];
+    case 9: XK_KAL_WTILE(9) [[fallthrough]];
+    case 10: XK_KAL_WTILE(10) [[fallthrough]];
+    default: XK_KAL_WTILE(11)
+  }
+#undef XK_KAL_WTILE
+  if (n > 192) {                                            // state rows 192..n-1: tile (12, w) = tile (w, 12)^T, read transposed from LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[192 + 4 * q], m.Pc[wave * 256 + 16 * li + 4 * q + lk], w1, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  XK_KSTAMP(2);
+  xk_d4 W = w0 + w1;
+  {   // my share of tile column 12: tile (w, 12) takes T's block w; wave 0 also (12, 12)
+    xk_d4 x = {0, 0, 0, 0};
+    if (wave >= k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[16 * wave + 4 * q], m.Pc[wave * 256 + 64 * q + lane], x, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.part[wave * 256 + 64 * r + lane] = x[r];
+    if (!REG) {
+      xk_d4 y = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[192 + 4 * q], m.Pc[12 * 256 + 64 * q + lane], y, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m.part[12 * 256 + 64 * r + lane] = y[r];
+    }
+  }
+  // ---- my share of S_k = W_k T_k^T: the contraction runs over the COLUMNS of my W tile -- one trip through LDS turns it
+  auto spart = [&](const xk_d4 &Wc, int J) {
+    xk_ldsd *wt = m.Wt + J * 288;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wt[(lk + 4 * r) * 18 + li] = Wc[r];
+    xk_d4 sacc = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[li * 18 + 4 * q + lk], ta[16 * J + 4 * q], sacc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.Sp[J * 288 + 64 * r + lane] = sacc[r];
+  };
+  __builtin_amdgcn_sched_barrier(0);
+  spart(W, wave);
+  __builtin_amdgcn_sched_barrier(0);
+  XK_KSTAMP(3);
+  __syncthreads();                                          // (1) the partial tiles of column 12
+  XK_KSTAMP(4);
+  if (REG && wave == 11) {
+    xk_d4 W12 = {0, 0, 0, 0};
+    for (int w = k; w < 13; ++w)                            // (tile rows < k meet zero columns of T_k: their partial tiles are zero)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W12[r] += m.part[w * 256 + 64 * r + lane];
+    if (li == XK_KAL_DC - 192) {                            // the d column: T_k d - z_k
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W12[r] -= m.zcol[lk + 4 * r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.W12s[64 * r + lane] = W12[r];
+    spart(W12, 12);
+  }
+  __syncthreads();                                          // (2) the partial tiles of S_k
+  XK_KSTAMP(5);
+  if (!REG) {
+    xk_d4 S = {0, 0, 0, 0};
+    for (int J = k; J < 13; ++J)                            // (likewise: T_k is zero in the state columns of tiles < k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[r] += m.Sp[J * 288 + 64 * r + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.dbuf[16 * (lk + 4 * r) + li] = S[r] + ((lk + 4 * r == li) ? sigma2 : 0.0);
+    if (nrows <= 4 ? xk_kal_chol16<4>(m.dbuf, m.Ls, lane) : xk_kal_chol16<16>(m.dbuf, m.Ls, lane)) bad = true;
+  }
+  XK_KSTAMP(6);
+  __syncthreads();                                          // (3) L^-1
+  XK_KSTAMP(7);
+  double lv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lv[q] = m.Ls[li * 17 + 4 * q + lk];
+  xk_d4 X = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) X = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[q], W[q], X, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m.Xs[wave * 256 + 64 * r + lane] = X[r];
+  if (REG && wave == 11) {
+    xk_d4 X12 = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X12 = __builtin_amdgcn_mfma_f64_16x16x4f64(lv[q], m.W12s[64 * q + lane], X12, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.Xs[12 * 256 + 64 * r + lane] = X12[r];
+  }
+  __syncthreads();                                          // (4) the X tiles
+  XK_KSTAMP(8);
+  // ---- [P | d] -= X^T X (rows of X past nrows are zero: their k-steps are skipped)
+  if (nq == 1) xk_kal_downdate<REG, 1>(m, Pt, X, wave, lane);   // (the headline's last block: 4 rows)
+  else xk_kal_downdate<REG, 4>(m, Pt, X, wave, lane);
+  XK_KSTAMP(9);
+  __syncthreads();                                          // (5) Tl, Xs are rewritten by the next block
+  XK_KSTAMP(10);
+#undef XK_KSTAMP
+}
+
+template <class G>
+__device__ __noinline__ bool xk_pipe_kalman(XkPipeArgsPtr ap, xk_ldsd *kb, unsigned *s_ok) {
+  constexpr int NB = XK_KAL_NB, TLD = XK_KAL_TLD, NCL = G::NCL;
+  const XkCaqrPipeArgs a = xk_pipe_args(ap);
+  unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
+  const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = a.kn, na = a.C1 - 1, npanels = (a.C1 + 15) / 16;
+  auto ldsym = [&](int row, int col) {                     // the prior, symmetrised
+    return (row < n && col < n) ? 0.5 * (a.Pin[(size_t)row + (size_t)col * n] + a.Pin[(size_t)col + (size_t)row * n]) : 0.0;
+  };
+  // what a block starts with: the rows of R the last level has just finished, by STATE index -- Tl[m][15 + c] = R[c0 + m][c],
+  // c0 <= c < na (zero elsewhere), z_k[m] = R[c0 + m][na]; false: the launch is giving up
+  auto fetch = [&](const XkKalLds &m, int k, int &nrows) -> bool {
+    const int c0 = 16 * k;
+    nrows = min(16, na - c0);
+    int ncl, lchalf, lsplit;
+    xk_pipe_lastcut(max(0, a.C1 - c0 - 16), NCL, ncl, lchalf, lsplit);
+    if (!xk_pipe_wait(sync + (XP_R_CNT + k) * 16, (unsigned)min(XK_PIPE_NLW, lsplit), ab, 8u, s_ok)) return false;
+    double tv[5];                                           // (every load first, then the stores: one round trip to the other XCDs' rows)
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int idx = tid + u * XK_PIPE_THREADS, mr = idx / 208, st = idx - 208 * mr, c = st - 15;
+      tv[u] = (idx < 16 * 208 && mr < nrows && c >= c0 && c < na) ? xk_ld_sc1(a.Rout + (size_t)(c0 + mr) * a.C1P + c) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int idx = tid + u * XK_PIPE_THREADS, mr = idx / 208, st = idx - 208 * mr;
+      if (idx < 16 * 208) m.Tl[mr * TLD + st] = tv[u];
+    }
+    if (tid < 16) m.zcol[tid] = (tid < nrows) ? xk_ld_sc1(a.Rout + (size_t)(c0 + tid) * a.C1P + na) : 0.0;
+    __syncthreads();
+    return true;
+  };
+  // The end of the role.  The correction -- column 207 of tile column 12, sixteen entries per wave -- is gathered in LDS; the
+  // factor wave sends it to the host with system-scope stores and, once they are complete (~3 us: they cross PCIe), the marker:
+  // the host has what it waits for while the other waves' tiles of the posterior are on their way out (the next kernel sees
+  // those through the kernel boundary).
+  auto publish = [&](const XkKalLds &m, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    if (li == XK_KAL_DC - 192) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        m.dbuf[16 * wave + lk + 4 * r] = m.Pc[wave * 256 + 64 * r + lane];
+        if (wave == 0) m.dbuf[192 + lk + 4 * r] = m.Pc[12 * 256 + 64 * r + lane];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      for (int i = lane; i < n; i += 64) xk_st_sys(a.corr + i, m.dbuf[i]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0 && a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
+  // P is symmetric bit for bit: element (row, col) goes to the address of (col, row), sixteen lanes to a 128-byte line; the
+  // lane's part of the address is formed once, the tile's part is uniform
+  auto store_tile = [&](int I, int J, int lane, const xk_d4 &v, bool both) {
+    const int li = lane & 15, lk = lane >> 4, col = 16 * J + li;
+    if (col >= n) return;
+    double *pb = a.Pout + (size_t)col + (size_t)lk * n;
+    double *pm = a.Pout + (size_t)lk + (size_t)col * n;     // the mirror image (tile column 12 stands for tile row 12 as well)
+    const bool whole = 16 * I + 16 <= n;                    // (uniform)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (whole || 16 * I + lk + 4 * r < n) {
+        pb[(size_t)((16 * I + 4 * r) * n)] = v[r];
+        if (both) pm[16 * I + 4 * r] = v[r];
+      }
+    }
+  };
+  const int nblocks = min(npanels, (na + 15) / 16);         // (a last panel that holds the residual column only brings no rows)
+  bool bad = false;
+  if (wave == 0) {
+    // ---- the factor wave: tile column 0 and tile (12, 12) in LDS, the pivot chains in registers
+    {
+      const XkKalLds m(kb);
+      const int lane = lane_, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m.P0[I * 256 + 64 * r + lane] = ldsym(16 * I + lk + 4 * r, li);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        m.Pc[64 * r + lane] = ldsym(lk + 4 * r, 192 + li);
+        m.Pc[12 * 256 + 64 * r + lane] = ldsym(192 + lk + 4 * r, 192 + li);
+      }
+    }
+    xk_d4 none[NB];
+    for (int k = 0; k < nblocks; ++k) {
+      const XkKalLds m(xk_opaque(kb));
+      int nrows;
+      long long *stp = a.dbg ? a.dbg + 2048 + 16 * k : nullptr;
+      if (stp && lane_ == 0) stp[0] = wall_clock64();
+      if (!fetch(m, k, nrows)) return false;
+      if (stp && lane_ == 0) stp[1] = wall_clock64();
+      xk_kal_block<false>(m, none, k, nrows, n, a.sigma2, 0, xk_launder(lane_), bad, stp);
+    }
+    const XkKalLds m(kb);
+    const int lane = lane_;
+    if (bad && lane == 0) __hip_atomic_store(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // XK_ESINGULAR
+    if (a.dbg && lane == 0) a.dbg[2048 + 16 * 31 + 1] = wall_clock64();
+    publish(m, lane);
+    if (a.dbg && lane == 0) a.dbg[2048 + 16 * 31 + 2] = wall_clock64();
+    {   // (tile column 0 is in LDS: waves 1..11 store it after their own tiles, this wave has the host to talk to)
+      xk_d4 cc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cc[r] = m.Pc[12 * 256 + 64 * r + lane];
+      store_tile(12, 12, lane, cc, false);
+    }
+    if (a.dbg && lane == 0) a.dbg[2048 + 16 * 31] = wall_clock64();
+    return true;
+  }
+  // ---- waves 1..11: tile column `wave` in registers
+  xk_d4 Pt[NB];
+  {
+    const XkKalLds m(kb);
+    const int lane = lane_, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[I][r] = ldsym(16 * I + lk + 4 * r, 16 * wave + li);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.Pc[wave * 256 + 64 * r + lane] = ldsym(16 * wave + lk + 4 * r, 192 + li);
+  }
+  for (int k = 0; k < nblocks; ++k) {
+    const XkKalLds m(xk_opaque(kb));
+    int nrows;
+    if (!fetch(m, k, nrows)) return false;
+    long long *stp = (a.dbg && wave == 5) ? a.dbg + 2560 + 16 * k : nullptr;
+    xk_kal_block<true>(m, Pt, k, nrows, n, a.sigma2, wave, xk_launder(lane_), bad, stp);
+  }
+  const XkKalLds m(kb);
+  const int lane = lane_;
+  publish(m, lane);
+#pragma unroll
+  for (int I = 0; I < NB; ++I) {
+    store_tile(I, wave, lane, Pt[I], false);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    xk_d4 c, c0t, p0a, p0b;                                  // my tile of column 12; and of the factor wave's column 0: tile wave (+ tile 0 / tile 12's
+    const int e = (wave == 1) ? 0 : 0;                      //  stand-in (0, 12) for waves 1 / 11)
+    (void)e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      c[r] = m.Pc[wave * 256 + 64 * r + lane];
+      p0a[r] = m.P0[wave * 256 + 64 * r + lane];
+      p0b[r] = m.P0[64 * r + lane];
+      c0t[r] = m.Pc[64 * r + lane];
+    }
+    store_tile(wave, 12, lane, c, true);
+    store_tile(wave, 0, lane, p0a, false);
+    if (wave == 1) store_tile(0, 0, lane, p0b, false);
+    if (wave == 11) store_tile(0, 12, lane, c0t, true);
+  }
   return true;
 }
 
@@ -829,6 +1227,8 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __shared__ unsigned s_slot, s_ok;
   // landing area of the first level's load-to-LDS prefetch: per wave (4 columns) 24 strips x 4 rows x 4 columns
   __shared__ __attribute__((aligned(16))) double pfbuf[XK_PIPE_PF ? (XK_PIPE_THREADS / 64) * 24 * 16 : 2];
+  constexpr bool KAL = G::COLS <= 192;                     // the Kalman role keeps [P | d] in registers: n <= 206
+  __shared__ __attribute__((aligned(16))) double kbuf[KAL ? XK_KAL_LDS : 2];
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const XkPipeArgsPtr ap = (XkPipeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned xcc = xk_xcc_id();
@@ -854,7 +1254,26 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   else {
     // nothing to do until the first roots arrive: leave the other set of sync words zeroed for the next launch
     for (int i = (int)xcc * XK_PIPE_THREADS + threadIdx.x; i < XP_WORDS * 16; i += 8 * XK_PIPE_THREADS) a.sync_next[i] = 0u;
-    ok = xk_pipe_last<G>(ap, (int)xcc, ubuf, sc, &s_ok);
+    if ((int)xcc < XK_PIPE_NLW) ok = xk_pipe_last<G>(ap, (int)xcc, ubuf, sc, &s_ok);
+    else {
+      ok = true;
+      if constexpr (KAL) {
+        if (a.kal) {
+          ok = xk_pipe_kalman<G>(ap, (xk_ldsd *)kbuf, &s_ok);
+          // A role that gave up has not told the host anything yet (a finished one wrote the correction, then the marker, from
+          // inside -- system-scope stores, complete before the marker; NOT a release fence, which at system scope is a write-back of
+          // this XCD's whole L2 on the launch's tail, and nothing but those words is for the host)
+          if (!ok) {
+            if (threadIdx.x == 0) __hip_atomic_store(a.status + 1, (int)__hip_atomic_load(ab, XK_RLX_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0 && a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          if (a.dbg && threadIdx.x == 0) a.dbg[2048 + 16 * 31 + 3] = wall_clock64();
+          return;
+        }
+      }
+    }
   }
   if (!ok && threadIdx.x == 0) a.status[1] = (int)__hip_atomic_load(ab, XK_RLX_AGENT);
 }

@@ -38,6 +38,10 @@ __device__ __forceinline__ void xk_inv_l1() { asm volatile("buffer_inv sc1" ::: 
 __device__ __forceinline__ void xk_st_sc1(double *p, double v) {
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), XK_RLX_AGENT);
 }
+// a store the HOST is meant to see (pinned, fine-grained memory): system scope, written through
+__device__ __forceinline__ void xk_st_sys(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ unsigned xk_xcc_id() {
   unsigned x;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));

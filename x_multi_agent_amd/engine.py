@@ -29,7 +29,7 @@ SYMBOLS = [
     "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
     "xk_stage_msckf_slam", "xk_msckf_slam_results", "xk_init_msckf_slam_features", "xk_init_standard_slam_features",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
-    "xk_apply_ci_resident", "xk_snapshot_P", "xk_debug_persist_stamps", "xk_caqr_status", "xk_set_option", "xk_build_compress_async", "xk_fetch_flags",
+    "xk_apply_ci_resident", "xk_snapshot_P", "xk_debug_persist_stamps", "xk_caqr_status", "xk_set_option", "xk_build_compress_async", "xk_build_compress_update_async", "xk_fetch_flags",
     "xk_pr_create", "xk_pr_destroy", "xk_pr_vlad_bytes", "xk_pr_size", "xk_pr_compute_vlad", "xk_pr_add_keyframe",
     "xk_pr_find_candidate", "xk_pr_keyframe", "xk_pr_copy_keyframe", "xk_pr_knn_match",
 ]
