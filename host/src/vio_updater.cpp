@@ -122,7 +122,14 @@ void VioUpdater::buildAndCompress(const State &state, const TrackList &tr, bool 
     // (and behind the covariance propagation / manage() of this frame); [T_H | z] stays in HBM, xk_apply_update consumes
     // it there and its synchronisation also brings the gate flags (fetched in postUpdate).  h only has to be non-empty
     // for Updater::update.
-    check(xk_, xk_build_compress_async(xk_, sigma_img_), "xk_build_compress_async");
+    // Single agent, one pass (updater.cpp:99-110 with iekf_iter = 1): nothing comes between constructUpdate and
+    // applyUpdate(correction_total = 0, cov_update = true), so the Kalman update is queued with the rows -- inside the compression
+    // launch where the geometry allows it.  The MULTI_UAV order (applyCI entries rewrite the covariance in between, :84-97) and
+    // IEKF passes (correction_total, cov_update known only at applyUpdate) keep the two-call form.
+    if (!multi_uav_ && (iekf_iter_ == 1 || !with_slam))   // (the short-track update, with_slam = false, is always one pass: updater.cpp:50-74)
+      check(xk_, xk_build_compress_update_async(xk_, sigma_img_), "xk_build_compress_update_async");
+    else
+      check(xk_, xk_build_compress_async(xk_, sigma_img_), "xk_build_compress_async");
     flags_pending_ = true;
     h = Matrix::Zero(1, 1);
     res = Matrix::Zero(1, 1);
