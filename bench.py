@@ -42,7 +42,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
-ROUND_TAG = "r03"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
+ROUND_TAG = "r04"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
 CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
 CI_TRACKS = 2             # shared MSCKF tracks fused per CI round
 PR_SCORE_THR = 0.6        # pr_score_thr (vio.cpp:670): minimum VLAD similarity for a keyframe to be sent back
@@ -60,6 +60,21 @@ def alg_flops(N, K, M, rows=None):
     qr = 2.0 * r * c * c - (2.0 / 3.0) * c ** 3
     upd = 7.0 * n ** 3
     return feat, qr, upd
+
+
+def as_written_flops(N, K, M):
+    """What the reference does AS WRITTEN (and oracle/xk_oracle.c restates) per update, SURVEY 8(a): per track the dense
+    A^T jac ((2L-3) x 2L x n), jac0 P jac0^T and the inverse of S; full Householder QR of the r x (n+1) stack, zero rows of
+    rejected tracks included; S, its inverse, the gain and (I - K H) P as dense n^3 products."""
+    L = N
+    d = 2 * L - 3
+    n = 15 + 6 * N + 3 * M
+    r = K * d + 2 * M
+    feat = K * (2.0 * d * 2 * L * n + 2.0 * d * n * n + 2.0 * d * d * n + 2.0 * d ** 3)
+    slam = M * (2.0 * 2 * n * n + 2.0 * 2 * 2 * n)
+    qr = 2.0 * r * (n + 1) ** 2 - (2.0 / 3.0) * (n + 1) ** 3 if r > n + 1 else 0.0
+    upd = 14.0 * n ** 3
+    return feat + slam + qr + upd
 
 
 def csrc_sha16():
@@ -152,12 +167,36 @@ def cpu_baseline(sc, budget_s=20.0):
     med = statistics.median(times)
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     M = len(sc.get("slam_anchor_idxs", []))
-    as_written_gf = 4.8e9 if (N, K, M) == (30, 400, 0) else None
+    as_written_gf = as_written_flops(N, K, M)
     out = {"value": 1.0 / med, "unit": "updates/s", "cores": 1, "kind": "port",
            "sample": f"median of {len(times)} updates after 3 warm-ups, same inputs as the GPU run, "
                      f"oracle/xk_oracle.c {flags}, pinned={pinned}",
            "ms_per_update": 1e3 * med, "host_cpus": os.cpu_count(),
-           "approx_gflops": (as_written_gf / med / 1e9) if as_written_gf else None}
+           "as_written_flops_per_update": as_written_gf,
+           "approx_gflops": as_written_gf / med / 1e9}
+    # footnote: the reference's dense rows x rows noise matrix (vio_updater.cpp:417), which the baseline keeps as a
+    # diagonal vector -- what allocating and filling it costs on this host, where it fits in memory
+    try:
+        import ctypes as C
+        rows = K * (2 * N - 3) + 2 * M
+        nbytes = 8 * rows * rows
+        avail = None
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = 1024 * int(ln.split()[1])
+        L.xo_dense_noise_footnote.restype = C.c_double
+        if avail is not None and avail > 3 * nbytes:
+            t0 = time.perf_counter()
+            tr = L.xo_dense_noise_footnote(C.c_int(rows), None)
+            dtn = time.perf_counter() - t0
+            out["as_written_dense_R"] = {"rows": rows, "bytes": nbytes, "ms": 1e3 * dtn, "ok": tr > 0,
+                                         "updates_per_s_with_it": 1.0 / (med + dtn),
+                                         "note": "r = r_diag.asDiagonal() as a dense Matrix (vio_updater.cpp:417), allocated, zero-filled, "
+                                                 "diagonal written, freed: the as-written cost the baseline is spared"}
+        else:
+            out["as_written_dense_R"] = {"rows": rows, "bytes": nbytes, "ms": None, "note": "does not fit this host's free memory three times over: not timed"}
+    except Exception as e:
+        out["as_written_dense_R"] = {"error": str(e)[:200]}
     # footnotes, each a few seconds: the reference's Release flags use unsafe math; and one agent
     # per core on the cores of this box (independent filters, so this is plain replication)
     try:
@@ -473,7 +512,11 @@ def main():
             ceil_fma, ceil_mfma = eng.probe_fp64_peak(False), eng.probe_fp64_peak(True)
         except Exception:
             ceil_fma = ceil_mfma = None
-        ach = f_qr / (qr_ms * 1e-3) / 1e12
+        # the Kalman update rides INSIDE the compression launch where the geometry allows it (xk_pipe_kalman): the dominant launch then
+        # does the QR's and the update's algorithmic flops, and there is no Kalman stage behind it
+        kal_fused = st.get("xk_kalman_update", {}).get("launches", 1) == 0
+        f_dom = f_qr + (f_upd if kal_fused else 0.0)
+        ach = f_dom / (qr_ms * 1e-3) / 1e12
         per_kernel = None
         if pmc:
             per_kernel = {k: {a: v for a, v in e.items() if a in ("avg_us", "l2_fabric_GBps", "mfma_util_pct", "wait_any_pct_of_wave_cycles", "l2_hit_pct")}
@@ -491,10 +534,13 @@ def main():
                                 f"profiles/{ROUND_TAG}_pmc_traffic.json; Infinity-Cache hits are included (no counter separates them)",
                 "pmc_file": pmc_state, "per_kernel": per_kernel,
                 "kernel": ("xk_caqr_pipe (Householder QR compression of the stacked [H|res]: ONE launch, the row stack resident in "
-                           "registers, the three levels of the CAQR tree pipelined on workgroups of their own; stage keys "
-                           + "+".join(qr_keys) + ")") if tm.get("n_levels") == 1 else
+                           "registers, the three levels of the CAQR tree pipelined on workgroups of their own"
+                           + ("; the Kalman update -- gain, P = (I - K H) P, correction -- applied block by block inside the same launch as "
+                              "the panels' rows of R become final, on the one workgroup the tree does not need" if kal_fused else "")
+                           + "; stage keys " + "+".join(qr_keys) + ")") if tm.get("n_levels") == 1 else
                           "+".join(qr_keys) + " (Householder QR compression of the stacked [H|res], multi-launch CAQR)",
-                "alg_flops_per_update": f_qr, "rows_stacked": rows, "stage_ms": qr_ms,
+                "alg_flops_per_update": f_dom, "alg_flops_qr": f_qr, "alg_flops_kalman_in_the_launch": (f_upd if kal_fused else 0.0),
+                "kalman_update_inside_the_launch": kal_fused, "rows_stacked": rows, "stage_ms": qr_ms,
                 "launches_per_update": sum(st[k]["launches"] for k in qr_keys),
                 "dominant_kernel_by_time": dom[0], "dominant_kernel_ms": dom[1]["ms"],
                 "dominant_kernel_launches": dom[1]["launches"],

@@ -949,6 +949,22 @@ done:
   return rc;
 }
 
+/* Footnote of the CPU baseline: the reference materialises the measurement-noise matrix DENSE,
+ * r = r_diag.asDiagonal() assigned to a Matrix (vio_updater.cpp:417: rows x rows doubles, zero-filled, diagonal written), and
+ * throws it away in applyQRDecomposition (:508-509).  The baseline keeps the diagonal as a vector; this times what the as-written
+ * allocation + fill costs on this host for `rows` stacked rows.  Returns the trace (so that nothing is optimised away), -1 if
+ * the allocation fails. */
+double xo_dense_noise_footnote(int rows, const double *r_diag) {
+  double *R = malloc(sizeof(double) * (size_t)rows * (size_t)rows);
+  if (!R) return -1.0;
+  memset(R, 0, sizeof(double) * (size_t)rows * (size_t)rows);           /* Matrix::Zero semantics of the dense assignment */
+  for (int i = 0; i < rows; ++i) R[(size_t)i * rows + i] = r_diag ? r_diag[i] : 1.0;
+  double tr = 0.0;
+  for (int i = 0; i < rows; ++i) tr += R[(size_t)i * rows + i];
+  free(R);
+  return tr;
+}
+
 /* Full visual update with iekf_iter = 1 (updater.cpp:99-110).  This is what the CPU baseline times.
  * P is updated in place; correction (n) is written. */
 int xo_visual_update(const double *C_q_G, const double *G_p_C, int n_poses, const int *trk_off,
