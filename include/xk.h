@@ -357,7 +357,9 @@ int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 /* Which schedule compressed the last update -- 0 the multi-launch CAQR, 2 the pipelined single launch (1 was round 2's
  * register-resident kernel, no longer built) -- whether the single-launch path is armed for the next update, how many launches have given up on
  * this handle so far (workgroups not co-resident: another process on the GPU, a CU mask) and the reason code of the last one
- * (2 XCD-local hand-off, 3 uneven XCD placement, 4 / 5 / 6 waiting for the last level / the roots / the tiles).  A launch that
+ * (2 XCD-local hand-off, 3 uneven XCD placement, 4 / 5 / 6 waiting for the last level / the roots / the tiles, 8 the Kalman role
+ * waiting for rows of R, 9 more rows passed the gates than the tiles of the launch hold -- not a co-residency problem: the fast
+ * path stays armed for smaller stacks).  A launch that
  * gives up costs one bounded retry (<= 2 ms) and the update is redone by the multi-launch schedule with the same result; the
  * handle tries the fast path again after XK_CAQR_REARM (64) clean updates, doubling that distance at every further give-up.
  * xk_last_error() carries the same information as text.  Any pointer may be NULL. */

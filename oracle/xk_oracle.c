@@ -957,7 +957,10 @@ done:
 double xo_dense_noise_footnote(int rows, const double *r_diag) {
   double *R = malloc(sizeof(double) * (size_t)rows * (size_t)rows);
   if (!R) return -1.0;
-  memset(R, 0, sizeof(double) * (size_t)rows * (size_t)rows);           /* Matrix::Zero semantics of the dense assignment */
+  /* the dense assignment writes every element (through a volatile function pointer: gcc would otherwise turn malloc + memset into
+   * calloc and the kernel would hand out lazily-zeroed pages that are never touched) */
+  void *(*volatile fill)(void *, int, size_t) = memset;
+  fill(R, 0, sizeof(double) * (size_t)rows * (size_t)rows);
   for (int i = 0; i < rows; ++i) R[(size_t)i * rows + i] = r_diag ? r_diag[i] : 1.0;
   double tr = 0.0;
   for (int i = 0; i < rows; ++i) tr += R[(size_t)i * rows + i];

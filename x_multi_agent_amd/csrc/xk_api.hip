@@ -46,15 +46,14 @@ struct xk_handle {
   double *d_gam, *d_gam_s, *d_gpf;
   double *d_R;
   int nleaf, nlevels;   // of the last compression
-  // single-launch CAQR (xk_caqr_pipe.hip.h): cross-XCD exchange slabs, XCD-local strips and panel blocks, the row map,
+  // single-launch CAQR (xk_caqr_pipe.hip.h): cross-XCD exchange slabs, XCD-local strips and panel blocks,
   // two sets of sync words (a launch uses one and zeroes the other for its successor)
   double *d_x1, *d_x1p, *d_x2;
   double *d_rs, *d_rpb;
   unsigned *d_xsync;
   int xsync_phase;
-  int *d_rowmap;
-  int rowmap_R;            // valid rows the device row map describes (-1: stale)
-  std::vector<int> *h_rowlens;   // track lengths the row map was built for
+  int pipe_rows_nominal;   // rows the last single launch was queued for, every track counted as accepted
+  int overflow_rows;       // a single launch of that many nominal rows found more accepted rows than its tiles hold: not tried again at that size
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
   bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
   long long *d_pdbg;
@@ -278,12 +277,9 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
       HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_PIPE_NT_MAX * 16 * h->C1P));
       HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_PIPE_NT_MAX * 256));
-      HIPCHK(h, dalloc(&h->d_rowmap, (size_t)XK_PIPE_ROWS_MAX));
       HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
       HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
       h->xsync_phase = 0;
-      h->rowmap_R = -1;
-      h->h_rowlens = new std::vector<int>();
       HIPCHK(h, dalloc(&h->d_pdbg, (size_t)256 + 64 * 256));
       HIPCHK(h, hipMemset(h->d_pdbg, 0, sizeof(long long) * (256 + 64 * 256)));
     }
@@ -361,9 +357,8 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_fq) hipFree(h->d_fq);
-  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_rowmap, (void *)h->d_xsync})
+  for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_xsync})
     if (p4) hipFree(p4);
-  delete h->h_rowlens;
   for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_pdbg})
     if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
@@ -842,42 +837,20 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     h->clean_classic = 0;
   }
   if (resident_env && h->persist_ok && fast_shape) {
-    // row map: valid row g -> physical row of the 64-row slots, in the reference's stacking order (vio_updater.cpp:406-422):
-    // MSCKF tracks (2 L - 3 rows each), MSCKF-SLAM tracks, then the packed SLAM rows.  It depends on the track lengths and
-    // the number of persistent features only, so it is rebuilt (and uploaded) when those change.
+    // The launch compacts the stack itself (xk_pipe_rowplan: rows of rejected tracks cost nothing), so what the tiles must hold
+    // is the rows that PASS the gates -- which the host does not know when it queues the launch.  It queues on the nominal count
+    // (every track accepted) up to a quarter over the capacity; a launch that finds more accepted rows than its tiles hold gives
+    // up at once (reason 9) and the multi-launch schedule serves the update -- and the following ones of that size.
     const bool narrow = h->C1 <= XkPipeNarrow::COLS;
     const int rows_cap = narrow ? XkPipeNarrow::ROWS : XkPipeWide::ROWS;
-    std::vector<int> &key = *h->h_rowlens;
-    const size_t nkey = (size_t)h->K + h->K2 + 2;
-    bool same = h->rowmap_R >= 0 && key.size() == nkey && key[h->K] == -1 - h->K2 && key[nkey - 1] == h->M;
-    for (int k = 0; same && k < h->K; ++k) same = key[k] == h->h_trk_off[k + 1] - h->h_trk_off[k];
-    for (int k = 0; same && k < h->K2; ++k) same = key[h->K + 1 + k] == h->h_trk2_off[k + 1] - h->h_trk2_off[k];
-    if (!same) {
-      key.resize(nkey);
-      int R = 0;
-      for (int k = 0; k < h->K; ++k) { key[k] = h->h_trk_off[k + 1] - h->h_trk_off[k]; R += 2 * key[k] - 3; }
-      key[h->K] = -1 - h->K2;
-      for (int k = 0; k < h->K2; ++k) { key[h->K + 1 + k] = h->h_trk2_off[k + 1] - h->h_trk2_off[k]; R += 2 * key[h->K + 1 + k] - 3; }
-      key[nkey - 1] = h->M;
-      R += 2 * h->M;
-      h->rowmap_R = -1;
-      if (R <= rows_cap && (size_t)R * sizeof(int) <= h->stage_bytes) {
-        int *st = (int *)stage_slot(h, sizeof(int) * (size_t)R);
-        if (!st) return fail(h, XK_EDEVICE, "row map staging");
-        int g = 0;
-        for (int k = 0; k < h->K; ++k)
-          for (int i = 0; i < 2 * key[k] - 3; ++i) st[g++] = k * 64 + i;
-        for (int k = 0; k < h->K2; ++k)
-          for (int i = 0; i < 2 * key[h->K + 1 + k] - 3; ++i) st[g++] = (h->K + k) * 64 + i;
-        for (int i = 0; i < 2 * h->M; ++i) st[g++] = (h->K + h->K2) * 64 + i;      // (SLAM rows are packed 64 to a slot)
-        if (hipMemcpyAsync(h->d_rowmap, st, sizeof(int) * (size_t)R, hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "row map");
-        h->rowmap_R = R;
-      }
-    }
-    const int NTP = 8 * (narrow ? XkPipeNarrow::NT : XkPipeWide::NT), rows_tile = narrow ? XkPipeNarrow::LPC * XkPipeNarrow::RPL : XkPipeWide::LPC * XkPipeWide::RPL;
-    if (h->rowmap_R >= 64 * 8 && (h->rowmap_R + NTP - 1) / NTP <= rows_tile) {
+    int R_nom = 2 * h->M;
+    for (int k = 0; k < h->K; ++k) R_nom += 2 * (h->h_trk_off[k + 1] - h->h_trk_off[k]) - 3;
+    for (int k = 0; k < h->K2; ++k) R_nom += 2 * (h->h_trk2_off[k + 1] - h->h_trk2_off[k]) - 3;
+    const int NTP = 8 * (narrow ? XkPipeNarrow::NT : XkPipeWide::NT);
+    h->pipe_rows_nominal = R_nom;
+    if (R_nom >= 64 * 8 && ntiles <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
       XkCaqrPipeArgs pa;
-      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.rowmap = h->d_rowmap; pa.R = h->rowmap_R; pa.TR = (h->rowmap_R + NTP - 1) / NTP;
+      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = ntiles;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
       pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.status = h->d_status;
       if (h->xsync_dirty) {
@@ -1158,6 +1131,16 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
     // The fast path steps aside, but not for the life of the handle: after `rearm_after` clean multi-launch updates it is
     // tried again (the other tenant of the GPU may be gone); every further give-up doubles that distance, so a permanently
     // shared GPU costs one bounded retry (<= 2 ms, xk_spin_ge) every few thousand updates at most.
+    if (pst == 9) {
+      // not a co-residency problem: more rows passed the gates than the tiles of the single launch hold.  The fast path stays
+      // armed for smaller stacks; this size goes to the multi-launch schedule from now on.
+      h->overflow_rows = h->overflow_rows ? std::min(h->overflow_rows, h->pipe_rows_nominal) : h->pipe_rows_nominal;
+      h->fast_giveups++; h->fast_reason = pst;
+      h->xsync_dirty = true;
+      h->have_rows = h->have_R = false;
+      snprintf(h->err, sizeof(h->err), "single-launch CAQR: %d nominal rows held more accepted rows than its tiles; multi-launch schedule from that size on", h->pipe_rows_nominal);
+      return allow_retry ? XK_RETRY_CLASSIC : XK_EDEVICE;
+    }
     h->persist_ok = false;
     h->fast_giveups++; h->fast_reason = pst; h->clean_classic = -1;   // (-1: the retry of THIS update is not a clean update)
     if (h->fast_giveups > 1) h->rearm_after = std::min(4096, std::max(1, h->rearm_after) * 2);

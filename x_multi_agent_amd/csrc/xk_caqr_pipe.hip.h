@@ -36,9 +36,11 @@
 // Geometry of a launch.  LPC lanes per column x RPL rows per lane = rows of a fat tile (768 / LPC columns per workgroup);
 // per XCD: NT tile workgroups + NM first-level workgroups + 1 last-level workgroup = 32 = the CUs of an XCD; NCL = column
 // sets per last-level thread (its 8 workgroups cover NCL x 8 x <= 32 trailing columns), NCM = column sets per first-level thread.
-template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1>
+template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_>
 struct XkPipeGeom {
   static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_, NCM = NCM_;
+  static constexpr int RPLS = RPLS_;                       // second tile-step instantiation: fewer rows per lane, taken when the ACCEPTED rows fit it
+  static_assert(RPLS_ % 4 == 0 && RPLS_ >= 16 && RPLS_ <= RPL_, "the lighter tile step");
   static constexpr int RM = (NT_ + 2) & ~1;                // registers of a first-level lane: pending strip + NT strips, even
   static constexpr int COLS = XK_PIPE_THREADS / LPC_;      // widest system (C1P) a tile workgroup holds
   static constexpr int ROWS = 8 * NT_ * LPC_ * RPL_;       // most stacked rows
@@ -46,15 +48,16 @@ struct XkPipeGeom {
   static_assert(RPL_ % 4 == 0 && RPL_ >= 16, "the pivot strip is the first 16 rows of the part-0 lane");
 };
 #ifndef XK_PIPE_NARROW
-#define XK_PIPE_NARROW 4, 32, 23, 8, 1
+#define XK_PIPE_NARROW 4, 32, 23, 8, 1, 1, 28
 #endif
 using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
 #ifndef XK_PIPE_WIDE
-#define XK_PIPE_WIDE 2, 40, 19, 12, 2
+#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32
 #endif
 using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
 #define XK_PIPE_NT_MAX 23
 #define XK_PIPE_ROWS_MAX 24320
+#define XK_PIPE_SLOTS_MAX 1536      // 64-row slots (tracks + packed SLAM rows) a launch can compact
 #ifndef XK_PIPE_NPH
 #define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
 #endif
@@ -106,9 +109,8 @@ enum {
 
 struct XkCaqrPipeArgs {
   const double *A;        // tiles [ntiles][64][C1P] row-major as the per-feature kernels wrote them (read once)
-  const int *tile_rows;   // valid rows per 64-row slot (0 = rejected track)
-  const int *rowmap;      // valid row g -> physical row of A, [R]
-  int R, TR;              // valid rows in total, rows per fat tile (<= 128)
+  const int *tile_rows;   // valid rows per 64-row slot (0 = rejected track), [nslots]: the stack is COMPACTED on the device --
+  int nslots;             // fat tile j takes rows [j TR, (j + 1) TR) of the rows that passed the gates, TR = ceil(rows / tiles)
   int C1P, C1;
   double *Rout;           // [C1P][C1P] row-major
   double *S;              // [8 NT][16 x C1P] pivot strips, block layout (xk_blk), XCD-local
@@ -435,9 +437,61 @@ __device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], double (*b2)[RPL
 }
 
 // ---- role T: one fat tile in registers for the whole factorisation
+// Which rows are mine.  The per-feature kernels leave tile_rows[slot] = rows of the slot that hold data (0: a track the gate
+// rejected); the reference appends inliers only (msckf_update.cpp:463-479), and so does this: every tile workgroup forms the
+// prefix sums of tile_rows (the same few hundred words, in LDS -- nobody waits for anybody), learns the number of rows that
+// passed, TR = ceil(rows / tiles), and turns its rows [j TR, (j + 1) TR) into physical rows by a binary search.  Rejected tracks
+// cost no registers; the host needs no row map (it does not know the verdicts when it queues the launch).
+// Returns TR (0: more rows than the tiles hold -- the launch gives up, the multi-launch schedule serves the update).
 template <class G>
-__device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NT = G::NT, LPC = G::LPC, RPL = G::RPL, NPH = XK_PIPE_NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
+__device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, int *pre, int *myrows) {
+  constexpr int NTP = 8 * G::NT, CAP = G::LPC * G::RPL;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int wsum[XK_PIPE_THREADS / 64];
+  int carry = 0;
+  for (int base = 0; base < a.nslots; base += XK_PIPE_THREADS) {
+    const int t = base + tid;
+    int v = t < a.nslots ? a.tile_rows[t] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {                    // inclusive scan inside the wave
+      const int u = __shfl_up(v, o, 64);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (t < a.nslots) pre[t + 1] = v + off;
+    int tot = 0;
+    for (int w = 0; w < XK_PIPE_THREADS / 64; ++w) tot += wsum[w];
+    carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) pre[0] = 0;
+  const int R = carry, TR = (R + NTP - 1) / NTP;
+  __syncthreads();
+  if (TR > CAP) return 0;
+  if (tid < CAP) {
+    const int g = j * TR + tid;
+    int phys = -1;
+    if (tid < TR && g < R) {
+      int lo = 0, hi = a.nslots;                           // largest slot with pre[slot] <= g
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pre[mid] <= g) lo = mid; else hi = mid;
+      }
+      phys = lo * 64 + (g - pre[lo]);
+    }
+    myrows[tid] = phys;
+  }
+  __syncthreads();
+  return max(TR, 1);
+}
+
+template <class G, int RPL>
+__device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok,
+                                          const int *myrows) {
+  constexpr int NT = G::NT, LPC = G::LPC, NPH = XK_PIPE_NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
   static_assert(ARRD < GS, "a phase is counted in before the next one is published");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
@@ -448,27 +502,23 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
   const int npanels = (a.C1 + 15) / 16;
   const bool stamp = a.dbg && xcc == 0 && slot == 1 && tid == 0;
   double b[RPL];
-  {   // The one pass over the stack: gather my rows through the row map.  Branch-free and in batches -- every index is clamped into
-      // range and every load issued whether or not its value is used -- so that 32 (row map) resp. 16 + 16 (verdict + row) loads
-      // are in flight at a time: with a branch per row the compiler waited for each row's row-map entry and then for its data,
-      // 64 dependent round trips = 22 us of the launch.
-    const int g0 = j * a.TR + part_ * RPL, gend = min(min((j + 1) * a.TR, g0 + RPL), a.R);
-    const int last = max(a.R - 1, 0);
+  {   // The one pass over the stack: my rows, through the physical row numbers xk_pipe_rowplan left in LDS (-1: no row).  Branch-free
+      // and in batches -- every index clamped into range, every load issued whether or not its value is used -- so that 16 loads are
+      // in flight at a time: with a branch per row the compiler waited for each row's data before the next, 22 us of the launch.
     int pr[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) pr[r] = a.rowmap[min(g0 + r, last)];
+    for (int r = 0; r < RPL; ++r) pr[r] = myrows[part_ * RPL + r];
     const double *Ac = a.A + min(cabs, a.C1P - 1);          // (the wide geometry's column slots run to 383, past C1P = 256 / 320: clamped into the row)
 #pragma unroll
     for (int h0 = 0; h0 < RPL; h0 += 16) {
-      int tr[16];
       double x[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (h0 + r < RPL) { tr[r] = a.tile_rows[pr[h0 + r] >> 6]; x[r] = Ac[(size_t)pr[h0 + r] * a.C1P]; }
+        if (h0 + r < RPL) x[r] = Ac[(size_t)max(pr[h0 + r], 0) * a.C1P];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (h0 + r < RPL) b[h0 + r] = (mine && g0 + h0 + r < gend && tr[r] > 0) ? x[r] : 0.0;
+        if (h0 + r < RPL) b[h0 + r] = (mine && pr[h0 + r] >= 0) ? x[r] : 0.0;
       }
     }
   }
@@ -1225,6 +1275,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
   __shared__ unsigned s_slot, s_ok;
+  __shared__ int rp_pre[XK_PIPE_SLOTS_MAX + 1], rp_rows[LPC * RPL];   // tile workgroups: prefix sums of the accepted rows, my rows
   // landing area of the first level's load-to-LDS prefetch: per wave (4 columns) 24 strips x 4 rows x 4 columns
   __shared__ __attribute__((aligned(16))) double pfbuf[XK_PIPE_PF ? (XK_PIPE_THREADS / 64) * 24 * 16 : 2];
   constexpr bool KAL = G::COLS <= 192;                     // the Kalman role keeps [P | d] in registers: n <= 206
@@ -1249,7 +1300,14 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __syncthreads();
   if (a.test_stall && xcc == 3 && slot == 5) return;
   bool ok;
-  if (slot < NT) ok = xk_pipe_tile<G>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok);
+  if (slot < NT) {
+    const int TR = xk_pipe_rowplan<G>(a, (int)xcc * NT + slot, rp_pre, rp_rows);
+    if (TR == 0) {                                         // more accepted rows than the tiles hold: everybody learns it from the abort word
+      if (threadIdx.x == 0) { __hip_atomic_store(ab, 9u, XK_RLX_AGENT); a.status[1] = 9; }
+      ok = false;
+    } else if (G::RPLS < RPL && TR <= LPC * G::RPLS) ok = xk_pipe_tile<G, G::RPLS>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
+    else ok = xk_pipe_tile<G, RPL>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
+  }
   else if (slot < NT + NM) ok = xk_pipe_first<G>(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok, pfbuf);
   else {
     // nothing to do until the first roots arrive: leave the other set of sync words zeroed for the next launch
