@@ -61,6 +61,19 @@ using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM fe
 #ifndef XK_PIPE_NPH
 #define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
 #endif
+// Phase boundaries: phase q = reflector steps / strip rows [xk_pb(q), xk_pb(q + 1)); equal phases unless NPH = 4 and XK_PIPE_PB says
+// otherwise.  (Measured, round 4: a short first phase -- the level above starts when the level below has published its first
+// phase -- does NOT pay: 0,2,6,11,16: QR 0.348 ms, 0,3,7,11,16: 0.342, 0,1,4,9,16: 0.347 against 0.339 for 0,4,8,12,16.)
+#ifndef XK_PIPE_PB
+#define XK_PIPE_PB 0, 4, 8, 12, 16
+#endif
+__host__ __device__ constexpr int xk_pb(int q) {
+  if (XK_PIPE_NPH == 4) {
+    constexpr int t[] = {XK_PIPE_PB};
+    return q <= 0 ? 0 : (q >= 4 ? 16 : t[q]);
+  }
+  return q * (16 / XK_PIPE_NPH);
+}
 #ifndef XK_PIPE_ARRD
 #define XK_PIPE_ARRD 1              // a phase's rows are counted in at the barrier ARRD steps after their stores were issued
 #endif
@@ -492,7 +505,7 @@ template <class G, int RPL>
 __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok,
                                           const int *myrows) {
   constexpr int NT = G::NT, LPC = G::LPC, NPH = XK_PIPE_NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
-  static_assert(ARRD < GS, "a phase is counted in before the next one is published");
+  static_assert(ARRD < xk_pb(1) && ARRD < 16 - xk_pb(NPH - 1), "a phase is counted in before the next one is published");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -542,16 +555,16 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_TQ_CNT + (q - 1) * 8 + xcc) * 16); };
-      xk_pipe_range<LPC, q * GS, (q + 1) * GS, (q > 0 ? q * GS + ARRD : -1), RPL>(b, nullptr, rel, mine, false, part, nsteps, ubuf, sc, full, hook);
+      xk_pipe_range<LPC, xk_pb(q), xk_pb(q + 1), (q > 0 ? xk_pb(q) + ARRD : -1), RPL>(b, nullptr, rel, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (pub) {
         if (rel < 16) {
           double *pb = xk_opaque(myPB + xk_blk(rel, 0));
 #pragma unroll
-          for (int r = q * GS; r < (q + 1) * GS; ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
+          for (int r = xk_pb(q); r < xk_pb(q + 1); ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
         } else {
           double *ps = xk_opaque(myS + xk_blk(cabs, 0));
 #pragma unroll
-          for (int r = q * GS; r < (q + 1) * GS; ++r) ps[r * 4] = b[r];
+          for (int r = xk_pb(q); r < xk_pb(q + 1); ++r) ps[r * 4] = b[r];
         }
       }
       if (stamp && q < 4) a.dbg[16 * k + 1 + q] = wall_clock64();
@@ -662,7 +675,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     // unit, 1.5 us per phase, four times per panel, on the chain of both dependency loops.  Instead every wave asks for its 23
     // lines with THREE 16-bytes-per-lane loads that land straight in LDS (lane l: strip 8 j + l / 8, piece l % 8), and the
     // lanes of the phase pick their 23 values up from there.
-    constexpr bool PF = XK_PIPE_PF && NCM == 1 && NPH == 4 && NT <= 24;
+    constexpr bool PF = XK_PIPE_PF && NCM == 1 && NPH == 4 && NT <= 24 && xk_pb(1) == 4 && xk_pb(2) == 8 && xk_pb(3) == 12;
     const int ln = tid & 63, cid4 = cidx & ~3;
     const int wcol = panel ? c0 + cid4 : c0 + 16 + item * mch + (cid4 - 16);
     const bool wv_ok = active && (panel || cid4 - 16 < mh) && wcol < a.C1;
@@ -711,14 +724,14 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
             }
           }
         } else {
-          if (active && mine && part >= loaded * GS && part < av * GS) {
+          if (active && mine && part >= xk_pb(loaded) && part < xk_pb(av)) {
             double *g = xk_opaque(g0);
 #pragma unroll
             for (int s = 1; s <= NT; ++s) b[s] = XK_LD_LOC(g + (size_t)(s - 1) * strip_step);
           }
         }
         if constexpr (NCM > 1) {
-          if (mine2 && part >= loaded * GS && part < av * GS) {
+          if (mine2 && part >= xk_pb(loaded) && part < xk_pb(av)) {
             double *g = xk_opaque(g02);
 #pragma unroll
             for (int s = 1; s <= NT; ++s) b2[s] = xk_ld_sc1(g + (size_t)(s - 1) * SS);
@@ -736,14 +749,14 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
       if constexpr (NCM > 1)
-        xk_pipe_range<0, q * GS, (q + 1) * GS, (q > 0 ? q * GS : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full, hook);
+        xk_pipe_range<0, xk_pb(q), xk_pb(q + 1), (q > 0 ? xk_pb(q) : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full, hook);
       else
-        xk_pipe_range<0, q * GS, (q + 1) * GS, (q > 0 ? q * GS : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
+        xk_pipe_range<0, xk_pb(q), xk_pb(q + 1), (q > 0 ? xk_pb(q) : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
       // rows [q GS, (q + 1) GS) of the root are final: out they go (write-through: the last level sits on other XCDs)
-      if (q < NPH - 1 && x1_mine && part >= q * GS && part < (q + 1) * GS) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if (q < NPH - 1 && x1_mine && part >= xk_pb(q) && part < xk_pb(q + 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
       if constexpr (NCM > 1) {
-        if (q < NPH - 1 && mine2 && part >= q * GS && part < (q + 1) * GS) xk_st_sc1(x12, b2[0]);
+        if (q < NPH - 1 && mine2 && part >= xk_pb(q) && part < xk_pb(q + 1)) xk_st_sc1(x12, b2[0]);
       }
       if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
     };
@@ -762,14 +775,14 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 #pragma unroll
         for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
       }
-      if (x1_mine && part >= (NPH - 1) * GS) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if (x1_mine && part >= xk_pb(NPH - 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
     }
     if constexpr (NCM > 1) {
       if (mine2) {
         double *g = xk_opaque(g02);
 #pragma unroll
         for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * SS] = b2[s];
-        if (part >= (NPH - 1) * GS) xk_st_sc1(x12, b2[0]);
+        if (part >= xk_pb(NPH - 1)) xk_st_sc1(x12, b2[0]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -824,12 +837,12 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     int loaded = 0;
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      if (!ok || nsteps <= q * GS) return;                 // (a short last panel: the roots' rows past its columns are zero)
+      if (!ok || nsteps <= xk_pb(q)) return;                 // (a short last panel: the roots' rows past its columns are zero)
       if (loaded <= q) {
         const int av = xk_pipe_wait_phases(sync + (XP_X1_CNT + k) * 16, XK_CAQR_MAXP * 16, q, NPH, 8u * NM, ab, 5u, s_ok);
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
-        if (part >= loaded * GS && part < av * GS) {
+        if (part >= xk_pb(loaded) && part < xk_pb(av)) {
           if (mine) {
 #pragma unroll
             for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
@@ -842,7 +855,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         loaded = av;
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
-      xk_pipe_range<0, q * GS, (q + 1) * GS, -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
+      xk_pipe_range<0, xk_pb(q), xk_pb(q + 1), -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
       if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q + 1] = wall_clock64();
     };
