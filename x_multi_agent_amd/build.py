@@ -26,6 +26,22 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_strict(verbose=True):
+    """libxk_strict.so: the same sources with -DXK_SYNC_STRICT=1 -- every hand-off of the single-launch kernels as an agent-scope
+    release / acquire pair (xk_xcd_sync.hip.h).  2.3x slower; it is the reference the default build's hand-offs are checked
+    against (tests/test_gpu_strict_sync.py), selected with XK_LIB_PATH."""
+    out = os.path.join(HERE, "libxk_strict.so")
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value",
+           "-DXK_SYNC_STRICT=1", "-o", out, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_fleet(verbose=True):
     """libxk_fleet.so: the RCCL exchange of the CI step (include/xk_fleet.h), host code over libxk.so + librccl.so."""
     out = os.path.join(HERE, "libxk_fleet.so")

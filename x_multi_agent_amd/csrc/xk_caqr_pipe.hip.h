@@ -36,11 +36,11 @@
 // Geometry of a launch.  LPC lanes per column x RPL rows per lane = rows of a fat tile (768 / LPC columns per workgroup);
 // per XCD: NT tile workgroups + NM first-level workgroups + 1 last-level workgroup = 32 = the CUs of an XCD; NCL = column
 // sets per last-level thread (its 8 workgroups cover NCL x 8 x <= 32 trailing columns), NCM = column sets per first-level thread.
-template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_>
+template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_, int RPLT_ = RPLS_>
 struct XkPipeGeom {
   static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_, NCM = NCM_;
-  static constexpr int RPLS = RPLS_;                       // second tile-step instantiation: fewer rows per lane, taken when the ACCEPTED rows fit it
-  static_assert(RPLS_ % 4 == 0 && RPLS_ >= 16 && RPLS_ <= RPL_, "the lighter tile step");
+  static constexpr int RPLS = RPLS_, RPLT = RPLT_;         // lighter tile-step instantiations: fewer rows per lane, taken when the ACCEPTED rows fit
+  static_assert(RPLS_ % 4 == 0 && RPLS_ >= 16 && RPLS_ <= RPL_ && RPLT_ % 4 == 0 && RPLT_ >= 16 && RPLT_ <= RPLS_, "the lighter tile steps");
   static constexpr int RM = (NT_ + 2) & ~1;                // registers of a first-level lane: pending strip + NT strips, even
   static constexpr int COLS = XK_PIPE_THREADS / LPC_;      // widest system (C1P) a tile workgroup holds
   static constexpr int ROWS = 8 * NT_ * LPC_ * RPL_;       // most stacked rows
@@ -48,11 +48,11 @@ struct XkPipeGeom {
   static_assert(RPL_ % 4 == 0 && RPL_ >= 16, "the pivot strip is the first 16 rows of the part-0 lane");
 };
 #ifndef XK_PIPE_NARROW
-#define XK_PIPE_NARROW 4, 32, 23, 8, 1, 1, 28
+#define XK_PIPE_NARROW 4, 32, 23, 8, 1, 1, 28, 24
 #endif
 using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
 #ifndef XK_PIPE_WIDE
-#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32
+#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28
 #endif
 using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
 #define XK_PIPE_NT_MAX 23
@@ -156,7 +156,7 @@ __device__ __forceinline__ XkCaqrPipeArgs xk_pipe_args(XkPipeArgsPtr ap) {
 // version, which kept an arrival counter + a flag the last arriver raised); the consumers poll the counter itself.  They are
 // few (8 first-level workgroups per tile counter, 23 tiles per first-level counter, one lane each, s_sleep between polls).
 __device__ __forceinline__ void xk_pipe_arrive(unsigned *cnt) {
-  (void)__hip_atomic_fetch_add(cnt, 1u, XK_RLX_AGENT);
+  (void)__hip_atomic_fetch_add(cnt, 1u, XK_ARRIVE_ORDER, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Hides a per-lane constant from loop-invariant code motion: the sixteen unrolled steps of a panel derive 0/1 masks, LDS
 // addresses and predicates from (part, column); hoisted out of the panel loop they are ~60 live registers that end up in
@@ -183,6 +183,7 @@ __device__ __forceinline__ bool xk_pipe_wait(unsigned *word, unsigned target, un
   if (threadIdx.x == 0) *s_ok = xk_spin_ge(word, target, ab, reason) ? 1u : 0u;
   __syncthreads();
   const bool ok = *s_ok != 0u;
+  XK_ACQUIRE_FENCE();
   __syncthreads();                  // (s_ok is rewritten by the next wait)
   return ok;
 }
@@ -204,6 +205,7 @@ __device__ __forceinline__ int xk_pipe_wait_phases(unsigned *cnt0, int stride, i
   }
   __syncthreads();
   const int av = (int)*s_ok;
+  XK_ACQUIRE_FENCE();
   __syncthreads();
   return av;
 }
@@ -1318,7 +1320,8 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
     if (TR == 0) {                                         // more accepted rows than the tiles hold: everybody learns it from the abort word
       if (threadIdx.x == 0) { __hip_atomic_store(ab, 9u, XK_RLX_AGENT); a.status[1] = 9; }
       ok = false;
-    } else if (G::RPLS < RPL && TR <= LPC * G::RPLS) ok = xk_pipe_tile<G, G::RPLS>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
+    } else if (G::RPLT < G::RPLS && TR <= LPC * G::RPLT) ok = xk_pipe_tile<G, G::RPLT>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
+    else if (G::RPLS < RPL && TR <= LPC * G::RPLS) ok = xk_pipe_tile<G, G::RPLS>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
     else ok = xk_pipe_tile<G, RPL>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
   }
   else if (slot < NT + NM) ok = xk_pipe_first<G>(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok, pfbuf);

@@ -24,6 +24,23 @@
 #define XK_SPIN_TICKS 200000LL      // 100 MHz ticks
 #endif
 #define XK_CAQR_MAXP 32             // panels per launch (C1 <= 512)
+// -DXK_SYNC_STRICT=1: every hand-off as the HIP memory model spells it -- the producer's counter update is an agent-scope RELEASE,
+// every consumer thread runs an agent-scope ACQUIRE fence behind the poll.  On gfx950 an agent-scope release writes the XCD's L2
+// back (buffer_wbl2 sc1) and an acquire invalidates it (buffer_inv sc1): with ~100 hand-offs per workgroup and launch that is what
+// the whole design exists to avoid -- measured in DESIGN 3.2 -- so the default keeps relaxed counters and makes the DATA visible
+// instead: write-through (sc1) stores for everything another XCD reads, plain stores + s_waitcnt vmcnt(0) inside an XCD (one L2),
+// L1-bypassing (sc1) loads on the consumer.  That is what the hardware does, not what the language promises; the soak tests are
+// the gate, and this switch is the reference the default can be checked against after a compiler or ROCm update.
+#ifndef XK_SYNC_STRICT
+#define XK_SYNC_STRICT 0
+#endif
+#if XK_SYNC_STRICT
+#define XK_ARRIVE_ORDER __ATOMIC_RELEASE
+#define XK_ACQUIRE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define XK_ARRIVE_ORDER __ATOMIC_RELAXED
+#define XK_ACQUIRE_FENCE()
+#endif
 #define XK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ double xk_ld_sc1(const double *p) {
