@@ -1,5 +1,5 @@
 // Clocks of the 16 x 16 factor-and-invert pivot chain (xk_chol16_bcast) on one wave, and its result against the host.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DXK_CHOL16_CHAIN=0|1] tools/exp/chol16_probe.hip -o tools/exp/bin/chol16_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/exp/chol16_probe.hip -o tools/exp/bin/chol16_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>
