@@ -3,7 +3,8 @@ unsynchronised column splits / redundant factorizations would show up here)."""
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from x_multi_agent_amd import engine, synth
-for cfg, reps in ((4, 300), (2, 100), (3, 30)):
+SCALE = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # python tools/exp/determinism.py 10 -> ten times the repetitions
+for cfg, reps in ((4, 300 * SCALE), (1, 300 * SCALE), (2, 100 * SCALE), (3, 30 * SCALE)):
     N, K, M = synth.CONFIGS[cfg]
     sc = synth.make_config(cfg)
     eng = engine.Engine(N, M, K)
