@@ -293,7 +293,7 @@ def main():
     # buffer in HBM beforehand.  Prints a short JSON report instead of the bench line.
     ap.add_argument("--dry-run-ranks", type=int, default=0)
     ap.add_argument("--dry-run-rank", type=int, default=0)
-    ap.add_argument("--dump-posterior", default=None, help="rank 0 / the dry-run rank: save the resident covariance after the run (.npy)")
+    ap.add_argument("--dump-posterior", default=None, help="rank 0 / the dry-run rank: save the covariance the last CI round fused (no round: the resident one) as .npy")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -448,6 +448,9 @@ def main():
             if allp.device.type != "cuda":
                 allp, allt = allp.cuda(dev), allt.cuda(dev)
             fused, _ = fleet.ci_round_device(eng, sc, 0, 2, allp, allt, CI_TRACKS, CI_MSCKF_W)
+            if args.dump_posterior:
+                ci_stats["P"] = eng.download_P()
+            eng.snapshot_P(restore=True)
             ci_stats["fused"] += fused
             ci_stats["keyframes_received"] = ci_stats.get("keyframes_received", 0) + 1
             return
@@ -456,6 +459,13 @@ def main():
             allp, allt = allp.cuda(dev), allt.cuda(dev)
         # the gathered snapshots stay in HBM: every per-agent stage of the CI block is batched on the device
         fused, _ = fleet.ci_round_device(eng, sc, rank, world, allp, allt, CI_TRACKS, CI_MSCKF_W)
+        # A replay: like the update's posterior, the fused covariance does not become the next prior -- every round fuses the
+        # staged prior with the snapshots that arrive.  (Fed back without the visual updates and the propagation between two
+        # rounds, a prior that only ever takes covariance intersections grows by 1 / w0 per fusion -- 1 / 0.65 with seven other
+        # agents -- and leaves the filter's numerical range after about eight rounds: XK_ESINGULAR at step ~90 of a fleet of 8.)
+        if args.dump_posterior:
+            ci_stats["P"] = eng.download_P()     # (checks only: what the last round fused, before the prior comes back)
+        eng.snapshot_P(restore=True)
         ci_stats["rounds"] += 1
         ci_stats["fused"] += fused
 
@@ -466,6 +476,7 @@ def main():
         torch.cuda.synchronize()
 
     # untimed warmup (also validates the staged path end to end)
+    eng.snapshot_P()                     # the staged prior: what every CI round starts from (see exchange())
     eng.run_steps(sigma, args.warmup)
     exchange(0)
     sync()
@@ -485,7 +496,7 @@ def main():
         dt = float(tt.item())
 
     if args.dump_posterior and (dry or rank == 0):
-        np.save(args.dump_posterior, eng.download_P())
+        np.save(args.dump_posterior, ci_stats["P"] if "P" in ci_stats else eng.download_P())
     if dry:
         rep = {"dry_run": True, "fleet": world, "rank": rank, "config": args.config, "backend": backend,
                "real_ranks_in_the_communicator": real_world, "steps": args.steps, "ms_per_step": 1e3 * dt / args.steps,

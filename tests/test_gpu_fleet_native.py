@@ -108,6 +108,21 @@ def test_bench_dry_run_of_an_eight_rank_fleet(config):
         assert d["ring_partner_per_tick"] == [4, 5, 6, 7] and d["keyframes_received"] >= 1
 
 
+@pytest.mark.parametrize("config,fleet", [(4, 8), (4, 4), (5, 8)])
+def test_bench_default_length_run_of_a_fleet_stays_in_the_filters_range(config, fleet):
+    """The driver's scaling run is `bench.py --gpus N` at the default 1000 steps = 100 CI rounds.  Every round must start from the
+    staged prior (a replay, like the updates): fed back, a prior that only ever takes covariance intersections grows by 1 / w0 per
+    fusion and the update's innovation covariance stops being positive definite -- XK_ESINGULAR at step ~90 of a fleet of eight,
+    which no short run shows.  Rank 1 of the fleet, 1000 steps, every round fusing what the first one fused."""
+    d = _bench(["--config", str(config), "--dry-run-ranks", str(fleet), "--dry-run-rank", "1", "--steps", "1000", "--warmup", "5",
+                "--no-cpu", "--no-frame-loop"])
+    every = 6 if config == 5 else 10
+    assert d["ci_rounds"] == 1 + 1000 // every
+    if config == 4:
+        # every round is the same round: the same tracks (one or both of the shared two) fuse each time
+        assert d["ci_fused"] >= d["ci_rounds"] and d["ci_fused"] % d["ci_rounds"] == 0
+
+
 def test_cpp_request_response_tick_in_loop_back(xk, tmp_path):
     """host/examples/fleet_main.cpp -- keyframe insert -> VLAD request -> keyframe reply from HBM -> xk_ci_round_device ->
     update, i.e. VIO::processOtherRequests / processOtherMeasurements (vio.cpp:462-570) in C++ over xk.h + xk_fleet.h -- in its

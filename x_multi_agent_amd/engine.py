@@ -147,6 +147,10 @@ class Engine:
                   "xk_download_P")
         return np.ascontiguousarray(P)
 
+    def snapshot_P(self, restore=False):
+        """Keep (restore=False) / bring back (restore=True) a device-side copy of the resident covariance (xk_snapshot_P)."""
+        self._chk(self.L.xk_snapshot_P(self.h, C.c_int(1 if restore else 0)), "xk_snapshot_P")
+
     # ---- staged path -------------------------------------------------
     def _flag_bufs(self):
         K, M = max(self._K, 1), max(self._M, 1)
