@@ -380,6 +380,24 @@ def main():
         kdb = place.Database(eng, place.load_vocabulary("visual"), PR_SCORE_THR, payload_doubles=pay_n, tracks_doubles=trk_n,
                              max_desc=256)
         pr_scene = synth.make_descriptors(96, 32, seed=0x5EED)        # the place every agent of the fleet looks at
+        # what the cameras see at every tick, made before the clock starts (synthetic input, 0.5 ms of host time per view)
+        n_ticks = args.steps // ci_every + 1
+        seen = {}
+
+        def view(kind, agent, tick):
+            key = (kind, agent, tick)
+            if key not in seen:
+                seen[key] = synth.observe_descriptors(pr_scene, 4, seed=(7919 if kind == "kf" else 104729) * agent + tick)
+            return seen[key]
+
+        for t_ in range(n_ticks):
+            view("kf", rank, t_), view("q", rank, t_)
+            if dry:
+                rsp_ = fleet.ring_requests(world, t_)[rank][1]
+                asker_ = [a for a, b in fleet.ring_requests(world, t_) if b == rank]
+                view("kf", rsp_, t_)
+                for a_ in asker_:
+                    view("q", a_, t_)
         vex = fleet.Exchange(dist, world, rank, kdb.vlad_bytes, xdev, dtype=torch.uint8, real_world=real_world)
         rex = fleet.Exchange(dist, world, rank, 2 + pay_n + trk_n, xdev, real_world=real_world)
         resp_dev = torch.zeros(2 + pay_n + trk_n, dtype=torch.float64, device=f"cuda:{dev}")
@@ -391,7 +409,7 @@ def main():
             vdbs, dry_tick = {}, [0]
 
             def peer_vlad(requester):
-                return torch.from_numpy(kdb.compute_vlad(synth.observe_descriptors(pr_scene, 4, seed=104729 * requester + dry_tick[0])).ravel()).to(xdev)
+                return torch.from_numpy(kdb.compute_vlad(view("q", requester, dry_tick[0])).ravel()).to(xdev)
 
             def peer_response(rsp):
                 if rsp not in vdbs:
@@ -399,7 +417,7 @@ def main():
                                                tracks_doubles=trk_n, max_desc=256)
                 pv = ex.recv.view(world, pay_n)[rsp].cuda(dev).contiguous()
                 tv = tex.recv.view(world, tex.n)[rsp].cuda(dev).contiguous()
-                vdbs[rsp].add_keyframe(synth.observe_descriptors(pr_scene, 4, seed=7919 * rsp + dry_tick[0]), pv.data_ptr(), tv.data_ptr(),
+                vdbs[rsp].add_keyframe(view("kf", rsp, dry_tick[0]), pv.data_ptr(), tv.data_ptr(),
                                        tag=dry_tick[0])
                 out = torch.zeros(2 + pay_n + trk_n, dtype=torch.float64, device=f"cuda:{dev}")
                 idx, _score, tag = vdbs[rsp].find_candidate(int(rank), vex.send.cpu().numpy())
@@ -427,9 +445,9 @@ def main():
             if dry:
                 dry_tick[0] = tick
             trk_dev.copy_(tex.send)
-            kdb.add_keyframe(synth.observe_descriptors(pr_scene, 4, seed=7919 * rank + tick), pay_dev.data_ptr(),
+            kdb.add_keyframe(view("kf", rank, tick), pay_dev.data_ptr(),
                              trk_dev.data_ptr(), tag=step)
-            my_vlad = torch.from_numpy(kdb.compute_vlad(synth.observe_descriptors(pr_scene, 4, seed=104729 * rank + tick)).ravel())
+            my_vlad = torch.from_numpy(kdb.compute_vlad(view("q", rank, tick)).ravel())
 
             def answer(requester, vlad):
                 idx, _score, tag = kdb.find_candidate(int(requester), vlad.cpu().numpy())
