@@ -88,6 +88,8 @@ struct xk_handle {
   double *d_payload;
   double *d_ci;  // scratch for the CI kernels
   double *d_ciws;          // workspace of the device-resident CI round (lazily allocated)
+  hipStream_t ci_stream[8];   // ... and its side streams: shared track j >= 1 runs its stages before the gate on ci_stream[j],
+  hipEvent_t ci_fork, ci_join[8];   // next to track 0 on the engine's stream (forked and joined with events)
   XkFeatBatch *d_batch;    // per-agent descriptors of the batched feature launch, [8 tracks][8 agents]
   XkFeatBatch *h_batch;    // pinned staging of the same
   int *h_ci_cols;          // pinned: per shared track, the block columns of xk_scale_blocks [8][128]
@@ -380,6 +382,11 @@ extern "C" int xk_destroy(xk_handle *h) {
   for (auto &e : h->ev)
     if (e) hipEventDestroy(e);
   if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+  for (int j = 1; j < 8; ++j) {
+    if (h->ci_stream[j]) { hipStreamSynchronize(h->ci_stream[j]); hipStreamDestroy(h->ci_stream[j]); }
+    if (h->ci_join[j]) hipEventDestroy(h->ci_join[j]);
+  }
+  if (h->ci_fork) hipEventDestroy(h->ci_fork);
   if (h->ev_flags) hipEventDestroy(h->ev_flags);
   if (h->ev_flags_done) hipEventDestroy(h->ev_flags_done);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -1992,6 +1999,11 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     HIPCHK(h, hipHostMalloc((void **)&h->h_ci_cols, sizeof(int) * (8 * 128 + 8)));   // + the per-track own-gate flags
     HIPCHK(h, hipHostMalloc((void **)&h->h_ci_w, sizeof(double) * 16));   // [0..7] 1/w0, [8..15] joint gamma
     hipFuncSetAttribute((const void *)xk_ci_hph, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    HIPCHK(h, hipEventCreateWithFlags(&h->ci_fork, hipEventDisableTiming));
+    for (int j = 1; j < 8; ++j) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->ci_stream[j], hipStreamNonBlocking));
+      HIPCHK(h, hipEventCreateWithFlags(&h->ci_join[j], hipEventDisableTiming));
+    }
   }
   // per-track workspace (the stages before the gate of every shared track are queued back to back, then ONE
   // synchronisation fetches all the gate results)
@@ -2012,7 +2024,14 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   { int rcw = flush_window(h); if (rcw != XK_OK) return rcw; }
   int fused = 0;
   int trk_L0[8], trk_dof[8];
+  // The shared tracks are independent until applyCI (every P_j is built from the same prior), and a track's stages are a chain of
+  // seven small launches (~160 us at 8 agents): track j >= 1 runs its chain on a side stream next to track 0's.
+  static const int side_env = env_int("XK_CI_SIDE_STREAMS", 1);
+  const bool side = side_env && n_tracks > 1;
+  if (side) HIPCHK(h, hipEventRecord(h->ci_fork, h->stream));
   for (int j = 0; j < n_tracks; ++j) {
+    hipStream_t sj = (side && j > 0) ? h->ci_stream[j] : h->stream;
+    if (side && j > 0) HIPCHK(h, hipStreamWaitEvent(sj, h->ci_fork, 0));
     const CiWs w = ci_ws(j);
     double *dq = w.dq, *dp = w.dp, *dobs = w.dobs, *up = w.up, *Hs = w.Hs, *Si = w.Si, *S1 = w.S1, *S2 = w.S2;
     double *dres = w.dres, *dgpf = w.dgpf, *dscal = w.dscal;
@@ -2042,9 +2061,9 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       const int src = (i < k) ? i + 1 : 0;
       ga.q[i] = aq[src]; ga.p[i] = ap[src]; ga.obs[i] = aobs[src]; ga.np[i] = anp[src]; ga.L[i] = aL[src];
     }
-    hipLaunchKernelGGL(xk_ci_gather, dim3(1), dim3(64), 0, h->stream, ga);
+    hipLaunchKernelGGL(xk_ci_gather, dim3(1), dim3(64), 0, sj, ga);
     XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint + 16, nullptr, 0};
-    hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, h->stream, ta);
+    hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, sj, ta);
     // per-agent column-space rows, one workgroup per agent (:168-204)
     XkFeatBatch *hb = h->h_batch + 8 * j, *db = h->d_batch + 8 * j;
     int npmax = 0;
@@ -2053,31 +2072,32 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       hb[i].n_poses = anp[i]; hb[i].n_poses_max = N; hb[i].n = n; hb[i].L = aL[i]; hb[i].up_out = up + i * upsz;
       npmax = std::max(npmax, anp[i]);
     }
-    HIPCHK(h, hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, sj));
     XkFeatArgs a;
     memset(&a, 0, sizeof(a));
     a.K = k1; a.var_img = var_img; a.chi95 = h->d_chi95; a.n = n; a.na = n - XK_CORE; a.n_poses = npmax; a.n_poses_max = N;
     a.tile_rows = dint + 8; a.inlier = dint; a.gamma = dscal + 2; a.gpf = (double *)(dint + 192); a.gn_iters = dint + 24;
     a.gpf_in = dgpf; a.batch = db;
-    hipLaunchKernelGGL(xk_msckf_feature, dim3(k1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(npmax), h->stream, a);
+    hipLaunchKernelGGL(xk_msckf_feature, dim3(k1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(npmax), sj, a);
     // null-space projection of the landmark and split into per-agent Jacobians (:207-223)
     XkCiProjArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.k1 = k1; pa.res = dres;
     for (int i = 0; i < k1; ++i) { pa.up[i] = up + i * upsz; pa.n[i] = n; pa.H[i] = Hs + (size_t)m * n * i; }
-    hipLaunchKernelGGL(xk_ci_project, dim3(1), dim3(256), 0, h->stream, pa);
+    hipLaunchKernelGGL(xk_ci_project, dim3(1), dim3(256), 0, sj, pa);
     // S_i = H_i P_i H_i^T for all agents, then the gate / CI combinations and gamma
     XkCiHphArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.m = m; ha.S = Si;
     for (int i = 0; i < k1; ++i) { ha.H[i] = pa.H[i]; ha.P[i] = aP[i]; ha.n[i] = n; }
     const int nchunk = (n + XK_CI_CHUNK - 1) / XK_CI_CHUNK;
-    hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), h->stream, ha);
+    hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), sj, ha);
     XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal};
-    hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, h->stream, ca);
+    hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, sj, ca);
     // the two gate decisions (own chi-square test :180, joint test :243-250) come back per track
-    HIPCHK(h, hipMemcpyAsync(&h->h_ci_cols[1024 + j], dint, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(&h->h_ci_w[8 + j], dscal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&h->h_ci_cols[1024 + j], dint, sizeof(int), hipMemcpyDeviceToHost, sj));
+    HIPCHK(h, hipMemcpyAsync(&h->h_ci_w[8 + j], dscal, sizeof(double), hipMemcpyDeviceToHost, sj));
+    if (side && j > 0) { HIPCHK(h, hipEventRecord(h->ci_join[j], sj)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ci_join[j], 0)); }
     trk_L0[j] = aL[0];
     trk_dof[j] = 2 * Ltot - 3;
     if (trk_dof[j] >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
