@@ -218,8 +218,13 @@ def ci_round_device(eng, sc, rank, world, payloads, tracks, n_tracks, ci_msckf_w
     [world, n_tracks * (1 + 2N)] (pack_tracks of every agent).  The engine must have agent `rank`'s problem staged
     (its shared tracks are its first n_tracks staged tracks).  Only the few header / length words come to the host."""
     N = sc["n_poses_max"]
-    tl = tracks.view(world, n_tracks, 1 + 2 * N)[:, :, 0].to("cpu").numpy().astype(np.int32)
-    nv = payloads[:, 5].to("cpu").numpy().astype(np.int32)
+    # the few words the host needs -- every agent's track lengths and window size -- in ONE device-to-host copy
+    words = payloads.new_empty(world * (n_tracks + 1))
+    words[:world * n_tracks].view(world, n_tracks).copy_(tracks.view(world, n_tracks, 1 + 2 * N)[:, :, 0])
+    words[world * n_tracks:].copy_(payloads[:, 5])
+    words = words.to("cpu").numpy()
+    tl = np.ascontiguousarray(words[:world * n_tracks].reshape(world, n_tracks)).astype(np.int32)
+    nv = words[world * n_tracks:].astype(np.int32)
     nv[rank] = len(sc["G_p_C"])
     return eng.ci_round_device(payloads.data_ptr(), payloads.shape[1], world, rank, tracks.data_ptr(), n_tracks, tl, nv,
                                np.arange(n_tracks, dtype=np.int32), sc["sigma_img"], ci_msckf_w, want_corrections)
