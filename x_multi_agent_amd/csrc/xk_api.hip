@@ -791,6 +791,7 @@ struct UpdateSpec {
   double *corr;       // where the correction goes: null -> h->d_corr (device); xk_apply_update passes pinned host memory
   unsigned long long *done_flag;   // optional completion marker (pinned host memory) written by the last launch ...
   unsigned long long done_seq;     // ... with this value
+  int tri;           // T is upper trapezoidal (T[r][k] == 0 for k < r: the compressed R): the products skip the zero blocks
 };
 
 template <int RPL>
@@ -1017,7 +1018,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
 }
 
 static void gemm(xk_handle *h, const XkGemmArgs &g) {
-  const int tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+  const int tiles = xk_gemm_grid(g);
   if (tiles <= 0) return;
   hipLaunchKernelGGL(xk_gemm_f64, dim3(tiles), dim3(64 * XK_GEMM_WAVES), 0, h->stream, g);
 }
@@ -1037,6 +1038,8 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
   g.C = h->d_Maug + c; g.scr = LDA; g.scc = 1;
   g.D = g.C; g.sdr = LDA; g.sdc = 1;
   g.M = c; g.N = n + 1; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 0;
+  static const int struct_env = env_int("XK_GEMM_STRUCT", 1);   // 0: every product as a general one (A/B switch)
+  g.tri_a = struct_env && u.tri;
   // extra column: z' = res + H corr_tot  (updater.cpp:126) lands next to W in the augmented matrix
   g.xcol = 1; g.bx = u.ct ? u.ct + u.col0 : nullptr; g.sbx = 1; g.dx = u.z; g.sdx = u.sz;
   g.cx = h->d_Maug + c + n; g.scx = LDA;
@@ -1052,6 +1055,8 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     g.C = h->d_Maug; g.scr = LDA; g.scc = 1;
     g.D = g.C; g.sdr = LDA; g.sdc = 1;
     g.M = c; g.N = c; g.K = u.kdim; g.alpha = 1.0; g.beta = 0.0; g.mode = 1;
+    g.tri_b = struct_env && u.tri;
+    g.sym_cols = struct_env ? c : 0;   // only the upper triangle of S is read (xk_chol_whole / xk_chol_step)
     g.diag = u.rdiag; g.diag_scalar = u.rscalar;
     gemm(h, g);
   }
@@ -1083,6 +1088,7 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
         s.C = h->d_Maug + (size_t)off * LDA + off; s.scr = LDA; s.scc = 1;
         s.D = s.C; s.sdr = LDA; s.sdc = 1;
         s.M = c - off; s.N = ncols - off; s.K = cb; s.alpha = -1.0; s.beta = 1.0; s.mode = 0;
+        s.sym_cols = struct_env ? c - off : 0;   // (the Schur complement of S: upper triangle only)
         gemm(h, s);
       }
     }
@@ -1101,6 +1107,7 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
     g.D = u.Pin; g.sdr = 1; g.sdc = n;
     g.C = u.Pout; g.scr = 1; g.scc = n;
     g.M = n; g.N = n + 1; g.K = c; g.alpha = -1.0; g.beta = 1.0; g.mode = 2;
+    g.sym_cols = struct_env ? n : 0;       // tiles below the diagonal: mirror images of the ones above
     // extra column: corr = X^T (L^-1 z') - corr_tot   (K z' - corr_tot, updater.cpp:126)
     g.xcol = 1; g.bx = h->d_X + c + n; g.sbx = LDA; g.ex = u.ct; g.cx = u.corr ? u.corr : h->d_corr; g.scx = 1;
     if (u.done_flag) { g.done_cnt = h->d_done_cnt; g.done_flag = u.done_flag; g.done_seq = u.done_seq; }
@@ -1124,6 +1131,7 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
   u.z = h->d_R + h->na; u.sz = h->C1P;           // residual column
   u.rdiag = nullptr; u.rscalar = h->sigma_img * h->sigma_img;  // vio_updater.cpp:508-509
   u.Pin = h->d_P; u.Pout = h->d_Pout; u.ct = d_ct; u.cov_update = cov_update;
+  u.tri = 1;                                      // d_R: zero below the diagonal (zeroed at creation, only the trapezoid is ever written)
   return u;
 }
 

@@ -64,11 +64,25 @@ struct XkGemmArgs {
   unsigned *done_cnt;
   unsigned long long *done_flag;
   unsigned long long done_seq;
+  // structure the caller vouches for (all zero = a general product):
+  //   tri_a: A[i][k] == 0 for k < i (the compressed measurement matrix, upper trapezoidal) -- row tile tm starts at k = 16 tm
+  //   tri_b: B[k][j] == 0 for k < j (its transpose)                                        -- column tile tn starts at k = 16 tn
+  //   sym_cols > 0: columns [0, sym_cols) of the output are a symmetric matrix of which only the tiles on and above the
+  //     diagonal are wanted (S: the Cholesky reads the upper triangle) -- or, in mode 2, of which the tiles below the diagonal
+  //     are written as the mirror image of the ones above (the same bits: the two operands of a mirrored entry are swapped sums)
+  int tri_a, tri_b, sym_cols;
 };
 
 #ifndef XK_GEMM_WAVES
 #define XK_GEMM_WAVES 4
 #endif
+// workgroups of a launch
+static inline int xk_gemm_grid(const XkGemmArgs &g) {
+  const int tiles_m = (g.M + 15) >> 4, tiles_n = (g.N + 15) >> 4, ts = g.sym_cols >> 4;
+  int n = 0;
+  for (int tm = 0; tm < tiles_m; ++tm) n += tiles_n - (g.sym_cols > 0 ? (tm < ts ? tm : ts) : 0);
+  return n;
+}
 __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) {
   // One 16 x 16 output tile per workgroup, K split over XK_GEMM_WAVES waves (these GEMMs are a few MFLOP each and pure
   // latency: with one wave per tile the 45 dependent MFMA steps of K = 180 and their three rounds of operand loads were
@@ -76,8 +90,23 @@ __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) 
   __shared__ double red[XK_GEMM_WAVES - 1][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_n = (g.N + 15) >> 4;
-  const int t = blockIdx.x;
-  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  // tile of this workgroup: row-major over the tiles that are wanted -- with sym_cols > 0 the tiles below the diagonal of the
+  // symmetric part (tn < min(tm, sym_cols / 16)) are not in the grid at all (xk_gemm_grid)
+  int tm, tn;
+  if (g.sym_cols > 0) {
+    const int ts = g.sym_cols >> 4;
+    int rest = blockIdx.x;
+    tm = 0;
+    for (;; ++tm) {
+      const int live = tiles_n - min(tm, ts);
+      if (rest < live) break;
+      rest -= live;
+    }
+    tn = min(tm, ts) + rest;
+  } else {
+    tm = (int)blockIdx.x / tiles_n;
+    tn = (int)blockIdx.x - tm * tiles_n;
+  }
   const int li = lane & 15, lk = lane >> 4;
   const int arow = tm * 16 + li, bcol = tn * 16 + li;
   const bool xc = g.xcol && bcol == g.N - 1;                    // this lane feeds the extra column
@@ -85,8 +114,9 @@ __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) 
   const double *ap = g.A + (long)arow * g.sar, *bp = xc ? g.bx : g.B + (long)bcol * g.sbc;
   const long sbr = xc ? g.sbx : g.sbr;
   xk_d4 acc = {0.0, 0.0, 0.0, 0.0};
-  const int kq = ((g.K + 4 * XK_GEMM_WAVES - 1) / (4 * XK_GEMM_WAVES)) * 4;   // K range of a wave, a multiple of the MFMA depth
-  const int kbeg = wave * kq, kend = min(g.K, kbeg + kq);
+  const int k0t = min(g.K, max(g.tri_a ? 16 * tm : 0, g.tri_b ? 16 * tn : 0));   // the operands are zero before k0t
+  const int kq = ((g.K - k0t + 4 * XK_GEMM_WAVES - 1) / (4 * XK_GEMM_WAVES)) * 4;   // K range of a wave, a multiple of the MFMA depth
+  const int kbeg = k0t + wave * kq, kend = min(g.K, kbeg + kq);
   // chunks of 64 with the NEXT chunk's 32 loads in flight while this one feeds the matrix core
   constexpr int CH = 16;   // MFMA steps per chunk
   double av[2][CH], bv[2][CH];
@@ -139,6 +169,7 @@ __global__ __launch_bounds__(64 * XK_GEMM_WAVES) void xk_gemm_f64(XkGemmArgs g) 
       if (g.mode == 1 && row == col) v += g.diag ? g.diag[row] : g.diag_scalar;
     }
     g.C[(long)row * g.scr + (long)col * g.scc] = v;
+    if (g.mode == 2 && g.sym_cols > 0 && tn > tm && col < g.sym_cols && col < g.M) g.C[(long)col * g.scr + (long)row * g.scc] = v;
   }
   if (g.done_flag) {
     if (g.xcol && tn == tiles_n - 1) __threadfence_system();   // the extra column may be host memory: its stores first
