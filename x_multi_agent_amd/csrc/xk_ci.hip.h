@@ -430,8 +430,15 @@ __global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
   for (int e = threadIdx.x; e < m * m; e += 512) {
     double g = 0.0, c = 0.0;
     for (int i = 0; i < a.k1; ++i) {
+      // the chunk partials of agent i: all loads in flight at once, added in chunk order (a load per addition, one after the
+      // other, was most of this kernel's 38 us)
+      double part[XK_CI_MAXCHUNK];
+#pragma unroll
+      for (int cb = 0; cb < XK_CI_MAXCHUNK; ++cb) part[cb] = (cb < a.nchunk) ? a.S[((size_t)i * XK_CI_MAXCHUNK + cb) * 576 + e] : 0.0;
       double v = 0.0;
-      for (int cb = 0; cb < a.nchunk; ++cb) v += a.S[((size_t)i * XK_CI_MAXCHUNK + cb) * 576 + e];
+#pragma unroll
+      for (int cb = 0; cb < XK_CI_MAXCHUNK; ++cb)
+        if (cb < a.nchunk) v += part[cb];
       g += v;
       c += v * (i == 0 ? 1.0 / a.w0 : 1.0 / a.w);
     }
