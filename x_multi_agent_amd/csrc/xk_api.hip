@@ -2118,16 +2118,9 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     int *dint = w.dint;
     // P_j: diagonal 3x3 blocks of the observed poses scaled by 1/w0 (:256-267), then applyCI (updater.cpp:144-161)
     const int L = trk_L0[j];
-    int *hc = h->h_ci_cols + 128 * j;            // per-track staging: no need to wait before the next track reuses it
-    for (int i = 0; i < L; ++i) {
-      const int pos = h->n_poses - L + i;
-      hc[2 * i] = XK_CORE + 3 * pos;
-      hc[2 * i + 1] = XK_CORE + 3 * pos + 3 * N;
-    }
-    h->h_ci_w[j] = 1.0 / w0;
-    HIPCHK(h, hipMemcpyAsync(dint + 32, hc, sizeof(int) * 2 * L, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(dscal + 1, h->h_ci_w + j, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    XkScaleArgs sc{h->d_P, h->d_tmpP, n, 2 * L, dint + 32, dscal + 1};
+    // (the blocks are those of the last L window poses: the kernel works their columns out itself -- no staging copies)
+    XkScaleArgs sc{h->d_P, h->d_tmpP, n, 2 * L, nullptr, nullptr, 1, h->n_poses - L, L, N, 1.0 / w0};
+    (void)dint; (void)dscal;
     hipLaunchKernelGGL(xk_scale_blocks, dim3(((size_t)n * n + 255) / 256), dim3(256), 0, h->stream, sc);
     UpdateSpec u;
     memset(&u, 0, sizeof(u));

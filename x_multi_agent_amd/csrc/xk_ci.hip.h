@@ -116,15 +116,27 @@ struct XkScaleArgs {
   int n, nblk;
   const int *cols;   // device: first column of each block
   const double *w;   // device scalar (w_result)
+  // arith != 0: the blocks are the position and attitude blocks of window poses [p0, p0 + L) -- first columns
+  // XK_CORE + 3 pos and XK_CORE + 3 N + 3 pos -- and the factor is wval: nothing to fetch, nothing to stage from the host
+  int arith, p0, L, N;
+  double wval;
 };
 __global__ void xk_scale_blocks(XkScaleArgs a) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)a.n * a.n) return;
   const int r = (int)(idx % a.n), c = (int)(idx / a.n);
   double v = a.P[idx];
-  for (int b = 0; b < a.nblk; ++b) {
-    const int c0 = a.cols[b];
-    if (r >= c0 && r < c0 + 3 && c >= c0 && c < c0 + 3) v *= *a.w;
+  if (a.arith) {
+    const int rb = (r - 15) / 3, cb = (c - 15) / 3;                 // 3 x 3 block coordinates behind the core states
+    if (r >= 15 && c >= 15 && rb == cb) {
+      const int pos = rb < a.N ? rb : rb - a.N;                     // position blocks, then attitude blocks
+      if (rb < 2 * a.N && pos >= a.p0 && pos < a.p0 + a.L) v *= a.wval;
+    }
+  } else {
+    for (int b = 0; b < a.nblk; ++b) {
+      const int c0 = a.cols[b];
+      if (r >= c0 && r < c0 + 3 && c >= c0 && c < c0 + 3) v *= *a.w;
+    }
   }
   a.Pj[idx] = v;
 }
@@ -447,13 +459,15 @@ __global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
     a.S_ci[e] = c;
   }
   __syncthreads();
-  // gamma = res^T S_gate^-1 res: right-looking Cholesky in LDS, lane i owns row i; then a column-oriented
-  // forward substitution (one wave: the barriers are wave barriers)
+  // gamma = res^T S_gate^-1 res: right-looking Cholesky in LDS, lane i owns row i; then a column-oriented forward substitution.
+  // m <= 24: ONE wave does it, with wave barriers (twenty-one steps of two 512-thread barriers each were most of this kernel)
   __shared__ double A[24][25], y[24];
   const int t = threadIdx.x;
-  for (int e = t; e < m * m; e += 512) A[e % m][e / m] = a.S_gate[e];
+  if (t >= 64) return;
+  auto wsync = [] { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
+  for (int e = t; e < m * m; e += 64) A[e % m][e / m] = a.S_gate[e];
   if (t < m) y[t] = a.res[t];
-  __syncthreads();
+  wsync();
   bool bad = false;
   for (int k = 0; k < m; ++k) {
     const double p = A[k][k];
@@ -461,19 +475,24 @@ __global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
     const double inv = 1.0 / sqrt(p);
     double lik = 0.0;
     if (t > k && t < m) { lik = A[t][k] * inv; A[t][k] = lik; }
-    __syncthreads();
-    if (t > k && t < m)
-      for (int j = k + 1; j <= t; ++j) A[t][j] -= lik * A[j][k];
+    wsync();
+    // trailing update A(r, j) -= L(r, k) L(j, k), k < j <= r: the (m - k - 1)^2 index pairs dealt over the 64 lanes (one lane per
+    // ROW walked its row with two dependent LDS reads per entry: 20 entries x 21 steps was most of the chain)
+    const int rem = m - k - 1;
+    for (int e = t; e < rem * rem; e += 64) {
+      const int r = k + 1 + e / rem, j = k + 1 + e % rem;
+      if (j <= r) A[r][j] -= A[r][k] * A[j][k];
+    }
     if (t == k) A[k][k] = p * inv;   // sqrt(p)
-    __syncthreads();
+    wsync();
   }
   double g = 0.0;
   for (int i = 0; i < m; ++i) {
     const double yi = y[i] / A[i][i];   // uniform
     g += yi * yi;
-    __syncthreads();
+    wsync();
     if (t > i && t < m) y[t] -= A[t][i] * yi;
-    __syncthreads();
+    wsync();
   }
   if (t == 0) *a.gamma = bad ? INFINITY : g;
 }
