@@ -2005,7 +2005,8 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     HIPCHK(h, hipMalloc((void **)&h->d_batch, sizeof(XkFeatBatch) * 64));
     HIPCHK(h, hipHostMalloc((void **)&h->h_batch, sizeof(XkFeatBatch) * 64));
     HIPCHK(h, hipHostMalloc((void **)&h->h_ci_cols, sizeof(int) * (8 * 128 + 8)));   // + the per-track own-gate flags
-    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_w, sizeof(double) * 16));   // [0..7] 1/w0, [8..15] joint gamma
+    HIPCHK(h, hipHostMalloc((void **)&h->h_ci_w, sizeof(double) * 48));   // [0..7] 1/w0, [8..15] joint gamma; [16 + 4 j ..] track j: own verdict, joint gamma, marker
+    memset(h->h_ci_w, 0, sizeof(double) * 48);
     hipFuncSetAttribute((const void *)xk_ci_hph, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     HIPCHK(h, hipEventCreateWithFlags(&h->ci_fork, hipEventDisableTiming));
     for (int j = 1; j < 8; ++j) {
@@ -2034,6 +2035,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   int trk_L0[8], trk_dof[8];
   // The shared tracks are independent until applyCI (every P_j is built from the same prior), and a track's stages are a chain of
   // seven small launches (~160 us at 8 agents): track j >= 1 runs its chain on a side stream next to track 0's.
+  const unsigned long long ci_seq = ++h->done_seq;
   static const int side_env = env_int("XK_CI_SIDE_STREAMS", 1);
   const bool side = side_env && n_tracks > 1;
   if (side) HIPCHK(h, hipEventRecord(h->ci_fork, h->stream));
@@ -2100,19 +2102,41 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     for (int i = 0; i < k1; ++i) { ha.H[i] = pa.H[i]; ha.P[i] = aP[i]; ha.n[i] = n; }
     const int nchunk = (n + XK_CI_CHUNK - 1) / XK_CI_CHUNK;
     hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), sj, ha);
-    XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal};
+    // the two gate decisions (own chi-square test :180, joint test :243-250) come back per track: written by the kernel into
+    // pinned host memory, a marker behind them
+    XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal,
+                       dint, h->h_ci_w + 16 + 4 * j, reinterpret_cast<unsigned long long *>(h->h_ci_w + 16 + 4 * j + 2), ci_seq};
     hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, sj, ca);
-    // the two gate decisions (own chi-square test :180, joint test :243-250) come back per track
-    HIPCHK(h, hipMemcpyAsync(&h->h_ci_cols[1024 + j], dint, sizeof(int), hipMemcpyDeviceToHost, sj));
-    HIPCHK(h, hipMemcpyAsync(&h->h_ci_w[8 + j], dscal, sizeof(double), hipMemcpyDeviceToHost, sj));
     if (side && j > 0) { HIPCHK(h, hipEventRecord(h->ci_join[j], sj)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ci_join[j], 0)); }
     trk_L0[j] = aL[0];
     trk_dof[j] = 2 * Ltot - 3;
     if (trk_dof[j] >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
   }
-  if (n_tracks > 0) HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (n_tracks > 0) {
+    // wait for the markers of all tracks (XK_SPIN_DONE=0, or a marker that does not come within ~1 s: the runtime's signal)
+    static const int spin_env = env_int("XK_SPIN_DONE", 1);
+    bool seen = spin_env != 0;
+    for (int j = 0; j < n_tracks && seen; ++j) {
+      const unsigned long long *mk = reinterpret_cast<const unsigned long long *>(h->h_ci_w + 16 + 4 * j + 2);
+      seen = false;
+      for (long spins = 0; spins < 40000000L && !(seen = (__atomic_load_n(mk, __ATOMIC_ACQUIRE) == ci_seq)); ++spins) {
+        if ((spins & 255) == 255 && __atomic_load_n(&h->d_status[1], __ATOMIC_RELAXED) != 0) break;
+        __builtin_ia32_pause();
+      }
+    }
+    if (!seen) {
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (int j = 1; j < n_tracks && side; ++j) HIPCHK(h, hipStreamSynchronize(h->ci_stream[j]));
+    }
+  }
+  int last_fused = -1;
+  for (int j = 0; j < n_tracks; ++j)
+    if (h->h_ci_w[16 + 4 * j] != 0.0 && h->h_ci_w[16 + 4 * j + 1] < XK_CHI2_095[trk_dof[j]]) last_fused = j;
+  static const int spin_done = env_int("XK_SPIN_DONE", 1);
+  unsigned long long *done = reinterpret_cast<unsigned long long *>(h->h_out + h->n + 2);
+  unsigned long long wait_seq = 0;
   for (int j = 0; j < n_tracks; ++j) {
-    if (!h->h_ci_cols[1024 + j] || !(h->h_ci_w[8 + j] < XK_CHI2_095[trk_dof[j]])) continue;
+    if (h->h_ci_w[16 + 4 * j] == 0.0 || !(h->h_ci_w[16 + 4 * j + 1] < XK_CHI2_095[trk_dof[j]])) continue;
     const CiWs w = ci_ws(j);
     double *Hs = w.Hs, *S2 = w.S2, *dres = w.dres, *dscal = w.dscal;
     int *dint = w.dint;
@@ -2129,13 +2153,24 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     u.z = dres; u.sz = 1;
     u.S = S2; u.ssr = 1; u.ssc = m;
     u.Pin = h->d_tmpP; u.Pout = h->d_Pout; u.ct = nullptr; u.cov_update = 1;   // every entry starts from the same prior
+    if (j == last_fused && !corrections && spin_done) { u.done_flag = done; u.done_seq = wait_seq = ++h->done_seq; }   // the round's last launch marks its end
     int rc = launch_update(h, u);
     if (rc != XK_OK) return rc;
     if (corrections) HIPCHK(h, hipMemcpyAsync(corrections + (size_t)fused * n, h->d_corr, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     ++fused;                                       // (the next track's gate decision, or read_status below, waits)
   }
   if (fused) {
-    int rc = read_status(h);
+    bool seen = false;
+    if (wait_seq) {   // (as xk_apply_update: the marker is the last store of the last kernel; a status word ends the wait early)
+      for (long spins = 0; spins < 40000000L && !(seen = (__atomic_load_n(done, __ATOMIC_ACQUIRE) == wait_seq)); ++spins) {
+        if ((spins & 255) == 255 && __atomic_load_n(&h->d_status[1], __ATOMIC_RELAXED) != 0) break;
+        __builtin_ia32_pause();
+      }
+      if (seen) h->done_seen = wait_seq;
+    }
+    int rc;
+    if (seen) { stage_stream_idle(h); rc = eval_status(h, h->d_status[0], h->d_status[1], false); }
+    else rc = read_status(h);
     if (rc != XK_OK) return rc;
     std::swap(h->d_P, h->d_Pout);   // applyCI overwrites P: the last fused entry is the resident covariance
     h->have_rows = h->have_R = false;

@@ -434,6 +434,13 @@ struct XkCiCombineArgs {
   const double *res;    // m
   double *S_gate, *S_ci;  // m x m column-major
   double *gamma;
+  // optional: the two gate results of the track written straight into pinned host memory -- host_gate[0] = own chi-square
+  // verdict (*own_inlier), host_gate[1] = joint gamma -- and then host_seq into *host_marker (system-scope release): a host that
+  // polls the marker has the decisions without a copy or the runtime's completion signal
+  const int *own_inlier;
+  double *host_gate;
+  unsigned long long *host_marker;
+  unsigned long long host_seq;
 };
 // 512 threads: one entry of the m x m matrices per thread for the sum over agents and chunks (k1 * nchunk
 // dependent-free loads each; on 64 threads this loop was 100 of the kernel's 110 us), then the small Cholesky.
@@ -494,5 +501,13 @@ __global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
     if (t > i && t < m) y[t] -= A[t][i] * yi;
     wsync();
   }
-  if (t == 0) *a.gamma = bad ? INFINITY : g;
+  if (t == 0) {
+    const double gam = bad ? INFINITY : g;
+    *a.gamma = gam;
+    if (a.host_marker) {
+      __hip_atomic_store(a.host_gate, (double)*a.own_inlier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.host_gate + 1, gam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.host_marker, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
