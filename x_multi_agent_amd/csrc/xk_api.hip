@@ -2071,7 +2071,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       const int src = (i < k) ? i + 1 : 0;
       ga.q[i] = aq[src]; ga.p[i] = ap[src]; ga.obs[i] = aobs[src]; ga.np[i] = anp[src]; ga.L[i] = aL[src];
     }
-    hipLaunchKernelGGL(xk_ci_gather, dim3(1), dim3(64), 0, sj, ga);
+    hipLaunchKernelGGL(xk_ci_gather, dim3(k1), dim3(64), 0, sj, ga);
     XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint + 16, nullptr, 0};
     hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, sj, ta);
     // per-agent column-space rows, one workgroup per agent (:168-204)
