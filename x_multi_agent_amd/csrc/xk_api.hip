@@ -1851,7 +1851,7 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
     pa.n[i] = (i == 0) ? n : m_n[i - 1];
     pa.H[i] = Hs + (size_t)m * nmax * i;
   }
-  hipLaunchKernelGGL(xk_ci_project, dim3(1), dim3(256), 0, h->stream, pa);
+  hipLaunchKernelGGL(xk_ci_project, dim3(k1), dim3(256), 0, h->stream, pa);
   // S_gate = sum H_i P_i H_i^T + sigma^2 I (:217-237) and the CI-weighted S (ci.cpp:78-85 + :255)
   const double w0 = 1.0 - (double)k * ci_msckf_w, var_img = sigma_img * sigma_img;
   for (int i = 0; i < k1; ++i) {
@@ -2094,7 +2094,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     memset(&pa, 0, sizeof(pa));
     pa.k1 = k1; pa.res = dres;
     for (int i = 0; i < k1; ++i) { pa.up[i] = up + i * upsz; pa.n[i] = n; pa.H[i] = Hs + (size_t)m * n * i; }
-    hipLaunchKernelGGL(xk_ci_project, dim3(1), dim3(256), 0, sj, pa);
+    hipLaunchKernelGGL(xk_ci_project, dim3(k1), dim3(256), 0, sj, pa);
     // S_i = H_i P_i H_i^T for all agents, then the gate / CI combinations and gamma
     XkCiHphArgs ha;
     memset(&ha, 0, sizeof(ha));

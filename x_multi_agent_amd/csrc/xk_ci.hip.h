@@ -307,12 +307,15 @@ __global__ __launch_bounds__(256) void xk_ci_project(XkCiProjArgs a) {
     }
     __syncthreads();
   }
-  if (tid < m) {                     // res = A^T res_pf, A = Q[:, 3:]
+  if (blockIdx.x == 0 && tid < m) {  // res = A^T res_pf, A = Q[:, 3:]
     double s = 0;
     for (int r = 0; r < mr; ++r) s += Q[r][3 + tid] * rp[r];
     a.res[tid] = s;
   }
-  for (int i = 0; i < a.k1; ++i) {     // H_i = A[3i:3i+3, :]^T * up_jac_i
+  // one workgroup per agent: every one forms the (tiny) Q itself and writes its own agent's Jacobian (eight agents one after
+  // the other, each behind its own round of load latency, were 16 of this kernel's 26 us)
+  {                                    // H_i = A[3i:3i+3, :]^T * up_jac_i
+    const int i = blockIdx.x;
     const double *uj = a.up[i];
     for (int col = tid; col < a.n[i]; col += 256) {
       const double u0 = uj[3 * (size_t)col], u1 = uj[3 * (size_t)col + 1], u2 = uj[3 * (size_t)col + 2];
