@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
   __syncthreads();
   // gamma = res^T S_gate^-1 res: right-looking Cholesky in LDS, lane i owns row i; then a column-oriented forward substitution.
   // m <= 24: ONE wave does it, with wave barriers (twenty-one steps of two 512-thread barriers each were most of this kernel)
-  __shared__ double A[24][25], y[24];
+  __shared__ double A[24][25], y[24], invd[24];
   const int t = threadIdx.x;
   if (t >= 64) return;
   auto wsync = [] { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); };
@@ -482,23 +482,28 @@ __global__ __launch_bounds__(512) void xk_ci_combine(XkCiCombineArgs a) {
   for (int k = 0; k < m; ++k) {
     const double p = A[k][k];
     if (!(p > 0)) bad = true;
-    const double inv = 1.0 / sqrt(p);
+    // 1 / sqrt(p) from the hardware seed and two Newton steps, as every other pivot chain here (the IEEE sqrt and division
+    // expansions were half of a step's 1400 clocks)
+    double inv = __builtin_amdgcn_rsq(p);
+    inv = inv * fma(-0.5 * p * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * p * inv, inv, 1.5);
+    if (t == k) invd[k] = inv;
     double lik = 0.0;
     if (t > k && t < m) { lik = A[t][k] * inv; A[t][k] = lik; }
     wsync();
-    // trailing update A(r, j) -= L(r, k) L(j, k), k < j <= r: the (m - k - 1)^2 index pairs dealt over the 64 lanes (one lane per
-    // ROW walked its row with two dependent LDS reads per entry: 20 entries x 21 steps was most of the chain)
-    const int rem = m - k - 1;
-    for (int e = t; e < rem * rem; e += 64) {
-      const int r = k + 1 + e / rem, j = k + 1 + e % rem;
-      if (j <= r) A[r][j] -= A[r][k] * A[j][k];
-    }
+    // trailing update A(r, j) -= L(r, k) L(j, k), k < j <= r, dealt over the 64 lanes (one lane per ROW walked its row with two
+    // dependent LDS reads per entry: 20 entries x 21 steps was most of the chain)
+    for (int r0 = k + 1; r0 < m; r0 += 8)          // 8 x 8 patches of the trailing triangle (no index divisions in the chain)
+      for (int j0 = k + 1; j0 <= r0 + 7 && j0 < m; j0 += 8) {
+        const int r = r0 + (t >> 3), j = j0 + (t & 7);
+        if (r < m && j <= r) A[r][j] -= A[r][k] * A[j][k];
+      }
     if (t == k) A[k][k] = p * inv;   // sqrt(p)
     wsync();
   }
   double g = 0.0;
   for (int i = 0; i < m; ++i) {
-    const double yi = y[i] / A[i][i];   // uniform
+    const double yi = y[i] * invd[i];   // uniform (1 / L(i,i) from the factorisation)
     g += yi * yi;
     wsync();
     if (t > i && t < m) y[t] -= A[t][i] * yi;
