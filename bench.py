@@ -3,8 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 4]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run);
-rank r is agent r with its own synthetic window/tracks/prior (seed
+One process per GPU.  N > 1: either a launcher started the ranks (torch.distributed.run -- RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) or the plain command `python bench.py --gpus N` starts them itself by
+re-running under torch.distributed.run on 127.0.0.1; a world size that is not --gpus is refused.  Rank r is agent r with its own synthetic window/tracks/prior (seed
 0x5EED0000 + 1000*config + agent).  A step = one Updater::update()-equivalent
 visual update (per-feature build -> CAQR compression -> Kalman update) on
 inputs already resident in HBM; P stays on the device.  Every CI_EVERY steps
@@ -277,9 +278,28 @@ def other_configs(engine, synth, with_cpu=True):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under torch.distributed.run with N ranks on
+    this node (rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, XK_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="agents = ranks = GPUs; default: WORLD_SIZE if a launcher set it, else 1")
     ap.add_argument("--steps", type=int, default=1000)     # ~0.65 s of timed work at the headline size
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=4)
@@ -296,11 +316,22 @@ def main():
     ap.add_argument("--dump-posterior", default=None, help="rank 0 / the dry-run rank: save the covariance the last CI round fused (no round: the resident one) as .npy")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dry = args.dry_run_ranks >= 2
+    launched = "WORLD_SIZE" in os.environ          # torch.distributed.run (the driver's form for N > 1) or another launcher
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not launched and not dry:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and become their launcher
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dry = args.dry_run_ranks >= 2
+    if not dry and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a "
+                         f"line whose n_gpus is not what was asked for")
     if dry and world != 1:
         raise SystemExit("--dry-run-ranks is a single-process mode")
     real_world = world
@@ -336,6 +367,9 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     xdev = f"cuda:{dev}" if backend == "nccl" else "cpu"
+    pg_world = dist.get_world_size() if dist is not None else 1
+    if not dry and pg_world != args.gpus:
+        raise SystemExit(f"bench.py: the process group has {pg_world} ranks, --gpus asked for {args.gpus}")
 
     N, K, M = synth.CONFIGS[args.config]
     ci_every = 6 if args.config == 5 else CI_EVERY    # config 5: 5 Hz requests at a 30 Hz update rate
@@ -614,6 +648,10 @@ def main():
         out = {"metric": "EKF updates/sec (window=30, 400 MSCKF feats)" if args.config in (4, 5)
                else f"EKF updates/sec (config {args.config})",
                "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "process_group": {"backend": (backend if world > 1 else None), "ranks": pg_world,
+                                 "launcher": ("bench.py itself (torch.distributed.run)" if os.environ.get("XK_BENCH_SELF_LAUNCHED")
+                                              else "external" if launched else None),
+                                 "devices_visible": torch.cuda.device_count(), "device_of_rank0": dev},
                "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: one agent per GPU, window N={N}, "

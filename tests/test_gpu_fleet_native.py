@@ -65,6 +65,29 @@ def test_bench_multi_rank_path_on_one_gpu(config, ranks):
     assert d["config"]["ci_rounds_rank0"] >= 2 and d["config"]["ci_fused_rank0"] > 0
 
 
+@pytest.mark.parametrize("config", [4, 5])
+def test_plain_bench_command_starts_its_own_ranks(config):
+    """`python bench.py --gpus 2 ...` with NO external launcher must run two ranks (it re-runs itself
+    under torch.distributed.run) and say so in the line; the two ranks share this box's GPU and exchange over gloo."""
+    d = _bench(["--gpus", "2", "--steps", "24", "--warmup", "2", "--config", str(config), "--no-cpu", "--no-frame-loop"],
+               {"XK_BENCH_BACKEND": "gloo", "XK_BENCH_DEVICE": "0"})
+    assert d["n_gpus"] == 2 and d["process_group"]["ranks"] == 2 and d["process_group"]["launcher"].startswith("bench.py itself")
+    assert d["config"]["agents"] == 2 and d["config"]["ci_rounds_rank0"] >= 2 and d["config"]["ci_fused_rank0"] > 0
+    assert d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_refuses_a_world_that_is_not_what_gpus_asked_for():
+    """--gpus 4 under a launcher that started 2 ranks: no line, non-zero exit (a line with another n_gpus than the caller
+    asked for would be read as the 4-GPU number)."""
+    env = dict(os.environ, XK_BENCH_BACKEND="gloo", XK_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29688", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "1", "--no-cpu",
+           "--no-frame-loop"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "WORLD_SIZE=2" in r.stderr
+
+
 def _bench(args, env_extra=None, launcher=None, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.update(env_extra or {})
