@@ -4,7 +4,8 @@
 // against the same IMU stream through the reference-semantics mode (every State owns its covariance):
 //   usage: xk_ring_wrap_example [n_steps] [buffer_sz]      prints "OK <max rel diff>" or "FAIL ..."
 //          xk_ring_wrap_example during_update [buffer_sz]  the ring wraps onto the resident covariance WHILE an update is in
-//                                                           flight on it (the IMU thread outruns a slow update): must throw
+//                                                           flight on it (the IMU thread outruns a slow update): that update
+//                                                           is discarded as in the reference (ekf.cpp:229-239)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,7 +62,9 @@ struct SlowUpdater : VioUpdater {
   }
 };
 
-static int wrap_during_update(int bsz) {
+// One update lapped by the IMU thread.  Returns the tail covariance afterwards; *discarded = the update came back as nullopt;
+// *threw = Ekf::processImu refused (resident mode, no saved prior: more than kWrapMargin samples during one update).
+static Matrix lapped_update(bool resident, int bsz, bool *discarded, bool *threw) {
   const int N = 4;
   SlowUpdater updater(0, N, 0, 8, 1e-3);
   Propagator prop(Vector3(0, 0, -9.81), ImuNoise());
@@ -69,12 +72,12 @@ static int wrap_during_update(int bsz) {
   prop.setEngine(updater.engine());
   Ekf ekf(updater);
   ekf.set(bsz, State(N, 0), &prop, 0.0025);
-  ekf.setResident(true);
+  ekf.setResident(resident);
   State s0(N, 0);
   const int n = s0.nErrorStates();
   s0.cov_.resize(n, n);
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) s0.cov_(i, j) = i == j ? 1e-2 : 0.0;
+    for (int j = 0; j < n; ++j) s0.cov_(i, j) = i == j ? 1e-2 * (1 + i % 5) : 0.0;
   s0.time_ = 1.0;
   ekf.initializeFromState(s0);
   for (int k = 0; k <= 2; ++k) ekf.processImu(1.0 + 0.005 * k, (unsigned)k, Vector3(0.1, 0, 0), Vector3(0, 0.1, 9.81));
@@ -86,16 +89,40 @@ static int wrap_during_update(int bsz) {
   updater.setWindow(2, {});
   updater.setMeasurement(meas);
   updater.ekf = &ekf; updater.burst = bsz + 1; updater.t0 = meas.timestamp;
+  *discarded = *threw = false;
   try {
-    (void)ekf.processUpdateMeasurement();
+    *discarded = !ekf.processUpdateMeasurement().has_value();
   } catch (const std::runtime_error &e) {
-    printf("OK threw: %s\n", e.what());
-    // the guard is released with the exception: the IMU stream goes on
-    ekf.processImu(meas.timestamp + 0.005 * (bsz + 2), 5000u, Vector3(0.1, 0, 0), Vector3(0, 0.1, 9.81));
-    return 0;
+    *threw = true;
+    printf("threw: %s\n", e.what());
   }
-  printf("FAIL no exception: the covariance was propagated under a running update\n");
-  return 1;
+  // the IMU stream goes on either way
+  updater.burst = 0;
+  ekf.processImu(meas.timestamp + 0.005 * (bsz + 2), 5000u, Vector3(0.1, 0, 0), Vector3(0, 0.1, 9.81));
+  return *threw ? Matrix() : ekf.covarianceAt(-1);
+}
+
+// The ring wraps onto the slot of the update in flight.  The reference overwrites the slot and loses that update (ekf.cpp:229-239);
+// so must the mirror with a resident covariance -- same nullopt, same covariances afterwards as the reference-semantics mode, in
+// which every State owns its covariance.  A ring with more than kWrapMargin (32) free slots at the start of the update saves no
+// prior: being lapped THEN (33+ IMU samples during one update) is the one case that throws.
+static int wrap_during_update(int bsz) {
+  bool d_res, t_res, d_ref, t_ref;
+  const Matrix a = lapped_update(true, bsz, &d_res, &t_res);
+  if (bsz - 1 >= 32) {
+    if (t_res) { printf("OK threw (no saved prior at %d free slots)\n", bsz - 1); return 0; }
+    printf("FAIL no exception although no prior was saved\n");
+    return 1;
+  }
+  const Matrix b = lapped_update(false, bsz, &d_ref, &t_ref);
+  if (t_res || t_ref) { printf("FAIL threw (resident %d, reference semantics %d)\n", (int)t_res, (int)t_ref); return 1; }
+  if (!d_res || !d_ref) { printf("FAIL the lapped update was not discarded (resident %d, reference semantics %d)\n", (int)d_res, (int)d_ref); return 1; }
+  double num = 0, den = 0;
+  for (size_t i = 0; i < a.size(); ++i) { num += (a.data()[i] - b.data()[i]) * (a.data()[i] - b.data()[i]); den += b.data()[i] * b.data()[i]; }
+  const double relv = std::sqrt(num / den);
+  if (!(relv <= 1e-12)) { printf("FAIL rel=%.3e between the resident covariance and the reference semantics after a discarded update\n", relv); return 1; }
+  printf("OK discarded, rel %.3e\n", relv);
+  return 0;
 }
 
 int main(int argc, char **argv) {

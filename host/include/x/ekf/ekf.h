@@ -55,5 +55,15 @@ class Ekf {
   InitStatus init_status_ = kNotInitialized;
   bool resident_ = false, compose_steps_ = true;
   bool update_in_flight_ = false;          // resident: updater_.update() is running on the device covariance (guarded by mutex_)
+  // resident: the ring wrapped onto the slot of the update in flight (ekf.cpp:229-239: the reference overwrites the slot and discards
+  // that update when it comes back).  The prior was saved on the device before the update started (only when the ring was within
+  // kWrapMargin slots of wrapping); the IMU steps that pass over the slot meanwhile are composed here and applied to the restored
+  // prior once the update has returned.
+  static constexpr int kWrapMargin = 32;
+  bool snapshot_valid_ = false, update_invalidated_ = false;
+  int cov_target_ = -1;
+  CoreCovMatrix deferred_phi_, deferred_q_;
+  bool beginResidentUpdate(int idx);       // under mutex_: advance the covariance, arm the guard, save the prior if a wrap is possible
+  bool endResidentUpdate();                // under mutex_: false = the update was discarded (prior restored, deferred steps applied)
 };
 }  // namespace x

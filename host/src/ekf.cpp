@@ -109,14 +109,31 @@ std::optional<State> Ekf::processImu(double timestamp, unsigned int seq, const V
   // so does this, after moving the device covariance one slot on (it then belongs to the oldest state that survives).
   // ... unless an update is in flight on that very covariance (updater_.update() runs WITHOUT the mutex, ekf.cpp:186-205, on the
   // same engine handle and stream): propagating it now would rewrite the prior under the update's feet, from a second thread
-  // inside a handle that is not thread-safe.  It takes buffer_sz - 1 IMU samples during ONE update to get here; the reference
-  // would discard that update (the slot's time no longer matches, ekf.cpp:229-239) with every State still owning a covariance,
-  // which a single resident covariance cannot reproduce -- so this is an error, loudly, not silent corruption.
-  if (resident_ && next == cov_idx_ && update_in_flight_)
-    throw std::runtime_error("Ekf::processImu: the state ring wrapped onto the resident covariance while an update is in flight "
-                             "(state_buffer_sz too small for the update latency)");
-  if (resident_ && next == cov_idx_ && !advanceDeviceCovariance((cov_idx_ + 1) % (int)buffer_.size()))
+  // inside a handle that is not thread-safe.  The reference overwrites the slot and DISCARDS that update when it comes back (the
+  // slot's time no longer matches, ekf.cpp:229-239: a warning and nullopt).  Same here: the slot is overwritten, the update is
+  // marked as discarded, and the step that would have carried the covariance past the slot is composed on the host and applied
+  // to the prior -- saved on the device when the update started, because the ring was about to wrap -- once the update has
+  // returned (endResidentUpdate).  Only an update that started with more than kWrapMargin free slots and still got lapped
+  // (that many IMU samples during ONE update) has no saved prior: that, and only that, is an error.
+  const int sz_ring = (int)buffer_.size();
+  const int cov_slot = update_invalidated_ ? cov_target_ : cov_idx_;
+  if (resident_ && next == cov_slot && update_in_flight_) {
+    if (!snapshot_valid_)
+      throw std::runtime_error("Ekf::processImu: the state ring wrapped onto the resident covariance while an update is in flight "
+                               "and more than kWrapMargin IMU samples arrived during that one update: unrecoverable");
+    if (!update_invalidated_) {
+      update_invalidated_ = true;
+      deferred_phi_ = CoreCovMatrix::Identity();
+      deferred_q_ = CoreCovMatrix::Zero();
+    }
+    const int to = (cov_slot + 1) % sz_ring;            // the oldest state that survives: its recorded step, before a later wrap reuses the slot
+    const CoreCovMatrix fq = mul15_nt(mul15(f_d_[to], deferred_q_), f_d_[to]);
+    for (int k = 0; k < 225; ++k) deferred_q_.m[k] = fq.m[k] + q_d_[to].m[k];
+    deferred_phi_ = mul15(f_d_[to], deferred_phi_);
+    cov_target_ = to;
+  } else if (resident_ && next == cov_idx_ && !advanceDeviceCovariance((cov_idx_ + 1) % sz_ring)) {
     throw std::runtime_error("Ekf: cannot advance the resident covariance past the slot the ring overwrites");
+  }
   State &next_state = buffer_[next];
   next_state.setImu(timestamp, seq, w_m, a_m_smoothed);
   if (!propagator_) throw std::runtime_error("Ekf::processImu: no propagator");
@@ -205,6 +222,34 @@ Matrix Ekf::covarianceAt(int idx) {
   return P;
 }
 
+// resident mode, under mutex_: the device covariance goes to slot idx, the guard is armed, and -- if the IMU thread could lap the
+// ring during this update (fewer than kWrapMargin free slots) -- the prior is saved on the device (one asynchronous copy)
+bool Ekf::beginResidentUpdate(int idx) {
+  if (!advanceDeviceCovariance(idx)) return false;                           // measurement older than the last update
+  const int sz = (int)buffer_.size(), live = (tail_ - idx + sz) % sz;
+  update_in_flight_ = true;
+  update_invalidated_ = false;
+  snapshot_valid_ = false;
+  if (sz - 1 - live < kWrapMargin) {
+    check(updater_.engine(), xk_snapshot_P(updater_.engine(), 0), "xk_snapshot_P");
+    snapshot_valid_ = true;
+  }
+  return true;
+}
+
+// resident mode, under mutex_, after the plugin has returned (or thrown).  false: the IMU thread overwrote the slot meanwhile, the
+// update is discarded as in ekf.cpp:229-239 -- the prior comes back and takes the IMU steps that passed over the slot.
+bool Ekf::endResidentUpdate() {
+  update_in_flight_ = false;
+  if (!update_invalidated_) return true;
+  update_invalidated_ = false;
+  xk_handle *xk = updater_.engine();
+  check(xk, xk_snapshot_P(xk, 1), "xk_snapshot_P");
+  check(xk, xk_cov_propagate(xk, deferred_phi_.m, 15, deferred_q_.m, 15), "xk_cov_propagate");
+  cov_idx_ = cov_target_;
+  return false;
+}
+
 std::optional<State> Ekf::processUpdateMeasurement() {                       // ekf.cpp:179-213
   if (init_status_ != kInitialized) return std::nullopt;
   int idx;
@@ -212,21 +257,23 @@ std::optional<State> Ekf::processUpdateMeasurement() {                       // 
   if (idx < 0) return std::nullopt;
   if (resident_) {
     std::lock_guard<std::mutex> g(mutex_);
-    if (!advanceDeviceCovariance(idx)) return std::nullopt;                  // measurement older than the last update
-    update_in_flight_ = true;
+    if (!beginResidentUpdate(idx)) return std::nullopt;
   }
   State update_state = buffer_[idx];        // copy, not under the lock (as the reference); no covariance when resident
   try {
     updater_.update(update_state);          // <- plugin call; the mutex is NOT held
   } catch (...) {
     std::lock_guard<std::mutex> g(mutex_);
-    update_in_flight_ = false;
+    if (resident_) (void)endResidentUpdate();
     throw;
   }
   bool ok;
-  { std::lock_guard<std::mutex> g(mutex_); update_in_flight_ = false; ok = repropagateFromStateAtIdx(update_state, idx); }
+  {
+    std::lock_guard<std::mutex> g(mutex_);
+    ok = (!resident_ || endResidentUpdate()) && repropagateFromStateAtIdx(update_state, idx);
+  }
   if (ok) return update_state;
-  return std::nullopt;
+  return std::nullopt;                      // (the reference: "state buffer overwritten during update", the update is lost)
 }
 
 std::optional<State> Ekf::processOthersMeasurement(double timestamp) {       // ekf.cpp:143-176
@@ -236,19 +283,21 @@ std::optional<State> Ekf::processOthersMeasurement(double timestamp) {       // 
   if (idx < 0) return std::nullopt;
   if (resident_) {
     std::lock_guard<std::mutex> g(mutex_);
-    if (!advanceDeviceCovariance(idx)) return std::nullopt;
-    update_in_flight_ = true;
+    if (!beginResidentUpdate(idx)) return std::nullopt;
   }
   State update_state = buffer_[idx];
   try {
     updater_.collaborativeUpdate(update_state);
   } catch (...) {
     std::lock_guard<std::mutex> g(mutex_);
-    update_in_flight_ = false;
+    if (resident_) (void)endResidentUpdate();
     throw;
   }
   bool ok;
-  { std::lock_guard<std::mutex> g(mutex_); update_in_flight_ = false; ok = repropagateFromStateAtIdx(update_state, idx); }
+  {
+    std::lock_guard<std::mutex> g(mutex_);
+    ok = (!resident_ || endResidentUpdate()) && repropagateFromStateAtIdx(update_state, idx);
+  }
   if (ok) return update_state;
   return std::nullopt;
 }

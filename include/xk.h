@@ -361,26 +361,16 @@ int xk_run_steps(xk_handle *h, double sigma_img, int steps);
  * waiting for rows of R, 9 more rows passed the gates than the tiles of the launch hold -- not a co-residency problem: the fast
  * path stays armed for smaller stacks).  A launch that
  * gives up costs one bounded retry (<= 2 ms) and the update is redone by the multi-launch schedule with the same result; the
- * handle tries the fast path again after XK_CAQR_REARM (64) clean updates, doubling that distance at every further give-up.
+ * handle tries the fast path again after "caqr_rearm" (64) clean updates, doubling that distance at every further give-up.
  * xk_last_error() carries the same information as text.  Any pointer may be NULL. */
 int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason);
 
-/* Experiment switches / test hooks of the compression on a live handle.  Their defaults are read from the environment ONCE, at
- * xk_create (XK_CAQR_RESIDENT, XK_CAQR_RESIDENT_POISON, XK_CAQR_TEST_STALL, XK_CAQR_TALL26, XK_CAQR_REARM) -- the per-update path
- * calls no getenv.  Names: "caqr_resident" (0: multi-launch schedule everywhere), "caqr_poison" (1: raise the abort word before
- * every single launch -- it gives up, the host redoes the update), "caqr_test_stall" (1: one workgroup of the single launch
- * never shows up), "caqr_tall26", "caqr_rearm".  Unknown name: XK_EINVAL.  No counterpart in the reference. */
+/* Operational switches of the compression on a live handle.  "caqr_resident": 0 = the multi-launch schedule serves every update
+ * (e.g. a GPU this process knowingly shares), 1 (default) = the single launch where the shape allows it; "caqr_rearm": clean
+ * multi-launch updates after which a single-launch path that gave up is tried again (default 64, doubling at every further give-up).
+ * Unknown name: XK_EINVAL.  The release library reads nothing from the environment; the experiment switches, test hooks, debug
+ * exports and probe kernels of the lab build are declared in xk_lab.h.  No counterpart in the reference. */
 int xk_set_option(xk_handle *h, const char *name, int value);
-
-/* Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST_DBG=1), for tools/exp/pipe_trace.py: per panel k,
- * out[16k ..] = one tile workgroup, out[512 + 16k ..] = one first-level workgroup, out[1024 + 16k ..] = one last-level
- * workgroup (phase by phase), out[1536 ..] = start-up and exit.  n_out <= 256 + 64 * 256. */
-int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out);
-
-/* Micro-benchmark of the fp64 ceiling this path is priced against: a grid of
- * waves issuing independent v_mfma_f64_16x16x4_f64 (use_mfma=1) or v_fma_f64
- * (use_mfma=0) chains.  Reports sustained TFLOP/s. */
-int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ behaviour:
       (distance, train index) order -- the brute-force matcher keeps the earlier index on ties (strict comparisons
       while inserting into the top-k list).  OpenCV is absent from this image: this ordering is the documented /
       observed behaviour, not something run here.
-PARITY PINNING: the vocabulary is pinned -- tests/golden/vocab_*.npz are the reference's own Vocabulary/*.yaml data
+PARITY PINNING: the vocabulary is pinned -- x_multi_agent_amd/data/vocab_*.npz are the reference's own Vocabulary/*.yaml data
 files unpacked by tests/golden/make_vocab_fixture.py (with the reference's own QuickLZ decoder).  The reference has
 no tests or golden vectors for VLAD / Database / findCorrespondences and cannot be built here (OpenCV, DBoW3 need
 OpenCV), so the OUTPUTS of this module are "parity unpinned": they follow the cited lines, nothing more.
@@ -35,7 +35,7 @@ def hamming(a, b):
 
 
 class Vocabulary:
-    """The tree of a DBoW3 binary vocabulary, from a tests/golden/vocab_*.npz fixture (or any dict of arrays)."""
+    """The tree of a DBoW3 binary vocabulary, from an x_multi_agent_amd/data/vocab_*.npz file (or any dict of arrays)."""
 
     def __init__(self, v):
         self.k, self.L = int(v["k"]), int(v["L"])

@@ -1,5 +1,5 @@
 """Turns the reference's own vocabulary data files (Vocabulary/*.yaml -- DBoW3 binary containers despite the
-extension) into plain-array fixtures: tests/golden/vocab_<name>.npz.  Data only: node descriptors, the tree, the
+extension) into plain arrays: x_multi_agent_amd/data/vocab_<name>.npz (the package owns the data it loads).  Data only: node descriptors, the tree, the
 word table.  Run in the build container (needs /root/reference and gcc):
     python tests/golden/make_vocab_fixture.py
 The stream layout parsed here is Vocabulary::fromStream (third_party/DBow3/src/Vocabulary.cpp:1374-1410) and
@@ -63,7 +63,7 @@ def main():
         with tempfile.NamedTemporaryFile(suffix=".raw") as t:
             subprocess.check_call([exe, path, t.name])
             v = parse(open(t.name, "rb").read())
-        out = os.path.join(HERE, f"vocab_{name}.npz")
+        out = os.path.join(HERE, "..", "..", "x_multi_agent_amd", "data", f"vocab_{name}.npz")
         np.savez_compressed(out, **v)
         print(out, "k", int(v["k"]), "L", int(v["L"]), "nodes", len(v["parent"]), "words", len(v["node_of_word"]),
               "desc bytes", v["desc"].shape[1])

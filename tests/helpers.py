@@ -5,6 +5,17 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PKG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "x_multi_agent_amd")
+LAB_DIR = os.path.join(PKG_DIR, "lab")          # lab/libxk.so: the -DXK_LAB build (test hooks, environment switches; include/xk_lab.h)
+
+
+def with_lab(env):
+    """Environment of a child process that needs a test hook or an environment switch: the C++ examples find lab/libxk.so
+    before the release library (LD_LIBRARY_PATH precedes their RUNPATH), Python children load it through XK_LIB_PATH."""
+    env = dict(env)
+    env["LD_LIBRARY_PATH"] = LAB_DIR + ":" + env.get("LD_LIBRARY_PATH", "")
+    env["XK_LIB_PATH"] = os.path.join(LAB_DIR, "libxk.so")
+    return env
 VISUAL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
                       if not os.path.basename(p).startswith(("ci_", "manage_", "msckf_slam_", "vocab_", "multi_uav_", "propagator_", "iekf_")))
 

@@ -23,6 +23,24 @@ def test_header_symbols_all_exported():
     assert sorted(engine.SYMBOLS) == declared
 
 
+def test_release_library_carries_no_lab_exports_and_the_lab_build_carries_both():
+    """the shipped library is not the lab.  include/xk_lab.h declares what only the -DXK_LAB build
+    (x_multi_agent_amd/lab/libxk.so) exports -- test hooks, debug stamps, probe kernels; the release library has none of it, does not
+    reference getenv, and refuses the test-hook options."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "xk_lab.h")).read()
+    lab_decl = sorted(set(re.findall(r"^\s*(?:const\s+)?(?:int|long|void|char)\s*\*?\s*(xk_[a-z_A-Z0-9]+)\s*\(", hdr, flags=re.M)))
+    assert lab_decl == sorted(engine.LAB_SYMBOLS)
+    rel, lab = engine.lib(), engine.lib(lab=True)
+    assert not [s for s in lab_decl if hasattr(rel, s)]
+    assert not [s for s in lab_decl + engine.SYMBOLS if not hasattr(lab, s)]
+    assert lab.xk_is_lab() == 1
+    und = lambda p: subprocess.run(["nm", "-D", "--undefined-only", p], capture_output=True, text=True).stdout
+    assert "getenv" not in und(engine.LIB_PATH) and "getenv" in und(engine.LAB_LIB_PATH)
+    syms = subprocess.run(["nm", "-D", "--defined-only", engine.LIB_PATH], capture_output=True, text=True).stdout
+    assert "xk_probe" not in syms and "xk_debug" not in syms
+
+
 def test_version_strerror_payload_size():
     L = engine.lib()
     assert L.xk_version() >= 100

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import rel
+from helpers import rel, with_lab
 from oracle import ref_np
 from x_multi_agent_amd import synth
 
@@ -28,7 +28,9 @@ def run_frame_loop(tmp_path, sc, frames, imu_per_frame, mode, extra_env=None):
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / f"out{mode}.bin")
     np.concatenate(parts).astype("<f8").tofile(fin)
     env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    env.update(extra_env or {})
+    if extra_env:                       # environment switches are read by the lab build of the library only
+        env = with_lab(env)
+        env.update(extra_env)
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     out = np.fromfile(fout, dtype="<f8")

@@ -31,7 +31,7 @@ SHAPES = {
 def _update(xk, sc, kalman):
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
-    eng = xk.Engine(N, M, max(K, 1))
+    eng = xk.LabEngine(N, M, max(K, 1))
     eng.set_option("pipe_kalman", kalman)
     eng.stage(sc)
     r = eng.visual_update_staged(sc["sigma_img"])
@@ -77,13 +77,13 @@ def test_launch_that_gives_up_with_the_update_inside(xk, oracle_c):
     sc = synth.make_config(4)
     ref = oracle_c.visual_update(sc)
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
-    eng = xk.Engine(N, 0, K)
+    eng = xk.LabEngine(N, 0, K)
     eng.set_option("caqr_poison", 1)
     eng.stage(sc)
     r = eng.visual_update_staged(sc["sigma_img"])
     assert rel(eng.download_P(), ref["P"]) <= 1e-8 and eng.caqr_status()["giveups"] == 1
     eng.close()
-    eng = xk.Engine(N, 0, K)
+    eng = xk.LabEngine(N, 0, K)
     eng.stage(sc)
     eng.visual_update_staged(sc["sigma_img"])                          # (warm: first-use costs out of the timing below)
     for poison in (0, 1):

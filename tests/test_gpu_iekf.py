@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import load_iekf_case, rel
+from helpers import load_iekf_case, rel, with_lab
 from oracle import c_oracle
 
 pytestmark = pytest.mark.gpu
@@ -34,7 +34,9 @@ def run_example(tmp_path, sc, st, iekf_iter, resident, extra_env=None):
     np.concatenate(parts).astype("<f8").tofile(fin)
     np.concatenate([st["p"], st["v"], st["q"], st["b_w"], st["b_a"]]).astype("<f8").tofile(fcore)
     env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
-    env.update(extra_env or {})
+    if extra_env:                       # environment switches are read by the lab build of the library only
+        env = with_lab(env)
+        env.update(extra_env)
     r = subprocess.run([exe, fin, fout, str(iekf_iter), str(int(resident)), fcore], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

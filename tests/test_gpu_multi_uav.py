@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import GOLDEN_DIR, rel
+from helpers import GOLDEN_DIR, rel, with_lab
 from oracle import ref_np
 from x_multi_agent_amd import synth
 
@@ -39,6 +39,8 @@ def _run(tmp_path, g, resident, n_short=0):
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / f"out{int(resident)}.bin")
     np.concatenate(parts).astype("<f8").tofile(fin)
     env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    if "XK_CAQR_RESIDENT_POISON" in env:            # (a test hook: the lab build of the library)
+        env = with_lab(env)
     r = subprocess.run([exe, fin, fout, str(int(resident))], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     out = np.fromfile(fout, dtype="<f8")

@@ -1,6 +1,6 @@
 """GPU parity (bit-exact) of the place-recognition request filter against oracle/ref_pr.py, through the C ABI:
 VLAD (xk_pr_compute_vlad), keyframe database (xk_pr_add_keyframe / xk_pr_find_candidate / xk_pr_keyframe) and
-2-NN descriptor matching (xk_pr_knn_match).  Vocabularies: the reference's own (tests/golden/vocab_*.npz) and
+2-NN descriptor matching (xk_pr_knn_match).  Vocabularies: the reference's own (x_multi_agent_amd/data/vocab_*.npz) and
 random trees with uneven child counts / 64-byte descriptors."""
 import numpy as np
 import pytest

@@ -29,6 +29,7 @@ ref = np.load(sys.argv[2])
 sc = synth.make_config(4)
 N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
 eng = engine.Engine(N, 0, K)
+if __import__("os").environ.get("TEST_MULTI_LAUNCH") == "1": eng.set_option("caqr_resident", 0)   # (operational switch of the release library)
 eng.stage(sc); eng.visual_update_staged(sc["sigma_img"])          # warm-up (module load, first launches)
 open(sys.argv[3], "w").write("ready")
 while not all(__import__("os").path.exists(p) for p in sys.argv[4:]): time.sleep(0.001)
@@ -56,7 +57,7 @@ def test_missing_workgroup_costs_one_bounded_retry(xk, oracle_c):
     sc = synth.make_config(4)
     ref = oracle_c.visual_update(sc)
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
-    eng = xk.Engine(N, 0, K)
+    eng = xk.LabEngine(N, 0, K)
     eng.stage(sc); eng.visual_update_staged(sc["sigma_img"])
     eng.set_option("caqr_test_stall", 1)
     eng.stage(sc)
@@ -91,7 +92,7 @@ def _two(env):
 
 def test_two_processes_share_one_gpu():
     fast = _two({})
-    slow = _two({"XK_CAQR_RESIDENT": "0"})
+    slow = _two({"TEST_MULTI_LAUNCH": "1"})
     print("two tenants, fast path armed:", json.dumps(fast))
     print("two tenants, multi-launch:   ", json.dumps(slow))
     for r in fast + slow:

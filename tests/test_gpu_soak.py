@@ -14,6 +14,24 @@ pytestmark = pytest.mark.gpu
 N_CASES = 30
 
 
+def _strict_twin(xk, N, M, K, sc, P, corr, schedule):
+    """the relaxed hand-offs of the single launch (csrc/xk_xcd_sync.hip.h: what gfx950 does) held to the
+    -DXK_SYNC_STRICT=1 build (agent-scope release / acquire pairs: what the HIP memory model promises) on EVERY shape of the soak,
+    bit for bit -- same arithmetic in the same order, so any difference is a hand-off that let a stale word through."""
+    import os
+    if not os.path.exists(xk.STRICT_LIB_PATH):
+        from x_multi_agent_amd import build
+        build.build_strict()
+    eng = xk.Engine(N, M, K, lib_path=xk.STRICT_LIB_PATH)
+    eng.stage(sc)
+    got = eng.visual_update_staged(sc["sigma_img"])
+    Ps = eng.download_P()
+    st = eng.caqr_status()
+    eng.close()
+    assert st["schedule"] == schedule and st["giveups"] == 0, (N, K, M, st)
+    assert np.array_equal(Ps, P) and np.array_equal(got["correction"], corr), (N, K, M, rel(Ps, P))
+
+
 def test_random_shapes_against_the_oracle(xk, oracle_c):
     rng = np.random.default_rng(20260928)
     worst, bad, took, ran = 0.0, [], 0, 0
@@ -45,7 +63,9 @@ def test_random_shapes_against_the_oracle(xk, oracle_c):
         st = eng.caqr_status()
         took += int(st["schedule"] == 2)
         assert st["giveups"] == 0, (N, K, kw, st)
+        P_last = eng.download_P()
         eng.close()
+        _strict_twin(xk, N, 0, K, sc, P_last, got["correction"], st["schedule"])
     assert not bad, bad
     assert took >= N_CASES // 2, f"only {took} of {N_CASES} random shapes took the single-launch path"
     print(f"soak: {N_CASES} shapes, {took} on the single launch, worst rel dP {worst:.2e}")
@@ -83,7 +103,9 @@ def test_random_shapes_with_slam_rows_against_the_oracle(xk, oracle_c):
         took += int(st["schedule"] == 2)
         wide += int(st["schedule"] == 2 and 6 * N + 3 * M + 1 > 192)
         assert st["giveups"] == 0, (N, K, M, kw, st)
+        P_last = eng.download_P()
         eng.close()
+        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], st["schedule"])
     assert not bad, bad
     assert took >= 8 and wide >= 3, (took, wide)
     print(f"soak (SLAM rows): 16 shapes, {took} on the single launch ({wide} wide), worst rel dP {worst:.2e}")
@@ -142,6 +164,33 @@ def test_random_wide_windows_against_the_oracle(xk, oracle_c):
                     or not (rp <= 1e-8) or not (rel(got["gamma"][fin], ref["gamma"][fin]) <= 1e-8)):
                 bad.append((N, K, M, kw, rep, rp))
         assert eng.caqr_status()["schedule"] == 0
+        P_last = eng.download_P()
         eng.close()
+        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], 0)      # (multi-launch schedule: no in-launch hand-offs, the two builds must agree trivially)
     assert not bad, bad
     print(f"soak: 12 wide windows, worst rel dP {worst:.2e}")
+
+
+@pytest.mark.parametrize("cfg,reps", [(4, 300), (1, 300), (2, 100), (3, 20)])
+def test_repeated_updates_are_bit_identical(xk, cfg, reps):
+    """tools/exp/determinism.py at reduced count inside the suite: the same staged inputs updated `reps`
+    times on one handle -- every posterior and every correction bit-identical to the first.  A hand-off that lets a stale word
+    through, or a race between unsynchronised column splits, shows here as a differing update; a driver / firmware change that
+    breaks what the relaxed hand-offs rely on fails this test instead of a flight."""
+    N, K, M = synth.CONFIGS[cfg]
+    sc = synth.make_config(cfg)
+    eng = xk.Engine(N, M, K)
+    eng.stage(sc)
+    first, diff = None, []
+    for i in range(reps):
+        eng.upload_P(sc["P"])
+        r = eng.visual_update_staged(sc["sigma_img"])
+        P = eng.download_P()
+        if first is None:
+            first = (P.copy(), r["correction"].copy())
+        elif not (np.array_equal(P, first[0]) and np.array_equal(r["correction"], first[1])):
+            diff.append(i)
+    st = eng.caqr_status()
+    eng.close()
+    assert not diff, (cfg, len(diff), diff[:10])
+    assert st["giveups"] == 0, st

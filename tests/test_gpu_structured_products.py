@@ -10,6 +10,8 @@ import sys
 import numpy as np
 import pytest
 
+from helpers import with_lab
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.join(os.path.dirname(__file__), "..")
 
@@ -36,7 +38,7 @@ print(json.dumps(out))
 
 
 def _run(tmp_path, tag, struct):
-    env = dict(os.environ, XK_GEMM_STRUCT=str(struct))
+    env = with_lab(dict(os.environ, XK_GEMM_STRUCT=str(struct)))      # (an A/B switch: the lab build reads it)
     r = subprocess.run([sys.executable, "-c", CHILD, str(tmp_path / tag)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -14,7 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.mark.parametrize("name", ["visual", "thermal"])
 def test_reference_vocabulary_fixture(name):
-    v = dict(np.load(os.path.join(GOLDEN, f"vocab_{name}.npz")))
+    v = place.load_vocabulary(name)            # x_multi_agent_amd/data/vocab_<name>.npz: the package owns its data
     voc = ref_pr.Vocabulary(v)
     assert (voc.k, voc.L) == (4, 3)                       # Vocabulary/*_voc_3_4_*: depth 3, branching 4
     assert voc.desc.shape == (85, 32) and len(voc.node_of_word) == 64

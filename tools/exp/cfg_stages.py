@@ -1,6 +1,7 @@
 """Stage times of a BASELINE config with the single-launch CAQR and with the multi-launch schedule: python tools/exp/cfg_stages.py 2"""
 import os, sys
 sys.path.insert(0, '.')
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 N, K, M = synth.CONFIGS[cfg]

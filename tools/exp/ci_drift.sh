@@ -1,3 +1,4 @@
+export XK_LIB_PATH=${XK_LIB_PATH:-${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}/x_multi_agent_amd/lab/libxk.so}   # lab build: env switches, hooks, probes
 for s in 10 50 100 150; do python bench.py --dry-run-ranks 8 --dry-run-rank 1 --steps $s --warmup 20 --no-cpu --no-frame-loop --no-other-configs --dump-posterior /tmp/P_$s.npy > /tmp/o_$s.log 2>&1; python - <<PY
 import numpy as np, os
 f="/tmp/P_$s.npy"

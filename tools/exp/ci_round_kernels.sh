@@ -1,4 +1,5 @@
 #!/bin/bash
+export XK_LIB_PATH=${XK_LIB_PATH:-${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}/x_multi_agent_amd/lab/libxk.so}   # lab build: env switches, hooks, probes
 # kernel trace of ONE device-resident CI round at 8 agents (tools/exp/ci_round_trace.py under rocprofv3): start, duration, name
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

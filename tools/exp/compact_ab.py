@@ -2,6 +2,7 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 from oracle import c_oracle
 cases = [("cfg4", lambda: synth.make_config(4)), ("cfg2", lambda: synth.make_config(2)), ("cfg1", lambda: synth.make_config(1)),

@@ -2,6 +2,7 @@
 unsynchronised column splits / redundant factorizations would show up here)."""
 import sys; sys.path.insert(0, '.')
 import numpy as np
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 SCALE = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # python tools/exp/determinism.py 10 -> ten times the repetitions
 for cfg, reps in ((4, 300 * SCALE), (1, 300 * SCALE), (2, 100 * SCALE), (3, 30 * SCALE)):

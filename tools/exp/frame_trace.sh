@@ -1,4 +1,5 @@
 #!/bin/bash
+export XK_LIB_PATH=${XK_LIB_PATH:-${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}/x_multi_agent_amd/lab/libxk.so}   # lab build: env switches, hooks, probes
 # Device timeline of the frame loop (resident covariance): kernel and copy intervals of a few frames under rocprofv3.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python - <<'PY'

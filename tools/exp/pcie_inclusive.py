@@ -1,5 +1,6 @@
 import sys, time; sys.path.insert(0,'.')
 import numpy as np
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 sc = synth.make_config(4)
 eng = engine.Engine(30, 0, 400)

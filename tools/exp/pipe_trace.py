@@ -5,6 +5,7 @@ import ctypes as C, os, sys, subprocess
 sys.path.insert(0, '.')
 os.environ.setdefault("XK_CAQR_PERSIST_DBG", "1")
 import numpy as np
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4

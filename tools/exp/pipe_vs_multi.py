@@ -2,6 +2,7 @@
 replay rate of BASELINE config 1."""
 import os, sys, time
 sys.path.insert(0, '.')
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 shapes = [(12, 26, 0), (10, 50, 0), (20, 60, 0), (30, 100, 0), (30, 200, 0), (24, 350, 0), (16, 400, 0), (30, 400, 0), (30, 410, 0), (20, 150, 40), (30, 200, 50), (33, 150, 0)]
 for N, K, M in shapes:

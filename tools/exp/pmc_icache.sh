@@ -1,4 +1,5 @@
 #!/bin/bash
+export XK_LIB_PATH=${XK_LIB_PATH:-${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}/x_multi_agent_amd/lab/libxk.so}   # lab build: env switches, hooks, probes
 # instruction-fetch side of the single-launch CAQR: does the unrolled step code of two roles thrash the I-cache two CUs share?
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; cd $R

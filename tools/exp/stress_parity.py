@@ -4,6 +4,7 @@ track counts / lengths, SLAM features, partial windows, rejection rates and prio
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, synth
 from oracle import c_oracle
 from helpers import rel

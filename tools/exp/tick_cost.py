@@ -3,6 +3,7 @@ VLAD, search, copy, CI round."""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
+import os as _os; _os.environ.setdefault("XK_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "..", "..", "x_multi_agent_amd", "lab", "libxk.so"))   # the lab build: env switches, hooks, probes (include/xk_lab.h)
 from x_multi_agent_amd import engine, fleet, synth, place
 N, K, M = synth.CONFIGS[5]
 sc = fleet.shared_scenario(synth, 5, 0); sc1 = fleet.shared_scenario(synth, 5, 1)

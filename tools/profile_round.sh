@@ -16,7 +16,7 @@ cd $R
 if [ "$CFG" = "4" ]; then
 python -c "
 from x_multi_agent_amd import engine
-e = engine.Engine(10, 0, 10)
+e = engine.LabEngine(10, 0, 10)   # the probe kernels are in the lab build (include/xk_lab.h)
 import json
 print(json.dumps({'fp64_mfma_tflops': e.probe_fp64_peak(True), 'fp64_fma_tflops': e.probe_fp64_peak(False)}))
 " > $OUT/fp64_peak.json 2>$OUT/fp64_peak.err

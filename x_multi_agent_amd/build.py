@@ -26,6 +26,24 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_lab(force=False, verbose=True):
+    """lab/libxk.so: the same sources with -DXK_LAB -- environment switches, test hooks (xk_set_option "caqr_poison" ...), debug
+    exports and probe kernels (include/xk_lab.h).  Same file name in a directory of its own, so that the C++ examples pick it up
+    through LD_LIBRARY_PATH and Python through engine.lib(lab=True); the release library has none of it."""
+    out = os.path.join(HERE, "lab", "libxk.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    deps = DEPS + [os.path.join(HERE, "..", "include", "xk_lab.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-Wno-unused-value",
+           "-DXK_LAB", "-o", out, SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_strict(verbose=True):
     """libxk_strict.so: the same sources with -DXK_SYNC_STRICT=1 -- every hand-off of the single-launch kernels as an agent-scope
     release / acquire pair (xk_xcd_sync.hip.h).  2.3x slower; it is the reference the default build's hand-offs are checked
@@ -85,5 +103,6 @@ def build_host(force=False, verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_lab(force="--force" in sys.argv)
     build_fleet()
     build_host()

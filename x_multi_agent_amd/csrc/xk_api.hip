@@ -2,6 +2,9 @@
 // Host-side orchestration only: every number in a result is produced by the
 // HIP kernels in xk_feature.hip.h / xk_linalg.hip.h / xk_ci.hip.h.
 #include "../../include/xk.h"
+#ifdef XK_LAB
+#include "../../include/xk_lab.h"
+#endif
 
 #include <hip/hip_runtime.h>
 
@@ -163,10 +166,17 @@ static hipError_t dalloc(T **p, size_t count) {
 static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out);
 extern "C" int xk_destroy(xk_handle *h);
 // (a failure part-way through releases everything allocated so far)
+// Experiment switches.  The RELEASE library (libxk.so) never looks at the environment: every switch has its default.  The LAB
+// build (-DXK_LAB: x_multi_agent_amd/lab/libxk.so, include/xk_lab.h) reads them -- once each -- and carries the test hooks,
+// the debug exports and the probe kernels the tests and tools/exp use.
+#ifdef XK_LAB
 static int env_int(const char *name, int dflt) {
   const char *v = getenv(name);
   return v ? atoi(v) : dflt;
 }
+#else
+static inline int env_int(const char *, int dflt) { return dflt; }
+#endif
 
 extern "C" int xk_create(int device, int n_poses_max, int n_feat_max, int k_max, xk_handle **out) {
   if (!out) return XK_EINVAL;
@@ -282,8 +292,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
       HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
       h->xsync_phase = 0;
+#ifdef XK_LAB
       HIPCHK(h, dalloc(&h->d_pdbg, (size_t)256 + 64 * 256));
       HIPCHK(h, hipMemset(h->d_pdbg, 0, sizeof(long long) * (256 + 64 * 256)));
+#endif
     }
   }
   HIPCHK(h, dalloc(&h->d_Maug, (size_t)h->CM * h->LDA));
@@ -1308,6 +1320,10 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
   bool ct_zero = true;                                 // Updater::update starts every update from a zero correction_total
   if (corr_total)
     for (int i = 0; i < h->n && ct_zero; ++i) ct_zero = corr_total[i] == 0.0;
+  // arguments first, before any state of the handle is touched: a mismatch with what xk_build_compress_update_async queued leaves the
+  // queued update (posterior in d_Pout, marker, retry bookkeeping) exactly as it was -- the matching call can still collect it
+  if (h->fused_pending && (!ct_zero || !cov_update))
+    return fail(h, XK_EINVAL, "xk_build_compress_update_async queued applyUpdate(correction_total = 0, cov_update = true)");
   if (corr_total && !ct_zero) {
     double *st = (double *)stage_slot(h, sizeof(double) * h->n);
     if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
@@ -1318,8 +1334,6 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
   const bool async = h->async_pending, queued = h->fused_pending;
   h->async_pending = false;
   h->fused_pending = false;
-  if (queued && (dct || !cov_update))
-    return fail(h, XK_EINVAL, "xk_build_compress_update_async queued applyUpdate(correction_total = 0, cov_update = true)");
   int rc = XK_OK;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1) {   // the single-launch CAQR of xk_build_compress_async gave up: rows, compression and update again
@@ -1344,10 +1358,16 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     bool seen = false;
     if (spin_env && u.done_seq) {
       // Acquire load: the correction and the status words read below are ordered after the marker.  The marker is the LAST
-      // store of the update -- a system-scope release by the last workgroup of the last kernel, after every workgroup of that
-      // kernel has been counted in (done_cnt) -- and the kernels before it on the stream (whose failure paths write the status
-      // words into the same pinned allocation) had completed, their stores released to system scope at their kernel
-      // boundaries, before that kernel started: whatever they wrote is visible by the time the marker is.
+      // host-visible store of the update.  Separate Kalman launches: a system-scope RELEASE by the last workgroup of the last
+      // kernel, after every workgroup of that kernel has been counted in (done_cnt).  Kalman role inside the single launch: the
+      // correction and the status word are relaxed system-scope stores whose acknowledgement the writing wave waits for
+      // (s_waitcnt vmcnt(0)) before it stores the marker, relaxed as well -- gfx950 behaviour, not a memory-model guarantee; the
+      // -DXK_SYNC_STRICT=1 build stores that marker with a system-scope release (XK_MARKER_ORDER, xk_xcd_sync.hip.h).  In both forms
+      // the marker covers ONLY the words in h_out: the posterior (d_Pout) may still be on its way out of the other waves when
+      // the marker lands and is valid to later work through STREAM ORDER -- everything that reads it is queued on h->stream
+      // behind this launch (the pointer swap below is host bookkeeping).  The kernels before it on the stream (whose failure
+      // paths write the status words into the same pinned allocation) had completed, their stores released to system scope at
+      // their kernel boundaries, before that kernel started: whatever they wrote is visible by the time the marker is.
       // (a single launch that gave up before its Kalman role got going -- placement census -- writes no marker: the status word
       //  ends the wait)
       for (long spins = 0; spins < 40000000L && !(seen = (__atomic_load_n(done, __ATOMIC_ACQUIRE) == u.done_seq)); ++spins) {
@@ -2033,21 +2053,45 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   { int rcw = flush_window(h); if (rcw != XK_OK) return rcw; }
   int fused = 0;
   int trk_L0[8], trk_dof[8];
+  // Every track is validated BEFORE anything is queued or forked: an early return below this point would leave side streams
+  // running into workspace and pinned words the next call reuses.
+  for (int j = 0; j < n_tracks; ++j) {
+    const int st = self_track[j];
+    int Ltot = h->h_trk_off[st + 1] - h->h_trk_off[st];
+    for (int r = 0; r < world; ++r) {
+      if (r == self_rank) continue;
+      const int np_r = n_poses_valid[r], L_r = track_len[r * n_tracks + j];
+      if (L_r < 2 || L_r > np_r || np_r > N) return fail(h, XK_EINVAL, "received track / window lengths inconsistent");
+      Ltot += L_r;
+    }
+    if (2 * Ltot - 3 >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
+  }
+  // (a HIP error after the fork: the side streams are joined before the error is returned)
+  auto bail = [&](int rc) {
+    for (int j = 1; j < 8; ++j)
+      if (h->ci_stream[j]) hipStreamSynchronize(h->ci_stream[j]);
+    hipStreamSynchronize(h->stream);
+    return rc;
+  };
+#define CI_CHK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) return bail(fail(h, XK_EDEVICE, #call, e_));                \
+  } while (0)
   // The shared tracks are independent until applyCI (every P_j is built from the same prior), and a track's stages are a chain of
   // seven small launches (~160 us at 8 agents): track j >= 1 runs its chain on a side stream next to track 0's.
   const unsigned long long ci_seq = ++h->done_seq;
   static const int side_env = env_int("XK_CI_SIDE_STREAMS", 1);
   const bool side = side_env && n_tracks > 1;
-  if (side) HIPCHK(h, hipEventRecord(h->ci_fork, h->stream));
+  if (side) CI_CHK(hipEventRecord(h->ci_fork, h->stream));
   for (int j = 0; j < n_tracks; ++j) {
     hipStream_t sj = (side && j > 0) ? h->ci_stream[j] : h->stream;
-    if (side && j > 0) HIPCHK(h, hipStreamWaitEvent(sj, h->ci_fork, 0));
+    if (side && j > 0) CI_CHK(hipStreamWaitEvent(sj, h->ci_fork, 0));
     const CiWs w = ci_ws(j);
     double *dq = w.dq, *dp = w.dp, *dobs = w.dobs, *up = w.up, *Hs = w.Hs, *Si = w.Si, *S1 = w.S1, *S2 = w.S2;
     double *dres = w.dres, *dgpf = w.dgpf, *dscal = w.dscal;
     int *dint = w.dint;
     const int st = self_track[j];
-    if (st < 0 || st >= h->K) return fail(h, XK_EINVAL, "shared track index outside the staged tracks");
     // agent order: index 0 = self, 1.. = the others by rank
     const double *aq[XK_CI_MAXK + 1], *ap[XK_CI_MAXK + 1], *aobs[XK_CI_MAXK + 1], *aP[XK_CI_MAXK + 1];
     int anp[XK_CI_MAXK + 1], aL[XK_CI_MAXK + 1], Ltot = 0;
@@ -2059,7 +2103,6 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       aq[i] = base + o_att; ap[i] = base + o_pos; aP[i] = base + o_cov;
       aobs[i] = d_tracks + ((size_t)r * n_tracks + j) * trk_stride + 1;
       anp[i] = n_poses_valid[r]; aL[i] = track_len[r * n_tracks + j];
-      if (aL[i] < 2 || aL[i] > anp[i] || anp[i] > N) return fail(h, XK_EINVAL, "received track / window lengths inconsistent");
       ++i;
     }
     for (int i = 0; i < k1; ++i) Ltot += aL[i];
@@ -2082,7 +2125,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       hb[i].n_poses = anp[i]; hb[i].n_poses_max = N; hb[i].n = n; hb[i].L = aL[i]; hb[i].up_out = up + i * upsz;
       npmax = std::max(npmax, anp[i]);
     }
-    HIPCHK(h, hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, sj));
+    CI_CHK(hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, sj));
     XkFeatArgs a;
     memset(&a, 0, sizeof(a));
     a.K = k1; a.var_img = var_img; a.chi95 = h->d_chi95; a.n = n; a.na = n - XK_CORE; a.n_poses = npmax; a.n_poses_max = N;
@@ -2107,11 +2150,11 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
     XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal,
                        dint, h->h_ci_w + 16 + 4 * j, reinterpret_cast<unsigned long long *>(h->h_ci_w + 16 + 4 * j + 2), ci_seq};
     hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, sj, ca);
-    if (side && j > 0) { HIPCHK(h, hipEventRecord(h->ci_join[j], sj)); HIPCHK(h, hipStreamWaitEvent(h->stream, h->ci_join[j], 0)); }
+    if (side && j > 0) { CI_CHK(hipEventRecord(h->ci_join[j], sj)); CI_CHK(hipStreamWaitEvent(h->stream, h->ci_join[j], 0)); }
     trk_L0[j] = aL[0];
     trk_dof[j] = 2 * Ltot - 3;
-    if (trk_dof[j] >= XK_CHI2_LEN) return fail(h, XK_ECAPACITY, "chi-square table too short");
   }
+#undef CI_CHK
   if (n_tracks > 0) {
     // wait for the markers of all tracks (XK_SPIN_DONE=0, or a marker that does not come within ~1 s: the runtime's signal)
     static const int spin_env = env_int("XK_SPIN_DONE", 1);
@@ -2225,6 +2268,7 @@ extern "C" int xk_pack_payload(xk_handle *h, double agent_id, double timestamp, 
 extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
   if (!h || steps < 0 || !(sigma_img > 0.0)) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
+#ifdef XK_LAB
   static const int use_graph = env_int("XK_GRAPH", 0);
   if (use_graph && steps > 1) {
     // experiment: the 30 launches of one update captured once and replayed
@@ -2244,6 +2288,7 @@ extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
     hipGraphDestroy(g);
     return rc;
   }
+#endif
   // (every step recomputes the same update from the resident prior, so a single-launch CAQR that gave up -- e.g. two
   //  processes sharing one GPU, each with a grid that wants every CU -- costs one more pass with the multi-launch schedule)
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -2263,8 +2308,9 @@ extern "C" int xk_run_steps(xk_handle *h, double sigma_img, int steps) {
 }
 
 // ---------------------------------------------------------------------------
-// fp64 ceiling probe
+// fp64 ceiling probe (lab build only: include/xk_lab.h)
 // ---------------------------------------------------------------------------
+#ifdef XK_LAB
 __global__ __launch_bounds__(256) void xk_probe_mfma(double *out, int iters) {
   xk_d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
   const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
@@ -2312,16 +2358,21 @@ extern "C" int xk_probe_fp64_peak(xk_handle *h, int use_mfma, double *tflops) {
   *tflops = flops / (ms * 1e-3) / 1e12;
   return XK_OK;
 }
+#endif   // XK_LAB
 
 // Which schedule compressed the last update, and how the fast path has fared on this handle (include/xk.h).
 extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
   if (!h || !name) return XK_EINVAL;
+  // operational switches of the release library: the schedule of the compression and how soon a fast path that gave up is retried
   if (!strcmp(name, "caqr_resident")) h->opt_resident = value;
+  else if (!strcmp(name, "caqr_rearm")) h->rearm_after = value;
+#ifdef XK_LAB
+  // test hooks and A/B switches (include/xk_lab.h)
   else if (!strcmp(name, "caqr_poison")) h->opt_poison = value;
   else if (!strcmp(name, "caqr_test_stall")) h->opt_test_stall = value;
   else if (!strcmp(name, "caqr_tall26")) h->opt_tall26 = value;
-  else if (!strcmp(name, "caqr_rearm")) h->rearm_after = value;
   else if (!strcmp(name, "pipe_kalman")) h->opt_kalman = value;
+#endif
   else return fail(h, XK_EINVAL, "xk_set_option: unknown option");
   return XK_OK;
 }
@@ -2335,6 +2386,8 @@ extern "C" int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int
   return XK_OK;
 }
 
+#ifdef XK_LAB
+extern "C" int xk_is_lab(void) { return 1; }
 // Wall-clock (100 MHz) stamps of the last single-launch CAQR (XK_CAQR_PERSIST_DBG=1): per panel k, out[8k + 0..5] = role-T
 // workgroup (XCD 0, slot 0): tile step start / end, after barrier 1, first-level merge start, end, after barrier 2;
 // out[8k + 6..7] = last-level workgroup 0: roots complete -> its strips published.  tools/exp/persist_trace.py prints them.
@@ -2345,8 +2398,9 @@ extern "C" int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out) 
   HIPCHK(h, hipMemcpy(out, h->d_pdbg, sizeof(long long) * (size_t)std::min(n_out, 256 + 64 * 256), hipMemcpyDeviceToHost));
   return XK_OK;
 }
+#endif   // XK_LAB
 
-#ifdef XK_FEAT_PROBE
+#if defined(XK_FEAT_PROBE) && defined(XK_LAB)
 extern "C" int xk_debug_feature_phases(xk_handle *h, double sigma_img, long long *out, int n_out) {
   // out[12k ..]: 8 clock64 phase stamps, wall start, wall end, (XCC_ID << 32 | HW_ID) of workgroup k
   const size_t bytes = sizeof(long long) * (size_t)(12 * h->K);

@@ -1173,7 +1173,7 @@ __device__ __noinline__ bool xk_pipe_kalman(XkPipeArgsPtr ap, xk_ldsd *kb, unsig
     if (wave == 0) {
       for (int i = lane; i < n; i += 64) xk_st_sys(a.corr + i, m.dbuf[i]);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0 && a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 0 && a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, XK_MARKER_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);   // (xk_xcd_sync.hip.h)
     }
   };
   // P is symmetric bit for bit: element (row, col) goes to the address of (col, row), sixteen lanes to a 128-byte line; the
@@ -1335,13 +1335,14 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
         if (a.kal) {
           ok = xk_pipe_kalman<G>(ap, (xk_ldsd *)kbuf, &s_ok);
           // A role that gave up has not told the host anything yet (a finished one wrote the correction, then the marker, from
-          // inside -- system-scope stores, complete before the marker; NOT a release fence, which at system scope is a write-back of
-          // this XCD's whole L2 on the launch's tail, and nothing but those words is for the host)
+          // inside -- relaxed system-scope stores, acknowledged (vmcnt) before the marker is stored; a system-scope RELEASE on the
+          // marker is a write-back of this XCD's whole L2 on the launch's tail and is what -DXK_SYNC_STRICT=1 builds: XK_MARKER_ORDER,
+          // xk_xcd_sync.hip.h -- nothing but those words is for the host, the posterior is ordered by the stream)
           if (!ok) {
             if (threadIdx.x == 0) __hip_atomic_store(a.status + 1, (int)__hip_atomic_load(ab, XK_RLX_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (threadIdx.x == 0 && a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (threadIdx.x == 0 && a.done_flag) __hip_atomic_store(a.done_flag, a.done_seq, XK_MARKER_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);
           }
           if (a.dbg && threadIdx.x == 0) a.dbg[2048 + 16 * 31 + 3] = wall_clock64();
           return;

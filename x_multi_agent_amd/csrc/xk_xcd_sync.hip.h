@@ -42,6 +42,20 @@
 #define XK_ACQUIRE_FENCE()
 #endif
 #define XK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+// The completion marker a launch writes into pinned host memory behind its host-visible results (correction, status words).  Default:
+// the results are relaxed system-scope stores, `s_waitcnt vmcnt(0)` waits for their acknowledgement, then the marker is a relaxed
+// system-scope store -- what gfx950 does (a system-scope store is acknowledged once it has left for the host), not what the HIP
+// memory model promises.  -DXK_SYNC_STRICT=1 (or -DXK_MARKER_RELEASE=1 alone) stores the marker with a system-scope RELEASE
+// (buffer_wbl2 sc0 sc1 in front of it: a write-back of the XCD's L2, once per launch).  Either way only the words the marker sits
+// behind are for the host; the posterior in HBM (Pout) is valid to later work THROUGH STREAM ORDER, not through the marker.
+#ifndef XK_MARKER_RELEASE
+#define XK_MARKER_RELEASE XK_SYNC_STRICT
+#endif
+#if XK_MARKER_RELEASE
+#define XK_MARKER_ORDER __ATOMIC_RELEASE
+#else
+#define XK_MARKER_ORDER __ATOMIC_RELAXED
+#endif
 
 __device__ __forceinline__ double xk_ld_sc1(const double *p) {
   return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), XK_RLX_AGENT));

@@ -11,7 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XK_LIB_PATH", os.path.join(_HERE, "libxk.so"))  # override: experiments only
-_LIB = None
+LAB_LIB_PATH = os.path.join(_HERE, "lab", "libxk.so")   # the same sources with -DXK_LAB: test hooks, env switches, probes (include/xk_lab.h)
+STRICT_LIB_PATH = os.path.join(_HERE, "libxk_strict.so")   # -DXK_SYNC_STRICT=1: release / acquire hand-offs, the bit-compare reference
+_LIBS = {}
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
@@ -28,11 +30,15 @@ SYMBOLS = [
     "xk_apply_update_dense", "xk_apply_ci", "xk_fuse_ci_msckf", "xk_fuse_ci_slam", "xk_multi_slam_match", "xk_msckf_ci_track",
     "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
     "xk_stage_msckf_slam", "xk_msckf_slam_results", "xk_init_msckf_slam_features", "xk_init_standard_slam_features",
-    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps", "xk_probe_fp64_peak",
-    "xk_apply_ci_resident", "xk_snapshot_P", "xk_debug_persist_stamps", "xk_caqr_status", "xk_set_option", "xk_build_compress_async", "xk_build_compress_update_async", "xk_fetch_flags",
+    "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps",
+    "xk_apply_ci_resident", "xk_snapshot_P", "xk_caqr_status", "xk_set_option", "xk_build_compress_async", "xk_build_compress_update_async", "xk_fetch_flags",
     "xk_pr_create", "xk_pr_destroy", "xk_pr_vlad_bytes", "xk_pr_size", "xk_pr_compute_vlad", "xk_pr_add_keyframe",
     "xk_pr_find_candidate", "xk_pr_keyframe", "xk_pr_copy_keyframe", "xk_pr_knn_match",
 ]
+
+
+# what include/xk_lab.h adds (lab build only; the release library must NOT export them)
+LAB_SYMBOLS = ["xk_is_lab", "xk_probe_fp64_peak", "xk_debug_persist_stamps"]
 
 
 class XkTiming(C.Structure):
@@ -48,29 +54,34 @@ class XkError(RuntimeError):
         self.status = status
 
 
-def lib():
-    """Load libxk.so or raise -- never falls back to anything else."""
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(f"{LIB_PATH} not found: build it with `python -m x_multi_agent_amd.build` "
-                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        try:
-            # PyTorch bundles its own HIP runtime; whichever libamdhip64 is loaded first serves the
-            # whole process, so when torch is installed (it is the device-memory / RCCL plumbing of
-            # bench.py and the tests) load it first -- the other order leaves torch without a GPU.
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        L = C.CDLL(LIB_PATH)
-        L.xk_strerror.restype = C.c_char_p
-        L.xk_last_error.restype = C.c_char_p
-        L.xk_last_error.argtypes = [C.c_void_p]
-        L.xk_stream.restype = C.c_void_p
-        L.xk_stream.argtypes = [C.c_void_p]
-        L.xk_payload_doubles.restype = C.c_long
-        _LIB = L
-    return _LIB
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python -m x_multi_agent_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    try:
+        # PyTorch bundles its own HIP runtime; whichever libamdhip64 is loaded first serves the
+        # whole process, so when torch is installed (it is the device-memory / RCCL plumbing of
+        # bench.py and the tests) load it first -- the other order leaves torch without a GPU.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    L.xk_strerror.restype = C.c_char_p
+    L.xk_last_error.restype = C.c_char_p
+    L.xk_last_error.argtypes = [C.c_void_p]
+    L.xk_stream.restype = C.c_void_p
+    L.xk_stream.argtypes = [C.c_void_p]
+    L.xk_payload_doubles.restype = C.c_long
+    return L
+
+
+def lib(lab=False, path=None):
+    """Load libxk.so (lab=True: lab/libxk.so, the -DXK_LAB build with the test hooks; path: any other build of the same ABI,
+    e.g. STRICT_LIB_PATH) or raise -- never falls back to anything else.  Several builds can be loaded in one process."""
+    p = os.path.abspath(path if path else (LAB_LIB_PATH if lab else LIB_PATH))
+    if p not in _LIBS:
+        _LIBS[p] = _load(p)
+    return _LIBS[p]
 
 
 def _d(a):
@@ -91,8 +102,8 @@ def _f(a):
 class Engine:
     """One xk_handle (= one agent / one x::Ekf)."""
 
-    def __init__(self, n_poses_max, n_feat_max, k_max, device=0):
-        self.L = lib()
+    def __init__(self, n_poses_max, n_feat_max, k_max, device=0, lab=False, lib_path=None):
+        self.L = lib(lab, lib_path)
         self.h = C.c_void_p()
         rc = self.L.xk_create(C.c_int(device), C.c_int(n_poses_max), C.c_int(n_feat_max), C.c_int(k_max),
                               C.byref(self.h))
@@ -427,8 +438,8 @@ class Engine:
         return dict(schedule=v[0].value, armed=bool(v[1].value), giveups=v[2].value, last_reason=v[3].value)
 
     def set_option(self, name, value):
-        """xk_set_option: experiment switches / test hooks of the compression on this handle ("caqr_resident", "caqr_poison",
-        "caqr_test_stall", "caqr_tall26", "caqr_rearm"); their defaults come from the environment at creation."""
+        """xk_set_option: "caqr_resident", "caqr_rearm" (release library); the lab build (Engine(..., lab=True)) adds the test hooks and
+        A/B switches "caqr_poison", "caqr_test_stall", "caqr_tall26", "pipe_kalman" (include/xk_lab.h)."""
         self._chk(self.L.xk_set_option(self.h, name.encode(), C.c_int(int(value))), "xk_set_option")
 
     def probe_fp64_peak(self, use_mfma=True):
@@ -450,3 +461,9 @@ class Engine:
 
     def run_steps(self, sigma_img, steps):
         self._chk(self.L.xk_run_steps(self.h, C.c_double(sigma_img), C.c_int(steps)), "xk_run_steps")
+
+
+def LabEngine(*a, **kw):
+    """An Engine on the lab build of the library (x_multi_agent_amd/lab/libxk.so, -DXK_LAB): what tests and tools/exp use when they
+    need a test hook, an environment switch or a probe kernel.  Both libraries can be loaded in one process."""
+    return Engine(*a, lab=True, **kw)

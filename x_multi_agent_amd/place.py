@@ -13,12 +13,15 @@ import numpy as np
 from .engine import XkError, c_dp, c_ip
 
 c_ub = C.POINTER(C.c_ubyte)
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
-def load_vocabulary(name="visual"):
-    """The reference's own vocabulary (Vocabulary/<name>_voc_3_4_dbow3.yaml) as unpacked arrays."""
-    return dict(np.load(os.path.join(GOLDEN, f"vocab_{name}.npz")))
+def load_vocabulary(name="visual", path=None):
+    """A DBoW3 vocabulary as unpacked arrays (k, L, desc, children, word_of_node, node_of_word).
+    path: an .npz a deployment unpacked from its own Vocabulary/*.yaml (tools in tests/golden/make_vocab_fixture.py);
+    default: the package's own copy of the reference's vocabulary `name` (Vocabulary/<name>_voc_3_4_dbow3.yaml),
+    x_multi_agent_amd/data/vocab_<name>.npz."""
+    return dict(np.load(path if path else os.path.join(DATA, f"vocab_{name}.npz")))
 
 
 def _u8(a):
