@@ -231,7 +231,7 @@ bool Ekf::beginResidentUpdate(int idx) {
   update_invalidated_ = false;
   snapshot_valid_ = false;
   if (sz - 1 - live < kWrapMargin) {
-    check(updater_.engine(), xk_snapshot_P(updater_.engine(), 0), "xk_snapshot_P");
+    check(updater_.engine(), xk_snapshot_P(updater_.engine(), 2), "xk_snapshot_P");   // (slot 2 / 3: the filter loop's own)
     snapshot_valid_ = true;
   }
   return true;
@@ -244,7 +244,7 @@ bool Ekf::endResidentUpdate() {
   if (!update_invalidated_) return true;
   update_invalidated_ = false;
   xk_handle *xk = updater_.engine();
-  check(xk, xk_snapshot_P(xk, 1), "xk_snapshot_P");
+  check(xk, xk_snapshot_P(xk, 3), "xk_snapshot_P");
   check(xk, xk_cov_propagate(xk, deferred_phi_.m, 15, deferred_q_.m, 15), "xk_cov_propagate");
   cov_idx_ = cov_target_;
   return false;

@@ -328,7 +328,9 @@ int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *in
 int xk_apply_ci_resident(xk_handle *h, const double *ci_P, int ldc, int n, const double *H, int ldh, int m,
                          const double *res, const double *S, int lds, double *correction);
 
-/* Save (restore = 0) / bring back (restore = 1) a device-side copy of the resident covariance. */
+/* Save (restore = 0) / bring back (restore = 1) a device-side copy of the resident covariance; 2 / 3: the same on a second slot,
+ * which the filter loop (x::Ekf with a resident covariance) keeps for itself: the prior of an update that the IMU thread may lap
+ * (Ekf::repropagateFromStateAtIdx, ekf.cpp:229-239, discards such an update). */
 int xk_snapshot_P(xk_handle *h, int restore);
 
 /* ---- measurement ----------------------------------------------------- */

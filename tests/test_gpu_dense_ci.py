@@ -381,16 +381,17 @@ def test_device_ci_round_full_size_against_the_oracle(xk, oracle_c, world):
     assert rel(P_d, sc["P"]) > 1e-3
 
 
-def test_fused_covariance_fed_back_with_updates_and_propagation_between_rounds(xk):
-    """bench.py replays every CI round from the staged prior because a prior that ONLY ever takes covariance
-    intersections grows by 1 / w0 per fusion (block scaling, msckf_update.cpp:256-267) and leaves the filter's range after a few
-    rounds at 8 agents.  That growth is the workload, not the CI kernels: the same kernels, with applyCI's posterior fed back as
-    the next prior the way the reference does it (updater.cpp:155) AND a visual update plus a covariance propagation between two
-    rounds -- what a running filter does -- stay bounded, symmetric and positive definite for 40 rounds; without the updates in
-    between the pose blocks grow geometrically (or the innovation covariance stops being positive definite)."""
+def test_fused_covariance_fed_back_with_updates_and_propagation_between_rounds(xk, oracle_c):
+    """bench.py replays every CI round from the staged prior because a prior that keeps taking covariance
+    intersections grows by 1 / w0 per fusion in the blocks it scales (msckf_update.cpp:256-267) -- the visual updates in between pull
+    back only what they observe (not the global position / yaw gauge) -- and leaves the filter's range after a few rounds at 8 agents.
+    That growth is the WORKLOAD, not the CI kernels: here applyCI's posterior is fed back as the next prior the way the reference does
+    it (updater.cpp:155), with a visual update and seven covariance propagations between two rounds, for eight rounds at four agents,
+    on the device AND through the C oracle (msckf_ci_track + apply_ci per track, visual_update, F P F^T + Q): the two chains agree to
+    rounding after every round and show the same growth."""
     import torch
     from x_multi_agent_amd import fleet
-    world, N, K, M, n_tracks, w = 8, 10, 40, 0, 2, 0.05
+    world, N, K, M, n_tracks, w, rounds = 4, 10, 40, 0, 2, 0.05, 8
     w0 = 1.0 - (world - 1) * w
     scs, lm = [], None
     for r in range(world):
@@ -408,35 +409,45 @@ def test_fused_covariance_fed_back_with_updates_and_propagation_between_rounds(x
     F = np.eye(15); F[0:3, 3:6] = 0.005 * np.eye(3)               # a short IMU step: position picks up velocity
     Q = 1e-8 * np.eye(15)
     pose = slice(15, 15 + 6 * N)
+    tr = [synth.tracks_as_list(s_) for s_ in scs]
 
-    def run(rounds, with_filter_steps):
-        eng = xk.Engine(N, M, K)
-        eng.stage(sc)
-        tr, err = [float(np.trace(sc["P"][pose, pose]))], None
-        try:
-            for _ in range(rounds):
-                fused, _ = fleet.ci_round_device(eng, sc, rank, world, dp, dt, n_tracks, w)      # the fused covariance STAYS resident
-                assert fused >= 1
-                if with_filter_steps:
-                    eng.visual_update_staged(sc["sigma_img"])                                    # posterior -> next prior
-                    for _ in range(7):
-                        eng.cov_propagate(F, Q)
-                P = eng.download_P()
-                assert np.isfinite(P).all() and np.abs(P - P.T).max() <= 1e-12 * np.abs(P).max()
-                tr.append(float(np.trace(P[pose, pose])))
-        except xk.XkError as e:
-            err = e
-        P = eng.download_P()
-        eng.close()
-        return tr, err, P
+    def oracle_round(P):
+        last = None
+        for j in range(n_tracks):                                  # every entry from the same prior, applyCI overwrites
+            matches = [dict(obs=tr[r][j], q_list=scs[r]["C_q_G"], p_list=scs[r]["G_p_C"], P=scs[r]["P"], n_poses_max=N)
+                       for r in range(world) if r != rank]
+            o = oracle_c.msckf_ci_track(tr[rank][j], sc["C_q_G"], sc["G_p_C"], P, N, sc["sigma_img"], matches, w)
+            if o["ci"] is not None:
+                c = o["ci"]
+                last, _ = oracle_c.apply_ci(c["P_j"], c["H"], c["res"], c["S"])
+        P = P if last is None else last
+        P = oracle_c.visual_update(dict(sc, P=P))["P"]
+        for _ in range(7):
+            P = P.copy()
+            P[:15, :] = F @ P[:15, :]
+            P[:, :15] = P[:, :15] @ F.T
+            P[:15, :15] += Q
+        return P
 
-    tr_f, err_f, P_f = run(40, True)
-    assert err_f is None, err_f
-    assert max(tr_f) <= 4.0 * tr_f[0] and min(tr_f) >= 1e-4 * tr_f[0], (tr_f[0], max(tr_f), min(tr_f))
-    ev = np.linalg.eigvalsh(P_f)
-    assert ev.min() > 0, ev.min()
-    tr_c, err_c, _ = run(12, False)
-    # CI only: either the update's innovation covariance gave out (XK_ESINGULAR) or the pose blocks grew like (1 / w0)^rounds
-    assert err_c is not None or tr_c[-1] >= (1.0 / w0) ** (0.5 * (len(tr_c) - 1)) * tr_c[0], (tr_c, err_c)
-    print(f"pose-block trace: with filter steps {tr_f[0]:.3e} -> {tr_f[-1]:.3e} over 40 rounds; CI only {tr_c[0]:.3e} -> {tr_c[-1]:.3e} over {len(tr_c) - 1} rounds"
-          f"{' (then ' + str(err_c) + ')' if err_c else ''}; 1 / w0 = {1 / w0:.3f}")
+    eng = xk.Engine(N, M, K)
+    eng.stage(sc)
+    P_o = sc["P"].copy()
+    growth, worst = [], 0.0
+    for rd in range(rounds):
+        fused, _ = fleet.ci_round_device(eng, sc, rank, world, dp, dt, n_tracks, w)          # the fused covariance STAYS resident
+        assert fused >= 1
+        eng.visual_update_staged(sc["sigma_img"])                                            # posterior -> next prior
+        for _ in range(7):
+            eng.cov_propagate(F, Q)
+        P_d = eng.download_P()
+        t_before = np.trace(P_o[pose, pose])
+        P_o = oracle_round(P_o)
+        growth.append(float(np.trace(P_o[pose, pose]) / t_before))
+        worst = max(worst, rel(P_d, P_o))
+        assert rel(P_d, P_o) <= 1e-7, (rd, rel(P_d, P_o))
+        assert np.isfinite(P_d).all() and np.abs(P_d - P_d.T).max() <= 1e-12 * np.abs(P_d).max()
+    eng.close()
+    # the pose blocks grow round after round in BOTH chains -- the workload -- by less than the 1 / w0 the block scaling alone would give
+    assert all(1.0 < g < 1.0 / w0 for g in growth[1:]), (growth, 1.0 / w0)
+    print(f"fed-back CI + filter steps, {rounds} rounds at {world} agents: device vs oracle worst rel dP {worst:.2e}; "
+          f"pose-block trace growth per round {min(growth):.3f}..{max(growth):.3f} (1 / w0 = {1 / w0:.3f})")

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 N_CASES = 30
 
 
-def _strict_twin(xk, N, M, K, sc, P, corr, schedule):
+def _strict_twin(xk, N, M, K, sc, P, corr, schedule, updates=1):
     """the relaxed hand-offs of the single launch (csrc/xk_xcd_sync.hip.h: what gfx950 does) held to the
     -DXK_SYNC_STRICT=1 build (agent-scope release / acquire pairs: what the HIP memory model promises) on EVERY shape of the soak,
     bit for bit -- same arithmetic in the same order, so any difference is a hand-off that let a stale word through."""
@@ -23,8 +23,9 @@ def _strict_twin(xk, N, M, K, sc, P, corr, schedule):
         from x_multi_agent_amd import build
         build.build_strict()
     eng = xk.Engine(N, M, K, lib_path=xk.STRICT_LIB_PATH)
-    eng.stage(sc)
-    got = eng.visual_update_staged(sc["sigma_img"])
+    for _ in range(updates):       # (the same history as the relaxed handle: the geometry of an update follows the acceptance ratio of the one before)
+        eng.stage(sc)
+        got = eng.visual_update_staged(sc["sigma_img"])
     Ps = eng.download_P()
     st = eng.caqr_status()
     eng.close()
@@ -65,7 +66,7 @@ def test_random_shapes_against_the_oracle(xk, oracle_c):
         assert st["giveups"] == 0, (N, K, kw, st)
         P_last = eng.download_P()
         eng.close()
-        _strict_twin(xk, N, 0, K, sc, P_last, got["correction"], st["schedule"])
+        _strict_twin(xk, N, 0, K, sc, P_last, got["correction"], st["schedule"], updates=3)
     assert not bad, bad
     assert took >= N_CASES // 2, f"only {took} of {N_CASES} random shapes took the single-launch path"
     print(f"soak: {N_CASES} shapes, {took} on the single launch, worst rel dP {worst:.2e}")
@@ -105,7 +106,7 @@ def test_random_shapes_with_slam_rows_against_the_oracle(xk, oracle_c):
         assert st["giveups"] == 0, (N, K, M, kw, st)
         P_last = eng.download_P()
         eng.close()
-        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], st["schedule"])
+        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], st["schedule"], updates=2)
     assert not bad, bad
     assert took >= 8 and wide >= 3, (took, wide)
     print(f"soak (SLAM rows): 16 shapes, {took} on the single launch ({wide} wide), worst rel dP {worst:.2e}")
@@ -166,7 +167,7 @@ def test_random_wide_windows_against_the_oracle(xk, oracle_c):
         assert eng.caqr_status()["schedule"] == 0
         P_last = eng.download_P()
         eng.close()
-        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], 0)      # (multi-launch schedule: no in-launch hand-offs, the two builds must agree trivially)
+        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], 0, updates=2)      # (multi-launch schedule: no in-launch hand-offs, the two builds must agree trivially)
     assert not bad, bad
     print(f"soak: 12 wide windows, worst rel dP {worst:.2e}")
 
@@ -186,6 +187,9 @@ def test_repeated_updates_are_bit_identical(xk, cfg, reps):
         eng.upload_P(sc["P"])
         r = eng.visual_update_staged(sc["sigma_img"])
         P = eng.download_P()
+        if i == 0:
+            zero = P.copy()          # (the first update of a handle may take another geometry than the following ones: it does not
+            continue                 #  know the acceptance ratio yet -- equal to rounding, not bit for bit)
         if first is None:
             first = (P.copy(), r["correction"].copy())
         elif not (np.array_equal(P, first[0]) and np.array_equal(r["correction"], first[1])):
@@ -193,4 +197,5 @@ def test_repeated_updates_are_bit_identical(xk, cfg, reps):
     st = eng.caqr_status()
     eng.close()
     assert not diff, (cfg, len(diff), diff[:10])
+    assert np.linalg.norm(zero - first[0]) <= 1e-11 * np.linalg.norm(first[0])
     assert st["giveups"] == 0, st

@@ -39,7 +39,8 @@ struct xk_handle {
   double *d_q, *d_p, *d_obs, *d_feat, *d_zlast;
   int *d_trk_off, *d_anchor, *d_tsz;
   double *d_P, *d_Pout;
-  double *d_Psnap;        // xk_snapshot_P
+  double *d_Psnap;        // xk_snapshot_P (slot of the caller)
+  double *d_Psnap2;       // ... slot of the filter loop (x::Ekf saves the prior of an update the IMU thread may lap)
   double *d_fq;           // f_d, q_d of xk_cov_propagate
   double *d_chi95, *d_chi90;
   double *d_A;
@@ -56,6 +57,12 @@ struct xk_handle {
   unsigned *d_xsync;
   int xsync_phase;
   int pipe_rows_nominal;   // rows the last single launch was queued for, every track counted as accepted
+  // Geometry with two first-level groups per XCD (XkPipeNarrow2: 152 tiles): taken when the rows expected to pass the gates fit it.
+  // The expectation is the acceptance ratio the last single launch reported (status word 2) applied to this update's nominal rows.
+  int opt_split;           // 0 never, 1 adaptive (default), 2 whenever the NOMINAL rows fit (lab)
+  double acc_ratio;        // accepted / nominal rows of the last single launch (0: none yet)
+  bool last_split;         // the last single launch used that geometry
+  int split_backoff;       // updates for which it stays off after it found more rows than it holds
   int overflow_rows;       // a single launch of that many nominal rows found more accepted rows than its tiles hold: not tried again at that size
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
   bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
@@ -265,6 +272,11 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       const void *kfn = h->C1 <= XkPipeNarrow::COLS ? (const void *)xk_caqr_pipe<XkPipeNarrow> : (const void *)xk_caqr_pipe<XkPipeWide>;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, kfn, XK_PIPE_THREADS, 0) != hipSuccess) nb1 = 0;
       h->persist_ok = nb1 >= 1;
+      if (h->persist_ok && h->C1 <= XkPipeNarrow::COLS) {
+        int nb2 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void *)xk_caqr_pipe<XkPipeNarrow2>, XK_PIPE_THREADS, 0) != hipSuccess) nb2 = 0;
+        if (nb2 < 1) h->opt_split = -1;      // (that geometry's kernel does not fit a CU: never taken)
+      }
       (void)hipGetLastError();
     }
     h->fast_capable = h->persist_ok;
@@ -274,6 +286,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     h->opt_test_stall = env_int("XK_CAQR_TEST_STALL", 0);
     h->opt_tall26 = env_int("XK_CAQR_TALL26", 1);
     h->opt_kalman = env_int("XK_PIPE_KALMAN", 1);
+    h->opt_split = env_int("XK_PIPE_SPLIT", 1);
     if (!h->fast_capable && h->DB == 64 && h->C1 <= XkPipeWide::COLS) {
       // Say so once, where an operator sees it: every update of this handle takes the multi-launch schedule (~1.6x slower).
       snprintf(h->err, sizeof(h->err), "single-launch CAQR unavailable on device %d: %s; the multi-launch schedule serves every update",
@@ -283,7 +296,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       if (!quiet) fprintf(stderr, "xk: %s (n_cu = %d)\n", h->err, h->n_cu);
     }
     if (h->persist_ok) {
-      const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * 8 * 16;
+      const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * 8 * 2 * 16;   // (x 2: the geometry with two first-level groups per XCD sends 16 roots up)
       HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
       HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
@@ -370,6 +383,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   free(h->h_trk2_off);
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Psnap) hipFree(h->d_Psnap);
+  if (h->d_Psnap2) hipFree(h->d_Psnap2);
   if (h->d_fq) hipFree(h->d_fq);
   for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_xsync})
     if (p4) hipFree(p4);
@@ -866,7 +880,15 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     int R_nom = 2 * h->M;
     for (int k = 0; k < h->K; ++k) R_nom += 2 * (h->h_trk_off[k + 1] - h->h_trk_off[k]) - 3;
     for (int k = 0; k < h->K2; ++k) R_nom += 2 * (h->h_trk2_off[k + 1] - h->h_trk2_off[k]) - 3;
-    const int NTP = 8 * (narrow ? XkPipeNarrow::NT : XkPipeWide::NT);
+    // two first-level groups per XCD when the rows expected to pass fit 152 tiles (4 % and a tile's worth of margin); a launch
+    // that finds more gives up at once (reason 9) and that geometry stays off for a while -- the 184-tile launch redoes the update
+    bool split = false;
+    if (narrow && h->opt_split > 0) {
+      if (h->split_backoff > 0) --h->split_backoff;
+      else if (h->opt_split >= 2) split = R_nom <= XkPipeNarrow2::ROWS;
+      else if (h->acc_ratio > 0.0) split = (long)(h->acc_ratio * 1.04 * R_nom) + 128 <= XkPipeNarrow2::ROWS;
+    }
+    const int NTP = 8 * (narrow ? (split ? XkPipeNarrow2::NT : XkPipeNarrow::NT) : XkPipeWide::NT);
     h->pipe_rows_nominal = R_nom;
     if (R_nom >= 64 * 8 && ntiles <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
       XkCaqrPipeArgs pa;
@@ -899,7 +921,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
         pa.done_flag = fuse->done_flag; pa.done_seq = fuse->done_seq;
         h->last_fused = true;
       }
-      if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      h->last_split = split;
+      if (split) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow2>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      else if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeWide>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       if (mid) hipEventRecord(mid, h->stream);
       h->nleaf = NTP; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = true;
@@ -1149,6 +1173,10 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
 
 #define XK_RETRY_CLASSIC 1000   // internal: the single-launch CAQR gave up, the multi-launch schedule must redo the update
 static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
+  if (h->last_pipe && h->pipe_rows_nominal > 0 && h->d_status[2] > 0) {   // what the last single launch found (status word 2)
+    h->acc_ratio = (double)h->d_status[2] / h->pipe_rows_nominal;
+    h->d_status[2] = 0;
+  }
   if (st != 0 || pst != 0) {
     hipStreamSynchronize(h->stream);
     h->d_status[0] = h->d_status[1] = 0;
@@ -1158,6 +1186,17 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
     // The fast path steps aside, but not for the life of the handle: after `rearm_after` clean multi-launch updates it is
     // tried again (the other tenant of the GPU may be gone); every further give-up doubles that distance, so a permanently
     // shared GPU costs one bounded retry (<= 2 ms, xk_spin_ge) every few thousand updates at most.
+    if (pst == 9 && h->last_split) {
+      // the 152-tile geometry was chosen on the LAST update's acceptance ratio and this update passed more: not a co-residency
+      // problem and not a capacity cliff of the fast path -- the 184-tile launch redoes the update, the split geometry stays off
+      // for the next 64 updates
+      h->split_backoff = 64;
+      h->fast_giveups++; h->fast_reason = pst;
+      h->xsync_dirty = true;
+      h->have_rows = h->have_R = false;
+      snprintf(h->err, sizeof(h->err), "single-launch CAQR (152 tiles): more rows passed the gates than expected; redone with 184 tiles");
+      return allow_retry ? XK_RETRY_CLASSIC : XK_EDEVICE;
+    }
     if (pst == 9) {
       // not a co-residency problem: more rows passed the gates than the tiles of the single launch hold.  The fast path stays
       // armed for smaller stacks; this size goes to the multi-launch schedule from now on.
@@ -1556,14 +1595,16 @@ extern "C" int xk_apply_ci_resident(xk_handle *h, const double *ci_P, int ldc, i
 // Keeps / brings back a copy of the resident covariance on the device (restore = 0: save, 1: restore).  Benchmarks
 // use it to replay a frame from the same prior without a PCIe upload.
 extern "C" int xk_snapshot_P(xk_handle *h, int restore) {
-  if (!h) return XK_EINVAL;
+  if (!h || restore < 0 || restore > 3) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t bytes = sizeof(double) * (size_t)h->n * h->n;
-  if (!h->d_Psnap) {
-    if (restore) return fail(h, XK_EINVAL, "xk_snapshot_P: nothing saved");
-    HIPCHK(h, dalloc(&h->d_Psnap, (size_t)h->n * h->n));
+  double *&slot = (restore >= 2) ? h->d_Psnap2 : h->d_Psnap;     // 0 / 1: the caller's slot; 2 / 3: the filter loop's own (x::Ekf)
+  const bool back = restore & 1;
+  if (!slot) {
+    if (back) return fail(h, XK_EINVAL, "xk_snapshot_P: nothing saved");
+    HIPCHK(h, dalloc(&slot, (size_t)h->n * h->n));
   }
-  HIPCHK(h, hipMemcpyAsync(restore ? h->d_P : h->d_Psnap, restore ? h->d_Psnap : h->d_P, bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(back ? h->d_P : slot, back ? slot : h->d_P, bytes, hipMemcpyDeviceToDevice, h->stream));
   return XK_OK;
 }
 
@@ -2372,6 +2413,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
   else if (!strcmp(name, "caqr_test_stall")) h->opt_test_stall = value;
   else if (!strcmp(name, "caqr_tall26")) h->opt_tall26 = value;
   else if (!strcmp(name, "pipe_kalman")) h->opt_kalman = value;
+  else if (!strcmp(name, "pipe_split")) { if (h->opt_split >= 0) h->opt_split = value; }
 #endif
   else return fail(h, XK_EINVAL, "xk_set_option: unknown option");
   return XK_OK;

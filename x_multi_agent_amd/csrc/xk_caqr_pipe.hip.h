@@ -36,12 +36,20 @@
 // Geometry of a launch.  LPC lanes per column x RPL rows per lane = rows of a fat tile (768 / LPC columns per workgroup);
 // per XCD: NT tile workgroups + NM first-level workgroups + 1 last-level workgroup = 32 = the CUs of an XCD; NCL = column
 // sets per last-level thread (its 8 workgroups cover NCL x 8 x <= 32 trailing columns), NCM = column sets per first-level thread.
-template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_, int RPLT_ = RPLS_>
+// NG = first-level GROUPS per XCD (round 5): the XCD's NT strips are merged NTG = ceil(NT / NG) at a time by NM / NG workgroups each,
+// every group with a pending strip and a root of its own -- the last level then merges 8 NG roots.  A first-level lane holds
+// NTG + 1 rows instead of NT + 1: its steps and its strip loads are that much shorter, and the first level's chain is what a panel
+// waits for.  It takes NG times the first-level workgroups for the same columns, i.e. fewer tile workgroups:
+// the geometry for stacks whose ACCEPTED rows fit them.
+template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_, int RPLT_ = RPLS_, int NG_ = 1>
 struct XkPipeGeom {
-  static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_, NCM = NCM_;
+  static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_, NCM = NCM_, NG = NG_;
+  static constexpr int NTG = (NT_ + NG_ - 1) / NG_, NMG = NM_ / NG_;   // strips / workgroups of a first-level group
+  static_assert(NM_ % NG_ == 0 && NG_ >= 1 && NG_ <= 2, "first-level groups share the first-level workgroups evenly");
   static constexpr int RPLS = RPLS_, RPLT = RPLT_;         // lighter tile-step instantiations: fewer rows per lane, taken when the ACCEPTED rows fit
   static_assert(RPLS_ % 4 == 0 && RPLS_ >= 16 && RPLS_ <= RPL_ && RPLT_ % 4 == 0 && RPLT_ >= 16 && RPLT_ <= RPLS_, "the lighter tile steps");
-  static constexpr int RM = (NT_ + 2) & ~1;                // registers of a first-level lane: pending strip + NT strips, even
+  static constexpr int RM = (NTG + 2) & ~1;                // registers of a first-level lane: pending strip + NTG strips, even
+  static constexpr int RL = 8 * NG_;                       // registers of a last-level lane: the roots
   static constexpr int COLS = XK_PIPE_THREADS / LPC_;      // widest system (C1P) a tile workgroup holds
   static constexpr int ROWS = 8 * NT_ * LPC_ * RPL_;       // most stacked rows
   static_assert(NT_ + NM_ + 1 == 32, "one workgroup per CU, 32 CUs per XCD");
@@ -51,6 +59,11 @@ struct XkPipeGeom {
 #define XK_PIPE_NARROW 4, 32, 23, 8, 1, 1, 28, 24
 #endif
 using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
+#ifndef XK_PIPE_NARROW2
+#define XK_PIPE_NARROW2 4, 32, 19, 12, 1, 1, 32, 28, 2
+#endif
+using XkPipeNarrow2 = XkPipeGeom<XK_PIPE_NARROW2>;         // the same columns, 152 tiles of 128 rows, TWO first-level groups per XCD (10 + 9 strips on
+                                                           // 6 workgroups each): taken when the rows that pass the gates are expected to fit 19 456
 #ifndef XK_PIPE_WIDE
 #define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28
 #endif
@@ -459,7 +472,7 @@ __device__ __forceinline__ void xk_pipe_range(double (&b)[RPL], double (*b2)[RPL
 // cost no registers; the host needs no row map (it does not know the verdicts when it queues the launch).
 // Returns TR (0: more rows than the tiles hold -- the launch gives up, the multi-launch schedule serves the update).
 template <class G>
-__device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, int *pre, int *myrows) {
+__device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, int *pre, int *myrows, int *rows_accepted) {
   constexpr int NTP = 8 * G::NT, CAP = G::LPC * G::RPL;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int wsum[XK_PIPE_THREADS / 64];
@@ -484,6 +497,7 @@ __device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, i
   }
   if (tid == 0) pre[0] = 0;
   const int R = carry, TR = (R + NTP - 1) / NTP;
+  *rows_accepted = R;
   __syncthreads();
   if (TR > CAP) return 0;
   if (tid < CAP) {
@@ -620,14 +634,20 @@ __device__ __forceinline__ void xk_lds_dma16(const double *src, unsigned lds_byt
 // (register RM - 1 stays zero when NT is even)
 template <class G>
 __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok, double *pfbuf) {
-  constexpr int NT = G::NT, NM = G::NM, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NCM = G::NCM;
+  constexpr int NT = G::NT, NM = G::NMG, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NCM = G::NCM;
+  constexpr int NG = G::NG, NTG = G::NTG;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
   const int cidx_ = tid / NP, part_ = tid & (NP - 1);
   const bool panel = cidx_ < 16;
   const int npanels = (a.C1 + 15) / 16;
-  const int base = xcc * NT;
+  // my group of this XCD's strips: tiles [grp NTG, grp NTG + nts); `item` counts inside the group from here on (NM = G::NMG)
+  const int grp = NG > 1 ? item / NM : 0;
+  item -= grp * NM;
+  const int nts = NG > 1 ? min(NTG, NT - grp * NTG) : NT;
+  const int base = xcc * NT + grp * NTG;
+  const bool has_pending = !(xcc == 0 && grp == 0);       // (XCD 0's first root is the last level's pivot strip)
   const size_t SS = (size_t)16 * a.C1P;                   // doubles per strip
   const bool stamp = a.dbg && xcc == 0 && item == 0 && tid == 0;
   for (int k = 0; k < npanels; ++k) {
@@ -644,26 +664,27 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
     const bool full = nsteps == 16;
     const unsigned epoch = (unsigned)(k + 1);
-    const size_t slab = (size_t)k * 8 + xcc;
+    const size_t slab = ((size_t)k * 8 + xcc) * NG + grp;
     double b[RM], b2[NCM > 1 ? RM : 2];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
     int ncl_prev, lchalf_prev, lsplit_prev;                 // last-level workgroups of panel k - 1
     xk_pipe_lastcut(a.C1 - c0, NCL, ncl_prev, lchalf_prev, lsplit_prev);
     lsplit_prev = min(XK_PIPE_NLW, lsplit_prev);
-    if (k >= 1 && xcc != 0) {
+    const size_t pslab = ((size_t)(k - 1) * 8 + xcc) * NG + grp;
+    if (k >= 1 && has_pending) {
       if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
-      if (mine) b[0] = xk_ld_sc1(a.X2 + ((size_t)(k - 1) * 8 + xcc) * SS + xk_blk(col, part));
+      if (mine) b[0] = xk_ld_sc1(a.X2 + pslab * SS + xk_blk(col, part));
     }
 #pragma unroll
     for (int s = 1; s < RM; ++s) b[s] = 0.0;
     if constexpr (NCM > 1) {
 #pragma unroll
       for (int s = 0; s < RM; ++s) b2[s] = 0.0;
-      if (k >= 1 && xcc != 0 && mine2) b2[0] = xk_ld_sc1(a.X2 + ((size_t)(k - 1) * 8 + xcc) * SS + xk_blk(col2, part));
+      if (k >= 1 && has_pending && mine2) b2[0] = xk_ld_sc1(a.X2 + pslab * SS + xk_blk(col2, part));
     }
     double *g02 = a.S + (size_t)base * SS + xk_blk(min(col2, a.C1P - 1), part);
-    double *x12 = a.X1 + ((size_t)k * 8 + xcc) * SS + xk_blk(min(col2, a.C1P - 1), part);
+    double *x12 = a.X1 + slab * SS + xk_blk(min(col2, a.C1P - 1), part);
     const size_t lane_off = panel ? xk_blk(cidx, part) : xk_blk(col, part);
     const size_t strip_step = panel ? 256 : SS;
     double *g0 = (panel ? a.PB + (size_t)base * 256 : a.S + (size_t)base * SS) + lane_off;
@@ -677,7 +698,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     // unit, 1.5 us per phase, four times per panel, on the chain of both dependency loops.  Instead every wave asks for its 23
     // lines with THREE 16-bytes-per-lane loads that land straight in LDS (lane l: strip 8 j + l / 8, piece l % 8), and the
     // lanes of the phase pick their 23 values up from there.
-    constexpr bool PF = XK_PIPE_PF && NCM == 1 && NPH == 4 && NT <= 24 && xk_pb(1) == 4 && xk_pb(2) == 8 && xk_pb(3) == 12;
+    constexpr bool PF = XK_PIPE_PF && NG == 1 && NCM == 1 && NPH == 4 && NT <= 24 && xk_pb(1) == 4 && xk_pb(2) == 8 && xk_pb(3) == 12;
     const int ln = tid & 63, cid4 = cidx & ~3;
     const int wcol = panel ? c0 + cid4 : c0 + 16 + item * mch + (cid4 - 16);
     const bool wv_ok = active && (panel || cid4 - 16 < mh) && wcol < a.C1;
@@ -729,14 +750,16 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
           if (active && mine && part >= xk_pb(loaded) && part < xk_pb(av)) {
             double *g = xk_opaque(g0);
 #pragma unroll
-            for (int s = 1; s <= NT; ++s) b[s] = XK_LD_LOC(g + (size_t)(s - 1) * strip_step);
+            for (int s = 1; s <= NTG; ++s)
+              if (NG == 1 || s <= nts) b[s] = XK_LD_LOC(g + (size_t)(s - 1) * strip_step);
           }
         }
         if constexpr (NCM > 1) {
           if (mine2 && part >= xk_pb(loaded) && part < xk_pb(av)) {
             double *g = xk_opaque(g02);
 #pragma unroll
-            for (int s = 1; s <= NT; ++s) b2[s] = xk_ld_sc1(g + (size_t)(s - 1) * SS);
+            for (int s = 1; s <= NTG; ++s)
+              if (NG == 1 || s <= nts) b2[s] = xk_ld_sc1(g + (size_t)(s - 1) * SS);
           }
         }
         loaded = av;
@@ -775,7 +798,8 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         // the tiles' strips first (the tiles wait for them), then the last rows of the root
         double *g = xk_opaque(g0);
 #pragma unroll
-        for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * strip_step] = b[s];
+        for (int s = 1; s <= NTG; ++s)
+          if (NG == 1 || s <= nts) g[(size_t)(s - 1) * strip_step] = b[s];
       }
       if (x1_mine && part >= xk_pb(NPH - 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
     }
@@ -783,7 +807,8 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       if (mine2) {
         double *g = xk_opaque(g02);
 #pragma unroll
-        for (int s = 1; s <= NT; ++s) g[(size_t)(s - 1) * SS] = b2[s];
+        for (int s = 1; s <= NTG; ++s)
+          if (NG == 1 || s <= nts) g[(size_t)(s - 1) * SS] = b2[s];
         if (part >= xk_pb(NPH - 1)) xk_st_sc1(x12, b2[0]);
       }
     }
@@ -807,7 +832,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 // Wide systems (NCL = 2): a trailing thread holds TWO columns, XK_PIPE_NLW lchalf apart -- the second set only takes reflectors.
 template <class G>
 __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NP = 16, RL = 8, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NM = G::NM;
+  constexpr int NP = 16, RL = G::RL, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NM = G::NM;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -829,8 +854,8 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     const bool mine = col < a.C1 && (panel || cidx - 16 < lchalf);
     const bool mine2 = ncl > 1 && !panel && cidx - 16 < lchalf && col2 < a.C1;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
-    const double *src = panel ? a.X1P + (size_t)k * 8 * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * 8 * SS + xk_blk(col, part);
-    const double *src2 = a.X1 + (size_t)k * 8 * SS + xk_blk(min(col2, a.C1P - 1), part);
+    const double *src = panel ? a.X1P + (size_t)k * RL * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * RL * SS + xk_blk(col, part);
+    const double *src2 = a.X1 + (size_t)k * RL * SS + xk_blk(min(col2, a.C1P - 1), part);
     const size_t sstep = panel ? 256 : SS;
     double b[RL], b2[RL];
 #pragma unroll
@@ -873,7 +898,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         if (lidx == 0 && c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col, (part > cidx) ? 0.0 : b[0]);
       } else {
         if (k + 1 < npanels) {
-          double *dst = a.X2 + (size_t)k * 8 * SS + xk_blk(col, part);
+          double *dst = a.X2 + (size_t)k * RL * SS + xk_blk(col, part);
 #pragma unroll
           for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b[s]);
         }
@@ -882,7 +907,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     }
     if (mine2) {
       if (k + 1 < npanels) {
-        double *dst = a.X2 + (size_t)k * 8 * SS + xk_blk(col2, part);
+        double *dst = a.X2 + (size_t)k * RL * SS + xk_blk(col2, part);
 #pragma unroll
         for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b2[s]);
       }
@@ -1285,7 +1310,7 @@ __device__ __noinline__ bool xk_pipe_kalman(XkPipeArgsPtr ap, xk_ldsd *kb, unsig
 template <class G>
 __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a) {
   constexpr int RPL = G::RPL, NT = G::NT, NM = G::NM, RM = G::RM, LPC = G::LPC;
-  constexpr int LDS_T = 2 * LPC * (RPL + 2), LDS_M = 2 * 16 * (RM + 2), LDS_L = 2 * 16 * 10;
+  constexpr int LDS_T = 2 * LPC * (RPL + 2), LDS_M = 2 * 16 * (RM + 2), LDS_L = 2 * 16 * (G::RL + 2);
   constexpr int LDS_MAX = LDS_T > LDS_M ? (LDS_T > LDS_L ? LDS_T : LDS_L) : (LDS_M > LDS_L ? LDS_M : LDS_L);
   __shared__ __attribute__((aligned(16))) double ubuf[LDS_MAX];
   __shared__ __attribute__((aligned(16))) double sc[2 * 4];
@@ -1316,7 +1341,10 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   if (a.test_stall && xcc == 3 && slot == 5) return;
   bool ok;
   if (slot < NT) {
-    const int TR = xk_pipe_rowplan<G>(a, (int)xcc * NT + slot, rp_pre, rp_rows);
+    int rows_acc;
+    const int TR = xk_pipe_rowplan<G>(a, (int)xcc * NT + slot, rp_pre, rp_rows, &rows_acc);
+    // how many rows passed the gates: the host picks the next launch's geometry by it (status word 2, pinned host memory)
+    if (xcc == 0 && slot == 0 && threadIdx.x == 0) __hip_atomic_store(a.status + 2, rows_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (TR == 0) {                                         // more accepted rows than the tiles hold: everybody learns it from the abort word
       if (threadIdx.x == 0) { __hip_atomic_store(ab, 9u, XK_RLX_AGENT); a.status[1] = 9; }
       ok = false;
