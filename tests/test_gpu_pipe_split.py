@@ -3,7 +3,7 @@ workgroups each, 16 roots at the last level -- csrc/xk_caqr_pipe.hip.h).  A firs
 chain a panel waits for is shorter; it holds 19 456 accepted rows instead of 23 552, so the host takes it when the acceptance
 ratio the LAST single launch reported says this update's rows will fit, and a launch that finds more gives up at once and is
 redone with 184 tiles.  Checked here: the geometry itself against the C oracle over the shapes that stress the row plan
-(forced with the lab option "pipe_split" = 2), the adaptive choice, and the overflow path."""
+(forced with the lab option "pipe_split" = 3), the adaptive choice, and the overflow path."""
 import numpy as np
 import pytest
 
@@ -32,7 +32,7 @@ def test_two_first_level_groups_against_the_oracle(xk, oracle_c, name):
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
     eng = xk.LabEngine(N, M, max(K, 1))
-    eng.set_option("pipe_split", 2)                       # the 152-tile geometry whenever the nominal rows fit it
+    eng.set_option("pipe_split", 3)                       # the 152-tile geometry whatever the host expects (every shape here fits it)
     for kal in (1, 0):                                    # Kalman update inside the launch / behind it
         eng.set_option("pipe_kalman", kal)
         eng.stage(sc)

@@ -59,7 +59,7 @@ struct xk_handle {
   int pipe_rows_nominal;   // rows the last single launch was queued for, every track counted as accepted
   // Geometry with two first-level groups per XCD (XkPipeNarrow2: 152 tiles): taken when the rows expected to pass the gates fit it.
   // The expectation is the acceptance ratio the last single launch reported (status word 2) applied to this update's nominal rows.
-  int opt_split;           // 0 never, 1 adaptive (default), 2 whenever the NOMINAL rows fit (lab)
+  int opt_split;           // 0 never, 1 adaptive (default); lab: 2 whenever the NOMINAL rows fit, 3 always
   double acc_ratio;        // accepted / nominal rows of the last single launch (0: none yet)
   bool last_split;         // the last single launch used that geometry
   int split_backoff;       // updates for which it stays off after it found more rows than it holds
@@ -880,13 +880,14 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     int R_nom = 2 * h->M;
     for (int k = 0; k < h->K; ++k) R_nom += 2 * (h->h_trk_off[k + 1] - h->h_trk_off[k]) - 3;
     for (int k = 0; k < h->K2; ++k) R_nom += 2 * (h->h_trk2_off[k + 1] - h->h_trk2_off[k]) - 3;
-    // two first-level groups per XCD when the rows expected to pass fit 152 tiles (4 % and a tile's worth of margin); a launch
+    // two first-level groups per XCD when the rows expected to pass fit 152 tiles (2 % and half a tile's worth of margin); a launch
     // that finds more gives up at once (reason 9) and that geometry stays off for a while -- the 184-tile launch redoes the update
     bool split = false;
     if (narrow && h->opt_split > 0) {
       if (h->split_backoff > 0) --h->split_backoff;
-      else if (h->opt_split >= 2) split = R_nom <= XkPipeNarrow2::ROWS;
-      else if (h->acc_ratio > 0.0) split = (long)(h->acc_ratio * 1.04 * R_nom) + 128 <= XkPipeNarrow2::ROWS;
+      else if (h->opt_split >= 3) split = true;                              // (lab: always -- a stack that does not fit gives up, reason 9)
+      else if (h->opt_split == 2) split = R_nom <= XkPipeNarrow2::ROWS;
+      else if (h->acc_ratio > 0.0) split = (long)(h->acc_ratio * 1.02 * R_nom) + 64 <= XkPipeNarrow2::ROWS;
     }
     const int NTP = 8 * (narrow ? (split ? XkPipeNarrow2::NT : XkPipeNarrow::NT) : XkPipeWide::NT);
     h->pipe_rows_nominal = R_nom;

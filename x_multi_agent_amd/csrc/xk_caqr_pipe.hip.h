@@ -41,9 +41,14 @@
 // NTG + 1 rows instead of NT + 1: its steps and its strip loads are that much shorter, and the first level's chain is what a panel
 // waits for.  It takes NG times the first-level workgroups for the same columns, i.e. fewer tile workgroups:
 // the geometry for stacks whose ACCEPTED rows fit them.
-template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_, int RPLT_ = RPLS_, int NG_ = 1>
+#ifndef XK_PIPE_NPH
+#define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
+#endif
+template <int LPC_, int RPL_, int NT_, int NM_, int NCL_, int NCM_ = 1, int RPLS_ = RPL_, int RPLT_ = RPLS_, int NG_ = 1, int NPH_ = XK_PIPE_NPH>
 struct XkPipeGeom {
   static constexpr int LPC = LPC_, RPL = RPL_, NT = NT_, NM = NM_, NCL = NCL_, NCM = NCM_, NG = NG_;
+  static constexpr int NPH = NPH_;                         // hand-off phases per panel of this geometry (1, 2 or 4: the sync words hold 4)
+  static_assert(NPH_ == 1 || NPH_ == 2 || NPH_ == 4, "XP_TQ_CNT / XP_X1_CNT hold four phases");
   static constexpr int NTG = (NT_ + NG_ - 1) / NG_, NMG = NM_ / NG_;   // strips / workgroups of a first-level group
   static_assert(NM_ % NG_ == 0 && NG_ >= 1 && NG_ <= 2, "first-level groups share the first-level workgroups evenly");
   static constexpr int RPLS = RPLS_, RPLT = RPLT_;         // lighter tile-step instantiations: fewer rows per lane, taken when the ACCEPTED rows fit
@@ -60,32 +65,37 @@ struct XkPipeGeom {
 #endif
 using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
 #ifndef XK_PIPE_NARROW2
-#define XK_PIPE_NARROW2 4, 32, 19, 12, 1, 1, 32, 28, 2
+#define XK_PIPE_NARROW2 4, 32, 19, 12, 1, 1, 32, 28, 2, 2
 #endif
 using XkPipeNarrow2 = XkPipeGeom<XK_PIPE_NARROW2>;         // the same columns, 152 tiles of 128 rows, TWO first-level groups per XCD (10 + 9 strips on
                                                            // 6 workgroups each): taken when the rows that pass the gates are expected to fit 19 456
 #ifndef XK_PIPE_WIDE
-#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28
+#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28, 1, 2
 #endif
 using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
 #define XK_PIPE_NT_MAX 23
 #define XK_PIPE_ROWS_MAX 24320
 #define XK_PIPE_SLOTS_MAX 1536      // 64-row slots (tracks + packed SLAM rows) a launch can compact
-#ifndef XK_PIPE_NPH
-#define XK_PIPE_NPH 4               // hand-off phases per panel: a level publishes 16 / NPH rows of its strip at a time
-#endif
-// Phase boundaries: phase q = reflector steps / strip rows [xk_pb(q), xk_pb(q + 1)); equal phases unless NPH = 4 and XK_PIPE_PB says
+// Phase boundaries: phase q = reflector steps / strip rows [xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1)); equal phases unless NPH = 4 and XK_PIPE_PB says
 // otherwise.  (Measured, round 4: a short first phase -- the level above starts when the level below has published its first
 // phase -- does NOT pay: 0,2,6,11,16: QR 0.348 ms, 0,3,7,11,16: 0.342, 0,1,4,9,16: 0.347 against 0.339 for 0,4,8,12,16.)
 #ifndef XK_PIPE_PB
 #define XK_PIPE_PB 0, 4, 8, 12, 16
 #endif
-__host__ __device__ constexpr int xk_pb(int q) {
-  if (XK_PIPE_NPH == 4) {
+#ifndef XK_PIPE_PB2
+#define XK_PIPE_PB2 0, 8, 16        // ... of the two-phase geometries
+#endif
+template <int NPH>
+__host__ __device__ constexpr int xk_pbn(int q) {
+  if (NPH == 4) {
     constexpr int t[] = {XK_PIPE_PB};
     return q <= 0 ? 0 : (q >= 4 ? 16 : t[q]);
   }
-  return q * (16 / XK_PIPE_NPH);
+  if (NPH == 2) {
+    constexpr int t[] = {XK_PIPE_PB2};
+    return q <= 0 ? 0 : (q >= 2 ? 16 : t[q]);
+  }
+  return q * (16 / NPH);
 }
 #ifndef XK_PIPE_ARRD
 #define XK_PIPE_ARRD 1              // a phase's rows are counted in at the barrier ARRD steps after their stores were issued
@@ -520,8 +530,8 @@ __device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, i
 template <class G, int RPL>
 __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok,
                                           const int *myrows) {
-  constexpr int NT = G::NT, LPC = G::LPC, NPH = XK_PIPE_NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
-  static_assert(ARRD < xk_pb(1) && ARRD < 16 - xk_pb(NPH - 1), "a phase is counted in before the next one is published");
+  constexpr int NT = G::NT, LPC = G::LPC, NPH = G::NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
+  static_assert(ARRD < xk_pbn<NPH>(1) && ARRD < 16 - xk_pbn<NPH>(NPH - 1), "a phase is counted in before the next one is published");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -571,16 +581,16 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_TQ_CNT + (q - 1) * 8 + xcc) * 16); };
-      xk_pipe_range<LPC, xk_pb(q), xk_pb(q + 1), (q > 0 ? xk_pb(q) + ARRD : -1), RPL>(b, nullptr, rel, mine, false, part, nsteps, ubuf, sc, full, hook);
+      xk_pipe_range<LPC, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) + ARRD : -1), RPL>(b, nullptr, rel, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (pub) {
         if (rel < 16) {
           double *pb = xk_opaque(myPB + xk_blk(rel, 0));
 #pragma unroll
-          for (int r = xk_pb(q); r < xk_pb(q + 1); ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
+          for (int r = xk_pbn<NPH>(q); r < xk_pbn<NPH>(q + 1); ++r) pb[r * 4] = (r > rel) ? 0.0 : b[r];
         } else {
           double *ps = xk_opaque(myS + xk_blk(cabs, 0));
 #pragma unroll
-          for (int r = xk_pb(q); r < xk_pb(q + 1); ++r) ps[r * 4] = b[r];
+          for (int r = xk_pbn<NPH>(q); r < xk_pbn<NPH>(q + 1); ++r) ps[r * 4] = b[r];
         }
       }
       if (stamp && q < 4) a.dbg[16 * k + 1 + q] = wall_clock64();
@@ -634,7 +644,7 @@ __device__ __forceinline__ void xk_lds_dma16(const double *src, unsigned lds_byt
 // (register RM - 1 stays zero when NT is even)
 template <class G>
 __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, double *ubuf, double *sc, unsigned *s_ok, double *pfbuf) {
-  constexpr int NT = G::NT, NM = G::NMG, RM = G::RM, NP = 16, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NCM = G::NCM;
+  constexpr int NT = G::NT, NM = G::NMG, RM = G::RM, NP = 16, NPH = G::NPH, GS = 16 / NPH, NCL = G::NCL, NCM = G::NCM;
   constexpr int NG = G::NG, NTG = G::NTG;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
@@ -698,7 +708,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     // unit, 1.5 us per phase, four times per panel, on the chain of both dependency loops.  Instead every wave asks for its 23
     // lines with THREE 16-bytes-per-lane loads that land straight in LDS (lane l: strip 8 j + l / 8, piece l % 8), and the
     // lanes of the phase pick their 23 values up from there.
-    constexpr bool PF = XK_PIPE_PF && NG == 1 && NCM == 1 && NPH == 4 && NT <= 24 && xk_pb(1) == 4 && xk_pb(2) == 8 && xk_pb(3) == 12;
+    constexpr bool PF = XK_PIPE_PF && NG == 1 && NCM == 1 && NPH == 4 && NT <= 24 && xk_pbn<NPH>(1) == 4 && xk_pbn<NPH>(2) == 8 && xk_pbn<NPH>(3) == 12;
     const int ln = tid & 63, cid4 = cidx & ~3;
     const int wcol = panel ? c0 + cid4 : c0 + 16 + item * mch + (cid4 - 16);
     const bool wv_ok = active && (panel || cid4 - 16 < mh) && wcol < a.C1;
@@ -747,7 +757,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
             }
           }
         } else {
-          if (active && mine && part >= xk_pb(loaded) && part < xk_pb(av)) {
+          if (active && mine && part >= xk_pbn<NPH>(loaded) && part < xk_pbn<NPH>(av)) {
             double *g = xk_opaque(g0);
 #pragma unroll
             for (int s = 1; s <= NTG; ++s)
@@ -755,7 +765,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
           }
         }
         if constexpr (NCM > 1) {
-          if (mine2 && part >= xk_pb(loaded) && part < xk_pb(av)) {
+          if (mine2 && part >= xk_pbn<NPH>(loaded) && part < xk_pbn<NPH>(av)) {
             double *g = xk_opaque(g02);
 #pragma unroll
             for (int s = 1; s <= NTG; ++s)
@@ -774,14 +784,14 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
       if constexpr (NCM > 1)
-        xk_pipe_range<0, xk_pb(q), xk_pb(q + 1), (q > 0 ? xk_pb(q) : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full, hook);
+        xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full, hook);
       else
-        xk_pipe_range<0, xk_pb(q), xk_pb(q + 1), (q > 0 ? xk_pb(q) : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
+        xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
       // rows [q GS, (q + 1) GS) of the root are final: out they go (write-through: the last level sits on other XCDs)
-      if (q < NPH - 1 && x1_mine && part >= xk_pb(q) && part < xk_pb(q + 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if (q < NPH - 1 && x1_mine && part >= xk_pbn<NPH>(q) && part < xk_pbn<NPH>(q + 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
       if constexpr (NCM > 1) {
-        if (q < NPH - 1 && mine2 && part >= xk_pb(q) && part < xk_pb(q + 1)) xk_st_sc1(x12, b2[0]);
+        if (q < NPH - 1 && mine2 && part >= xk_pbn<NPH>(q) && part < xk_pbn<NPH>(q + 1)) xk_st_sc1(x12, b2[0]);
       }
       if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
     };
@@ -801,7 +811,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         for (int s = 1; s <= NTG; ++s)
           if (NG == 1 || s <= nts) g[(size_t)(s - 1) * strip_step] = b[s];
       }
-      if (x1_mine && part >= xk_pb(NPH - 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
+      if (x1_mine && part >= xk_pbn<NPH>(NPH - 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
     }
     if constexpr (NCM > 1) {
       if (mine2) {
@@ -809,7 +819,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 #pragma unroll
         for (int s = 1; s <= NTG; ++s)
           if (NG == 1 || s <= nts) g[(size_t)(s - 1) * SS] = b2[s];
-        if (part >= xk_pb(NPH - 1)) xk_st_sc1(x12, b2[0]);
+        if (part >= xk_pbn<NPH>(NPH - 1)) xk_st_sc1(x12, b2[0]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -832,7 +842,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 // Wide systems (NCL = 2): a trailing thread holds TWO columns, XK_PIPE_NLW lchalf apart -- the second set only takes reflectors.
 template <class G>
 __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ubuf, double *sc, unsigned *s_ok) {
-  constexpr int NP = 16, RL = G::RL, NPH = XK_PIPE_NPH, GS = 16 / NPH, NCL = G::NCL, NM = G::NM;
+  constexpr int NP = 16, RL = G::RL, NPH = G::NPH, GS = 16 / NPH, NCL = G::NCL, NM = G::NM;
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x;
@@ -864,12 +874,12 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     int loaded = 0;
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      if (!ok || nsteps <= xk_pb(q)) return;                 // (a short last panel: the roots' rows past its columns are zero)
+      if (!ok || nsteps <= xk_pbn<NPH>(q)) return;                 // (a short last panel: the roots' rows past its columns are zero)
       if (loaded <= q) {
         const int av = xk_pipe_wait_phases(sync + (XP_X1_CNT + k) * 16, XK_CAQR_MAXP * 16, q, NPH, 8u * NM, ab, 5u, s_ok);
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
-        if (part >= xk_pb(loaded) && part < xk_pb(av)) {
+        if (part >= xk_pbn<NPH>(loaded) && part < xk_pbn<NPH>(av)) {
           if (mine) {
 #pragma unroll
             for (int s = 0; s < RL; ++s) b[s] = xk_ld_sc1(src + s * sstep);
@@ -882,7 +892,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         loaded = av;
       }
       if (panel) __builtin_amdgcn_s_setprio(3);
-      xk_pipe_range<0, xk_pb(q), xk_pb(q + 1), -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
+      xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
       if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q + 1] = wall_clock64();
     };
