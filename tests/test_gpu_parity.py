@@ -169,7 +169,8 @@ def test_no_measurements_and_all_outliers(xk):
 def test_staged_equals_convenience_and_is_repeatable(xk):
     sc = synth.make_config(1)
     eng = _engine(xk, sc)
-    a = eng.visual_update(sc)
+    eng.visual_update(sc)          # (a handle's first update does not know the acceptance ratio yet: it may take the 184-tile geometry
+    a = eng.visual_update(sc)      #  and the following ones the 152-tile one -- equal to rounding; bit for bit from the second on)
     eng.stage(sc)
     b = eng.visual_update_staged(sc["sigma_img"])
     Pb = eng.download_P()
@@ -200,12 +201,16 @@ def test_repeated_updates_are_bit_identical(xk):
     sc = synth.make_config(4)
     eng = _engine(xk, sc)
     eng.stage(sc)
-    first = None
-    for _ in range(12):
+    first, zero = None, None
+    for i in range(13):
         eng.upload_P(sc["P"])
         r = eng.visual_update_staged(sc["sigma_img"])
         P = eng.download_P()
+        if i == 0:                 # (the first update of a handle may take another geometry: equal to rounding, checked below)
+            zero = P.copy()
+            continue
         if first is None:
             first = (P.copy(), r["correction"].copy())
         assert np.array_equal(P, first[0]) and np.array_equal(r["correction"], first[1])
+    assert np.linalg.norm(zero - first[0]) <= 1e-11 * np.linalg.norm(first[0])
     eng.close()

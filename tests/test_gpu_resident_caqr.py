@@ -61,7 +61,8 @@ def test_resident_equals_multi_launch(xk, oracle_c, name):
     sc = CASES[name]()
     ra, Pa, ta = _run(xk, sc, True)
     rb, Pb, tb = _run(xk, sc, False)
-    assert ta["n_levels"] == 1 and ta["n_leaf"] == NLEAF.get(name, 184), "the single-launch path did not run"
+    # (narrow systems: 184 tiles, or 152 with two first-level groups per XCD once the handle knows the acceptance ratio -- round 5)
+    assert ta["n_levels"] == 1 and ta["n_leaf"] in ((NLEAF[name],) if name in NLEAF else (184, 152)), "the single-launch path did not run"
     assert tb["n_levels"] > 1
     assert np.array_equal(ra["inlier"], rb["inlier"])
     assert rel(Pa, Pb) <= 1e-11 and rel(ra["correction"], rb["correction"]) <= 1e-9
@@ -80,7 +81,7 @@ def test_msckf_slam_rows_go_through_the_single_launch_too(xk, oracle_c):
     sc2["obs_xy"] = sc["obs_xy"][:sc["trk_off"][50]].copy()
     ra, Pa, ta = _run(xk, sc2, True, ms_tracks=tr[50:56])
     rb, Pb, tb = _run(xk, sc2, False, ms_tracks=tr[50:56])
-    assert ta["n_levels"] == 1 and ta["n_leaf"] == 184 and tb["n_levels"] > 1
+    assert ta["n_levels"] == 1 and ta["n_leaf"] in (184, 152) and tb["n_levels"] > 1
     assert np.array_equal(ra["inlier"], rb["inlier"])
     assert rel(Pa, Pb) <= 1e-11 and rel(ra["correction"], rb["correction"]) <= 1e-9
 
@@ -157,6 +158,8 @@ def test_tracks_staged_in_place_give_the_same_update(xk, oracle_c):
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     eng = xk.Engine(N, 0, K)
     eng.stage(sc)
+    eng.visual_update_staged(sc["sigma_img"])                      # (the first update of a handle does not know the acceptance ratio yet and
+    eng.stage(sc)                                                  #  may take another geometry than the following ones: compare the 2nd and 3rd)
     ra = eng.visual_update_staged(sc["sigma_img"])
     Pa = eng.download_P()
     eng.stage(sc)                                                  # window, SLAM (none) and prior again, then the tracks in place
