@@ -533,6 +533,7 @@ def main():
             if dry:
                 dry_tick[0] = tick
             trk_dev.copy_(tex.send)
+            torch.cuda.current_stream().synchronize()      # (torch's stream wrote trk_dev; the keyframe store copies on the engine's stream)
             kdb.add_keyframe(view("kf", rank, tick), pay_dev.data_ptr(),
                              trk_dev.data_ptr(), tag=step)
             my_vlad = torch.from_numpy(kdb.compute_vlad(view("q", rank, tick)).ravel())

@@ -80,6 +80,7 @@ def test_database_sequence_matches_oracle(eng, vname, thr):
         d = synth.observe_descriptors(scenes[i % 4], int(rng.integers(0, 12)), seed=i)
         pay = torch.full((pay_n,), float(i), dtype=torch.float64, device="cuda")
         trk = torch.arange(trk_n, dtype=torch.float64, device="cuda") + 100.0 * i
+        torch.cuda.synchronize()                     # (torch filled them on ITS stream; the store copies on the engine's)
         db.add_keyframe(d, pay.data_ptr(), trk.data_ptr(), tag=i)
         ora.add_keyframe(ref_pr.Keyframe(d, tag=i))
         payloads[i] = (pay.cpu().numpy(), trk.cpu().numpy())
