@@ -47,8 +47,13 @@ stats = find("trace", "*kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], os.path.join(PROF, f"{tag}{suf}_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats[0])))
-    for r in rows:
-        avg_ns[kname(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]))
+    tot = {}
+    for r in rows:      # (instantiations of one kernel -- the geometries of xk_caqr_pipe -- are one entry: call-weighted average)
+        e = tot.setdefault(kname(r["Name"]), [0.0, 0])
+        e[0] += float(r["TotalDurationNs"])
+        e[1] += int(r["Calls"])
+    for k, (t, c) in tot.items():
+        avg_ns[k] = (t / max(c, 1), c)
     with open(os.path.join(PROF, f"{tag}{suf}_kernel_stats.md"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --config {cfg} --steps 20 --warmup 3 --no-cpu --no-frame-loop ({tag})\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
