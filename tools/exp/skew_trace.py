@@ -1,0 +1,30 @@
+"""Skew of the hand-offs of the single launch across workgroups (XK_CAQR_PERSIST_DBG=1, lab build): per panel, when each
+first-level workgroup had its pending strip / had its phase-0 root rows out, and when each last-level workgroup had the roots."""
+import ctypes as C, os, sys
+sys.path.insert(0, '.')
+os.environ.setdefault("XK_CAQR_PERSIST_DBG", "1")
+os.environ.setdefault("XK_PIPE_SPLIT", "3")
+import numpy as np
+from x_multi_agent_amd import engine, synth
+sc = synth.make_config(4)
+N, K, M = synth.CONFIGS[4]
+eng = engine.LabEngine(N, M, K)
+eng.stage(sc)
+t = eng.bench_staged(sc["sigma_img"], 3, 10)
+NW = 16000
+out = (C.c_longlong * NW)()
+eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
+w = np.array(list(out), dtype=np.int64)
+T = w[:512].reshape(32, 16)
+us = lambda x: x / 100.0
+M1 = w[4096:4096 + 96 * 32].reshape(96, 32)       # [wg][0..15 pending in | 16..31 phase-0 rows out]
+Lw = w[8192:8192 + 7 * 64].reshape(7, 64)          # [lidx][0..15 ph0 in | 16..31 ph1 in | 32..47 out]
+for k in range(1, 11):
+    t0 = T[k, 0]
+    pin = M1[:, k]; pout = M1[:, 16 + k]
+    pin = pin[pin > 0]; pout = pout[pout > 0]
+    l0 = Lw[:, k]; l1 = Lw[:, 16 + k]; lo = Lw[:, 32 + k]; lop = Lw[:, 32 + k - 1]
+    print(f"panel {k:2d}: L(k-1) out {us(lop.min()-t0):6.2f}..{us(lop.max()-t0):6.2f} | M1 pending in {us(pin.min()-t0):6.2f}..{us(pin.max()-t0):6.2f} | "
+          f"M1 ph0 out {us(pout.min()-t0):6.2f}..{us(pout.max()-t0):6.2f} | L ph0 in {us(l0.min()-t0):6.2f}..{us(l0.max()-t0):6.2f} | "
+          f"L ph1 in {us(l1.min()-t0):6.2f}..{us(l1.max()-t0):6.2f} | L out {us(lo.min()-t0):6.2f}..{us(lo.max()-t0):6.2f}")
+eng.close()

@@ -52,7 +52,8 @@ struct xk_handle {
   int nleaf, nlevels;   // of the last compression
   // single-launch CAQR (xk_caqr_pipe.hip.h): cross-XCD exchange slabs, XCD-local strips and panel blocks,
   // two sets of sync words (a launch uses one and zeroes the other for its successor)
-  double *d_x1, *d_x1p, *d_x2;
+  double *d_x1;            // both sets of the cross-XCD slabs (X1 | X2 | X1P each)
+  size_t xslab_doubles;    // ... doubles per set
   double *d_rs, *d_rpb;
   unsigned *d_xsync;
   int xsync_phase;
@@ -296,10 +297,12 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       if (!quiet) fprintf(stderr, "xk: %s (n_cu = %d)\n", h->err, h->n_cu);
     }
     if (h->persist_ok) {
-      const size_t np = (size_t)(h->C1 + 15) / 16, slab = np * 8 * 2 * 16;   // (x 2: the geometry with two first-level groups per XCD sends 16 roots up)
-      HIPCHK(h, dalloc(&h->d_x1, slab * h->C1P));
-      HIPCHK(h, dalloc(&h->d_x2, slab * h->C1P));
-      HIPCHK(h, dalloc(&h->d_x1p, slab * 16));
+      // cross-XCD slabs of the single launch, TWO sets (a launch works on one and re-arms the other for its successor with the
+      // NOT-YET pattern of the data-polled hand-offs, xk_xcd_sync.hip.h): per set X1 | X2 ([panels][16 strips][16 x C1P]) | X1P
+      const size_t np = (size_t)(h->C1 + 15) / 16, strips = np * XK_PIPE_RLS;
+      h->xslab_doubles = strips * 16 * h->C1P * 2 + strips * 256;
+      HIPCHK(h, dalloc(&h->d_x1, 2 * h->xslab_doubles));
+      HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->d_x1, (int)(XK_NOTYET_BITS & 0xffffffffu), 2 * 2 * h->xslab_doubles, h->stream));
       HIPCHK(h, dalloc(&h->d_rs, (size_t)8 * XK_PIPE_NT_MAX * 16 * h->C1P));
       HIPCHK(h, dalloc(&h->d_rpb, (size_t)8 * XK_PIPE_NT_MAX * 256));
       HIPCHK(h, dalloc(&h->d_xsync, (size_t)2 * XP_WORDS * 16));
@@ -387,7 +390,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   if (h->d_fq) hipFree(h->d_fq);
   for (void *p4 : {(void *)h->d_rs, (void *)h->d_rpb, (void *)h->d_xsync})
     if (p4) hipFree(p4);
-  for (void *p3 : {(void *)h->d_x1, (void *)h->d_x2, (void *)h->d_x1p, (void *)h->d_pdbg})
+  for (void *p3 : {(void *)h->d_x1, (void *)h->d_pdbg})
     if (p3) hipFree(p3);
   if (h->d_ciws) hipFree(h->d_ciws);
   if (h->d_batch) hipFree(h->d_batch);
@@ -895,10 +898,19 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       XkCaqrPipeArgs pa;
       pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = ntiles;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
-      pa.X1 = h->d_x1; pa.X1P = h->d_x1p; pa.X2 = h->d_x2; pa.status = h->d_status;
+      pa.status = h->d_status;
       if (h->xsync_dirty) {
         if (hipMemsetAsync(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
+        // (a launch that gave up leaves its slabs half written and the other set half re-armed: arm both)
+        if (hipMemsetD32Async((hipDeviceptr_t)h->d_x1, (int)(XK_NOTYET_BITS & 0xffffffffu), 2 * 2 * h->xslab_doubles, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "slabs");
         h->xsync_dirty = false; h->xsync_phase = 0;
+      }
+      {
+        const size_t np_ = (size_t)(h->C1 + 15) / 16, strips_ = np_ * XK_PIPE_RLS, x1n = strips_ * 16 * h->C1P;
+        double *set = h->d_x1 + (size_t)h->xsync_phase * h->xslab_doubles;
+        pa.X1 = set; pa.X2 = set + x1n; pa.X1P = set + 2 * x1n;
+        pa.Xnext = h->d_x1 + (size_t)(h->xsync_phase ^ 1) * h->xslab_doubles;
+        pa.xnext_doubles = (long)h->xslab_doubles;
       }
       pa.sync = h->d_xsync + (size_t)h->xsync_phase * XP_WORDS * 16;
       pa.sync_next = h->d_xsync + (size_t)(h->xsync_phase ^ 1) * XP_WORDS * 16;

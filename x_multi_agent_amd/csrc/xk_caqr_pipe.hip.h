@@ -65,14 +65,15 @@ struct XkPipeGeom {
 #endif
 using XkPipeNarrow = XkPipeGeom<XK_PIPE_NARROW>;           // C1 <= 192 (MSCKF-only windows up to 31 poses): 184 tiles of 128 rows
 #ifndef XK_PIPE_NARROW2
-#define XK_PIPE_NARROW2 4, 32, 19, 12, 1, 1, 32, 28, 2, 2
+#define XK_PIPE_NARROW2 4, 32, 19, 12, 1, 1, 32, 28, 2, 4
 #endif
 using XkPipeNarrow2 = XkPipeGeom<XK_PIPE_NARROW2>;         // the same columns, 152 tiles of 128 rows, TWO first-level groups per XCD (10 + 9 strips on
                                                            // 6 workgroups each): taken when the rows that pass the gates are expected to fit 19 456
 #ifndef XK_PIPE_WIDE
-#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28, 1, 2
+#define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28, 1, 4
 #endif
 using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
+#define XK_PIPE_RLS 16              // strips per panel of the cross-XCD slabs X1 / X1P / X2, whatever the geometry uses of them
 #define XK_PIPE_NT_MAX 23
 #define XK_PIPE_ROWS_MAX 24320
 #define XK_PIPE_SLOTS_MAX 1536      // 64-row slots (tracks + packed SLAM rows) a launch can compact
@@ -153,6 +154,8 @@ struct XkCaqrPipeArgs {
   double *PB;             // [8 NT][16 x 16]  their panel blocks
   double *X1, *X1P;       // [panels][8][16 x C1P] / [panels][8][16 x 16]: the root of XCD x (write-through)
   double *X2;             // [panels][8][16 x C1P]: what the last level sends down to XCD s (write-through)
+  double *Xnext;          // the OTHER set of X1 | X2 | X1P slabs (contiguous, xnext_doubles): re-armed with the NOT-YET pattern for the
+  long xnext_doubles;     // next launch by the workgroups that idle at the start (data-polled hand-offs, xk_xcd_sync.hip.h)
   unsigned *sync, *sync_next;
   int *status;
   long long *dbg;
@@ -674,17 +677,27 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
     const bool full = nsteps == 16;
     const unsigned epoch = (unsigned)(k + 1);
-    const size_t slab = ((size_t)k * 8 + xcc) * NG + grp;
+    const size_t slab = (size_t)k * XK_PIPE_RLS + xcc * NG + grp;
     double b[RM], b2[NCM > 1 ? RM : 2];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
     int ncl_prev, lchalf_prev, lsplit_prev;                 // last-level workgroups of panel k - 1
     xk_pipe_lastcut(a.C1 - c0, NCL, ncl_prev, lchalf_prev, lsplit_prev);
     lsplit_prev = min(XK_PIPE_NLW, lsplit_prev);
-    const size_t pslab = ((size_t)(k - 1) * 8 + xcc) * NG + grp;
+    const size_t pslab = (size_t)(k - 1) * XK_PIPE_RLS + xcc * NG + grp;
     if (k >= 1 && has_pending) {
+#if XK_DATA_POLL
+      // the slots say themselves when the last level has written them (xk_xcd_sync.hip.h): no counter, no barrier in front of the load
+      double pb1[1] = {0.0};
+      if (!xk_poll_slots<1>(pb1, a.X2 + pslab * SS + xk_blk(min(col, a.C1P - 1), part), 0, mine, ab, 4u)) *s_ok = 0u;
+      __syncthreads();
+      if (*s_ok == 0u) return false;                         // (s_ok: 1 on entry, only ever cleared -- uniform verdict, no second barrier)
+      if (mine) b[0] = pb1[0];
+      if (a.dbg && tid == 0) a.dbg[4096 + ((xcc * NG + grp) * NM + item) * 32 + k] = wall_clock64();
+#else
       if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
       if (mine) b[0] = xk_ld_sc1(a.X2 + pslab * SS + xk_blk(col, part));
+#endif
     }
 #pragma unroll
     for (int s = 1; s < RM; ++s) b[s] = 0.0;
@@ -784,9 +797,9 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       // (the first barrier of the range, behind the loads above, is where the root's rows of the previous phase are counted in)
       auto hook = [&]() { xk_pipe_arrive(sync + (XP_X1_CNT + (q - 1) * XK_CAQR_MAXP + k) * 16); };
       if constexpr (NCM > 1)
-        xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full, hook);
+        xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) : -1), RM>(b, &b2, cidx, mine, mine2, part, nsteps, ubuf, sc, full && !XK_DATA_POLL, hook);
       else
-        xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full, hook);
+        xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) : -1), RM>(b, nullptr, cidx, mine, false, part, nsteps, ubuf, sc, full && !XK_DATA_POLL, hook);
       if (panel) __builtin_amdgcn_s_setprio(0);
       // rows [q GS, (q + 1) GS) of the root are final: out they go (write-through: the last level sits on other XCDs)
       if (q < NPH - 1 && x1_mine && part >= xk_pbn<NPH>(q) && part < xk_pbn<NPH>(q + 1)) xk_st_sc1(x1, (panel && part > cidx) ? 0.0 : b[0]);
@@ -794,6 +807,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
         if (q < NPH - 1 && mine2 && part >= xk_pbn<NPH>(q) && part < xk_pbn<NPH>(q + 1)) xk_st_sc1(x12, b2[0]);
       }
       if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
+      if (a.dbg && tid == 0 && q == 0) a.dbg[4096 + ((xcc * NG + grp) * NM + item) * 32 + 16 + k] = wall_clock64();
     };
     phase(std::integral_constant<int, 0>{});
     if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
@@ -826,7 +840,8 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     __syncthreads();
     if (tid == 0) {
       xk_pipe_arrive(sync + (XP_MB_CNT + xcc) * 16);
-      for (int q = (full && active) ? NPH - 1 : 0; q < NPH; ++q) xk_pipe_arrive(sync + (XP_X1_CNT + q * XK_CAQR_MAXP + k) * 16);
+      if (!XK_DATA_POLL)
+        for (int q = (full && active) ? NPH - 1 : 0; q < NPH; ++q) xk_pipe_arrive(sync + (XP_X1_CNT + q * XK_CAQR_MAXP + k) * 16);
     }
     if (stamp) a.dbg[512 + 16 * k + 8] = wall_clock64();
   }
@@ -864,8 +879,8 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     const bool mine = col < a.C1 && (panel || cidx - 16 < lchalf);
     const bool mine2 = ncl > 1 && !panel && cidx - 16 < lchalf && col2 < a.C1;
     const int nsteps = (a.C1 - c0 < 16) ? a.C1 - c0 : 16;
-    const double *src = panel ? a.X1P + (size_t)k * RL * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * RL * SS + xk_blk(col, part);
-    const double *src2 = a.X1 + (size_t)k * RL * SS + xk_blk(min(col2, a.C1P - 1), part);
+    const double *src = panel ? a.X1P + (size_t)k * XK_PIPE_RLS * 256 + xk_blk(cidx, part) : a.X1 + (size_t)k * XK_PIPE_RLS * SS + xk_blk(col, part);
+    const double *src2 = a.X1 + (size_t)k * XK_PIPE_RLS * SS + xk_blk(min(col2, a.C1P - 1), part);
     const size_t sstep = panel ? 256 : SS;
     double b[RL], b2[RL];
 #pragma unroll
@@ -875,6 +890,20 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
       if (!ok || nsteps <= xk_pbn<NPH>(q)) return;                 // (a short last panel: the roots' rows past its columns are zero)
+#if XK_DATA_POLL
+      {
+        // rows [pb(q), pb(q + 1)) of the roots: the lanes that hold them load their slots until every one has been written
+        const bool rows_q = part >= xk_pbn<NPH>(q) && part < xk_pbn<NPH>(q + 1);
+        bool got = xk_poll_slots<RL>(b, src, sstep, rows_q && mine, ab, 5u);
+        if (got && ncl > 1) got = xk_poll_slots<RL>(b2, src2, SS, rows_q && mine2, ab, 5u);
+        if (!got) *s_ok = 0u;
+        __syncthreads();
+        if (*s_ok == 0u) { ok = false; return; }
+        if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
+        if (a.dbg && tid == 0 && q < 2) a.dbg[8192 + lidx * 64 + 16 * q + k] = wall_clock64();
+        (void)loaded;
+      }
+#else
       if (loaded <= q) {
         const int av = xk_pipe_wait_phases(sync + (XP_X1_CNT + k) * 16, XK_CAQR_MAXP * 16, q, NPH, 8u * NM, ab, 5u, s_ok);
         if (av == 0) { ok = false; return; }
@@ -891,6 +920,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         }
         loaded = av;
       }
+#endif
       if (panel) __builtin_amdgcn_s_setprio(3);
       xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
@@ -908,7 +938,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         if (lidx == 0 && c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col, (part > cidx) ? 0.0 : b[0]);
       } else {
         if (k + 1 < npanels) {
-          double *dst = a.X2 + (size_t)k * RL * SS + xk_blk(col, part);
+          double *dst = a.X2 + (size_t)k * XK_PIPE_RLS * SS + xk_blk(col, part);
 #pragma unroll
           for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b[s]);
         }
@@ -917,7 +947,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     }
     if (mine2) {
       if (k + 1 < npanels) {
-        double *dst = a.X2 + (size_t)k * RL * SS + xk_blk(col2, part);
+        double *dst = a.X2 + (size_t)k * XK_PIPE_RLS * SS + xk_blk(col2, part);
 #pragma unroll
         for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b2[s]);
       }
@@ -926,10 +956,11 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      if (k + 1 < npanels) xk_pipe_arrive(sync + (XP_P_CNT + k) * 16);
+      if (!XK_DATA_POLL && k + 1 < npanels) xk_pipe_arrive(sync + (XP_P_CNT + k) * 16);
       if (a.kal) xk_pipe_arrive(sync + (XP_R_CNT + k) * 16);
     }
     if (stamp) a.dbg[1024 + 16 * k + 8] = wall_clock64();
+    if (a.dbg && tid == 0) a.dbg[8192 + lidx * 64 + 32 + k] = wall_clock64();
   }
   if (stamp) a.dbg[1539] = wall_clock64();
   return true;
@@ -1349,6 +1380,24 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
   __syncthreads();
   if (a.test_stall && xcc == 3 && slot == 5) return;
+#if XK_DATA_POLL
+  if (slot >= NT && a.Xnext) {
+    // The workgroups that have nothing to do until the tiles publish their first rows re-arm the OTHER set of cross-XCD slabs
+    // for the next launch: X1 | X2 ([panel][16 strips][16 x C1P]: panel k is only ever read at columns >= 16 k, i.e. from offset
+    // 256 k of a strip on) then X1P ([panel][16][256]).  Plain stores: the kernel boundary publishes them.
+    const long SSl = 16L * a.C1P, per_panel = (long)XK_PIPE_RLS * SSl, npl = (a.C1 + 15) / 16, x12 = 2 * npl * per_panel;
+    const long nw = 8L * (32 - NT) * XK_PIPE_THREADS, me = ((long)xcc * (32 - NT) + (slot - NT)) * XK_PIPE_THREADS + threadIdx.x;
+    const double ny = xk_notyet();
+    for (long i = me; i < a.xnext_doubles; i += nw) {
+      bool live = true;
+      if (i < x12) {
+        const long j = i < npl * per_panel ? i : i - npl * per_panel;
+        live = (j % SSl) >= 256 * (j / per_panel);
+      }
+      if (live) a.Xnext[i] = ny;
+    }
+  }
+#endif
   bool ok;
   if (slot < NT) {
     int rows_acc;

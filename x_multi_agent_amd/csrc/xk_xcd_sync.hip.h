@@ -94,6 +94,41 @@ __device__ __forceinline__ bool xk_spin_ge(unsigned *p, unsigned target, unsigne
   return false;
 }
 
+// DATA-POLLED hand-offs (round 5; relaxed build only).  The cross-XCD slabs (roots going up, pending strips coming down) are
+// per-panel and never reused inside a launch, so a slot can say by itself whether it has been written: every slot holds a
+// NOT-YET pattern -- a NaN payload no arithmetic produces -- until its producer stores the value (one write-through 8-byte store,
+// untorn on gfx950), and the consumer's lanes load their slots until none of them is that pattern.  No counter, no drain of the
+// producer's stores, no barriers around the poll: a hand-off costs a store's and a load's latency (~1.5 us) instead of 3.5-4.
+// The launch re-arms the OTHER set of slabs for its successor (xk_caqr_pipe entry), the host arms both at creation and after a
+// launch that gave up.  -DXK_SYNC_STRICT=1 keeps the counters and release / acquire pairs.
+#define XK_NOTYET_BITS 0x7FF8BEEF7FF8BEEFull           // (both halves equal: hipMemsetD32Async arms a slab)
+__device__ __forceinline__ bool xk_is_notyet(double v) { return __builtin_bit_cast(unsigned long long, v) == XK_NOTYET_BITS; }
+__device__ __forceinline__ double xk_notyet() { return __builtin_bit_cast(double, (unsigned long long)XK_NOTYET_BITS); }
+// One wave: the lanes with want = true load their R slots (stride `step` doubles) until every one of them has been written.
+// Returns false if the wave gave up (bound of the spin, or somebody else's abort word).
+template <int R>
+__device__ __forceinline__ bool xk_poll_slots(double (&b)[R], const double *src, size_t step, bool want, unsigned *abort_, unsigned reason) {
+  const long long t0 = wall_clock64();
+  for (unsigned it = 0;; ++it) {
+    bool ok = true;
+    if (want) {
+#pragma unroll
+      for (int s = 0; s < R; ++s) b[s] = xk_ld_sc1(src + (size_t)s * step);
+#pragma unroll
+      for (int s = 0; s < R; ++s) ok = ok && !xk_is_notyet(b[s]);
+    }
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) return true;
+    if ((it & 15u) == 15u) {
+      if (__hip_atomic_load(abort_, XK_RLX_AGENT)) return false;
+      if (wall_clock64() - t0 > XK_SPIN_TICKS) { __hip_atomic_store(abort_, reason, XK_RLX_AGENT); return false; }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+#ifndef XK_DATA_POLL
+#define XK_DATA_POLL (!XK_SYNC_STRICT)
+#endif
+
 // Hides a pointer from loop-invariant code motion: the per-row addresses of a strip are then formed where they are used (one
 // 64-bit add each) instead of being hoisted out of the panel loop, dozens of registers' worth, and spilled.
 template <typename T> __device__ __forceinline__ T *xk_opaque(T *p) {
