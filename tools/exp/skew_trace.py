@@ -27,4 +27,17 @@ for k in range(1, 11):
     print(f"panel {k:2d}: L(k-1) out {us(lop.min()-t0):6.2f}..{us(lop.max()-t0):6.2f} | M1 pending in {us(pin.min()-t0):6.2f}..{us(pin.max()-t0):6.2f} | "
           f"M1 ph0 out {us(pout.min()-t0):6.2f}..{us(pout.max()-t0):6.2f} | L ph0 in {us(l0.min()-t0):6.2f}..{us(l0.max()-t0):6.2f} | "
           f"L ph1 in {us(l1.min()-t0):6.2f}..{us(l1.max()-t0):6.2f} | L out {us(lo.min()-t0):6.2f}..{us(lo.max()-t0):6.2f}")
+TS = w[12288:12288 + 8 * 32].reshape(8, 32)
+print("per XCD, us after XCD 0's tile started the panel: tile start | group 0 / 1: pending in, phase-0 rows out (slowest item)")
+for k in (3, 6, 9):
+    t0 = TS[0, k]
+    row = []
+    for x in range(8):
+        cells = []
+        for g in range(2):
+            wg = M1[(x * 2 + g) * 6:(x * 2 + g) * 6 + 6]
+            pin = wg[:, k][wg[:, k] > 0]; pout = wg[:, 16 + k][wg[:, 16 + k] > 0]
+            cells.append(f"{us(pin.max()-t0) if len(pin) else float('nan'):5.1f}/{us(pout.max()-t0) if len(pout) else float('nan'):5.1f}")
+        row.append(f"X{x} {us(TS[x,k]-t0):5.1f} | " + " ".join(cells))
+    print(f"panel {k}: " + "  ||  ".join(row))
 eng.close()
