@@ -578,6 +578,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     const bool pub = mine && part == 0 && rel >= 0;
     const unsigned epoch = (unsigned)(k + 1);
     if (stamp) { a.dbg[16 * k + 0] = wall_clock64(); a.dbg[16 * k + 8] = clock64(); }
+    if (a.dbg && slot == 0 && tid == 0) a.dbg[12288 + xcc * 32 + k] = wall_clock64();       // (skew_trace: every XCD's panel start)
     if (hot) __builtin_amdgcn_s_setprio(3);
     // phase q: steps [q GS, (q + 1) GS), then rows [q GS, (q + 1) GS) of the pivot strip are final and go out; they are counted in
     // ARRD steps into the next phase (their stores drain behind those steps), the last phase after the panel
