@@ -231,6 +231,11 @@ def cpu_baseline(sc, budget_s=20.0):
                            "note": "independent agents, one process per core, 3 updates each, slowest worker's time"}
     except Exception as e:
         out["all_core"] = {"error": str(e)[:200]}
+    # footnote: the true-Eigen variant of a9 / a11 / a12, if this box has Eigen3 ("absent" on this image)
+    try:
+        out["eigen_variant"] = c_oracle.eigen_variant(sc)
+    except Exception as e:
+        out["eigen_variant"] = {"error": str(e)[:200]}
     out["_ref"] = ref          # the oracle's posterior on these inputs: main() turns it into the line's `parity` block
     return out
 

@@ -354,3 +354,58 @@ def msckf_ci_track(trk, C_q_G, G_p_C, P, n_poses_max, sigma_img, matches, ci_msc
     if hc.value:
         out["ci"] = dict(S=np.ascontiguousarray(S), P_j=np.ascontiguousarray(Pj), H=np.ascontiguousarray(H), res=res)
     return out
+
+
+def track_jacobians(sc, k, gpf):
+    """jac (2L x n), hf (2L x 3), res (2L) of track k BEFORE the null-space projection (msckf_update.cpp:328-417), nan flag."""
+    off = sc["trk_off"]
+    L = int(off[k + 1] - off[k])
+    n = sc["P"].shape[0]
+    ob, obp = _d(sc["obs_xy"][off[k]:off[k + 1]])
+    q, qp = _d(sc["C_q_G"])
+    p, pp = _d(sc["G_p_C"])
+    g, gp = _d(gpf)
+    jac = np.zeros((2 * L, n), order="F")
+    hf = np.zeros((2 * L, 3), order="F")
+    res = np.zeros(2 * L)
+    bad = C.c_int()
+    _chk(lib().xo_track_jacobians(obp, C.c_int(L), C.c_int(n), qp, pp, C.c_int(len(sc["G_p_C"])), C.c_int(sc["n_poses_max"]), gp,
+                                  jac.ctypes.data_as(c_dp), hf.ctypes.data_as(c_dp), res.ctypes.data_as(c_dp), C.byref(bad)),
+         "xo_track_jacobians")
+    return jac, hf, res, bool(bad.value)
+
+
+def eigen_variant(sc, reps=3, workdir="/tmp"):
+    """the true-Eigen variant of a9 / a11 / a12 (oracle/eigen_variant.cpp) on this scenario (MSCKF tracks only),
+    when the box has Eigen3; {"eigen": "absent"} otherwise.  Returns the program's JSON as a dict."""
+    import json
+    import subprocess
+    src = os.path.join(_HERE, "eigen_variant.cpp")
+    exe = os.path.join(workdir, "xk_eigen_variant")
+    inc = [a for d in ("/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/eigen3") if os.path.isdir(d) for a in ("-I", d)]
+    r = subprocess.run(["g++", "-std=c++17", "-O3", "-march=native", "-DNDEBUG"] + inc + ["-o", exe, src], capture_output=True, text=True)
+    if r.returncode != 0:
+        return {"eigen": "present, did not build", "error": r.stderr[-400:]}
+    probe = subprocess.run([exe], capture_output=True, text=True)
+    if '"absent"' in probe.stdout:
+        return json.loads(probe.stdout.strip().splitlines()[-1])
+    if "slam_anchor_idxs" in sc and len(sc["slam_anchor_idxs"]):
+        return {"eigen": "present", "error": "the variant covers MSCKF tracks only"}
+    _, _, _, info = msckf_update(sc)
+    ref = visual_update(sc)
+    n = sc["P"].shape[0]
+    K = len(sc["trk_off"]) - 1
+    parts = [np.array([n, K, sc["sigma_img"] ** 2, reps], float), np.asfortranarray(sc["P"]).ravel(order="F")]
+    for k in range(K):
+        jac, hf, res, bad = track_jacobians(sc, k, info["feats"][k])
+        L = len(res) // 2
+        parts += [np.array([L, chi2inv(0.95, 2 * L - 3), float(bad)]), jac.ravel(order="F"), hf.ravel(order="F"), res]
+    parts += [np.asfortranarray(ref["P"]).ravel(order="F"), ref["correction"]]
+    dump = os.path.join(workdir, "xk_eigen_dump.bin")
+    np.concatenate(parts).astype("<f8").tofile(dump)
+    r = subprocess.run([exe, dump, str(reps)], capture_output=True, text=True, timeout=600)
+    os.remove(dump)
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return {"eigen": "present", "error": (r.stdout + r.stderr)[-300:]}

@@ -529,27 +529,20 @@ typedef struct {
 
 static void track_out_free(track_out_t *t) { free(t->jac0); free(t->res0); free(t->up_jac); }
 
-static int process_one_track(const double *obs, int L, const double *P, int n, const double *C_q_G,
-                             const double *G_p_C, int n_poses, int n_poses_max, double var_img,
-                             const double gpf[3], int want_up, track_out_t *o) {
-  memset(o, 0, sizeof(*o));
-  int m = 2 * L, d = m - 3;
-  double *jac = calloc((size_t)m * n, sizeof(double));
-  double *hf = calloc((size_t)m * 3, sizeof(double));
-  double *res = calloc((size_t)m, sizeof(double));
-  double *Q = malloc(sizeof(double) * (size_t)m * m);
-  if (!jac || !hf || !res || !Q) { free(jac); free(hf); free(res); free(Q); return XO_ENOMEM; }
+/* msckf_update.cpp:328-417: per observation the residual, the 2 x 3 position / attitude Jacobians with the observability
+ * constraint, scattered into jac (m x n, ld m), hf (m x 3), res (m), m = 2 L.  Returns 1 if a camera-frame point is NaN
+ * (the reference drops such a track, :349-357), 0 otherwise.  jac / hf / res must be zero on entry. */
+static int track_jacobians(const double *obs, int L, int n, const double *C_q_G, const double *G_p_C, int n_poses,
+                           int n_poses_max, const double gpf[3], double *jac, double *hf, double *res) {
+  (void)n;
+  const int m = 2 * L;
   for (int i = 0; i < L; ++i) { /* :328-417 */
     int pos = n_poses - L + i;
     double R[3][3], c[3], dlt[3];
     quat_to_rot(C_q_G + 4 * pos, R);
     for (int a = 0; a < 3; ++a) dlt[a] = gpf[a] - G_p_C[3 * pos + a];
     for (int a = 0; a < 3; ++a) c[a] = R[0][a] * dlt[0] + R[1][a] * dlt[1] + R[2][a] * dlt[2];
-    if (!(c[0] == c[0] && c[1] == c[1] && c[2] == c[2])) { /* :349-357 */
-      free(jac); free(hf); free(res); free(Q);
-      o->valid = 0; o->gamma = NAN;
-      return XO_OK;
-    }
+    if (!(c[0] == c[0] && c[1] == c[1] && c[2] == c[2])) return 1; /* :349-357 */
     res[2 * i] = obs[2 * i] - c[0] / c[2];
     res[2 * i + 1] = obs[2 * i + 1] - c[1] / c[2];
     double Ji[2][3] = {{1.0 / c[2], 0.0, -c[0] / (c[2] * c[2])}, {0.0, 1.0 / c[2], -c[1] / (c[2] * c[2])}};
@@ -583,6 +576,38 @@ static int process_one_track(const double *obs, int L, const double *P, int n, c
         jac[(2 * i + a) + (size_t)(cp + b) * m] = Jp[a][b];
         jac[(2 * i + a) + (size_t)(ca + b) * m] = Ja[a][b];
       }
+  }
+  return 0;
+}
+
+/* The same for a caller outside this file (oracle/eigen_variant.cpp is handed these matrices: the per-track inputs of the
+ * linear algebra the reference does with Eigen, msckf_update.cpp:423-463).  gpf = the track's triangulated landmark
+ * (xo_msckf_update's `feats`).  Column-major jac (2L x n), hf (2L x 3), res (2L); *nan_track = 1 if the track is dropped. */
+int xo_track_jacobians(const double *obs, int L, int n, const double *C_q_G, const double *G_p_C, int n_poses,
+                       int n_poses_max, const double *gpf, double *jac, double *hf, double *res, int *nan_track) {
+  if (!obs || L < 2 || !jac || !hf || !res) return XO_EINVAL;
+  memset(jac, 0, sizeof(double) * (size_t)2 * L * n);
+  memset(hf, 0, sizeof(double) * (size_t)2 * L * 3);
+  memset(res, 0, sizeof(double) * (size_t)2 * L);
+  const int bad = track_jacobians(obs, L, n, C_q_G, G_p_C, n_poses, n_poses_max, gpf, jac, hf, res);
+  if (nan_track) *nan_track = bad;
+  return XO_OK;
+}
+
+static int process_one_track(const double *obs, int L, const double *P, int n, const double *C_q_G,
+                             const double *G_p_C, int n_poses, int n_poses_max, double var_img,
+                             const double gpf[3], int want_up, track_out_t *o) {
+  memset(o, 0, sizeof(*o));
+  int m = 2 * L, d = m - 3;
+  double *jac = calloc((size_t)m * n, sizeof(double));
+  double *hf = calloc((size_t)m * 3, sizeof(double));
+  double *res = calloc((size_t)m, sizeof(double));
+  double *Q = malloc(sizeof(double) * (size_t)m * m);
+  if (!jac || !hf || !res || !Q) { free(jac); free(hf); free(res); free(Q); return XO_ENOMEM; }
+  if (track_jacobians(obs, L, n, C_q_G, G_p_C, n_poses, n_poses_max, gpf, jac, hf, res)) { /* :349-357 */
+    free(jac); free(hf); free(res); free(Q);
+    o->valid = 0; o->gamma = NAN;
+    return XO_OK;
   }
   /* nullspace :423-432 */
   double hfqr[3 * 512], tau[3];
