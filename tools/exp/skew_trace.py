@@ -11,7 +11,7 @@ N, K, M = synth.CONFIGS[4]
 eng = engine.LabEngine(N, M, K)
 eng.stage(sc)
 t = eng.bench_staged(sc["sigma_img"], 3, 10)
-NW = 16000
+NW = 65536
 out = (C.c_longlong * NW)()
 eng.L.xk_debug_persist_stamps(eng.h, out, C.c_int(NW))
 w = np.array(list(out), dtype=np.int64)
@@ -27,6 +27,17 @@ for k in range(1, 11):
     print(f"panel {k:2d}: L(k-1) out {us(lop.min()-t0):6.2f}..{us(lop.max()-t0):6.2f} | M1 pending in {us(pin.min()-t0):6.2f}..{us(pin.max()-t0):6.2f} | "
           f"M1 ph0 out {us(pout.min()-t0):6.2f}..{us(pout.max()-t0):6.2f} | L ph0 in {us(l0.min()-t0):6.2f}..{us(l0.max()-t0):6.2f} | "
           f"L ph1 in {us(l1.min()-t0):6.2f}..{us(l1.max()-t0):6.2f} | L out {us(lo.min()-t0):6.2f}..{us(lo.max()-t0):6.2f}")
+MP = w[16640:16640 + 96 * 16 * 4].reshape(96, 16, 4)          # [first-level wg][panel][phase] root rows of the phase out
+LP = w[32768:32768 + 7 * 16 * 4 * 2].reshape(7, 16, 4, 2)      # [last-level wg][panel][phase][in, done]
+print("per phase: first level out (earliest .. latest workgroup) -> last level in (earliest .. latest) / done, us after XCD 0's tile started the panel")
+for k in (3, 6, 9):
+    t0 = T[k, 0]
+    cells = []
+    for q in range(4):
+        m = MP[:, k, q]; m = m[m > 0]
+        li = LP[:, k, q, 0]; li = li[li > 0]; ld = LP[:, k, q, 1]; ld = ld[ld > 0]
+        cells.append(f"q{q}: M1 {us(m.min()-t0):5.1f}..{us(m.max()-t0):5.1f} -> L in {us(li.min()-t0):5.1f}..{us(li.max()-t0):5.1f} done {us(ld.max()-t0):5.1f}")
+    print(f"panel {k}: " + " | ".join(cells))
 TS = w[12288:12288 + 8 * 32].reshape(8, 32)
 print("per XCD, us after XCD 0's tile started the panel: tile start | group 0 / 1: pending in, phase-0 rows out (slowest item)")
 for k in (3, 6, 9):

@@ -24,6 +24,7 @@
 
 #define XK_VERSION_NUM 200
 #define XK_STAGE_SLOTS 8
+#define XK_PDBG_WORDS 65536     // debug stamps of the single launch (lab build)
 
 struct xk_handle {
   int device;
@@ -309,8 +310,8 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       HIPCHK(h, hipMemset(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16));
       h->xsync_phase = 0;
 #ifdef XK_LAB
-      HIPCHK(h, dalloc(&h->d_pdbg, (size_t)256 + 64 * 256));
-      HIPCHK(h, hipMemset(h->d_pdbg, 0, sizeof(long long) * (256 + 64 * 256)));
+      HIPCHK(h, dalloc(&h->d_pdbg, (size_t)XK_PDBG_WORDS));
+      HIPCHK(h, hipMemset(h->d_pdbg, 0, sizeof(long long) * XK_PDBG_WORDS));
 #endif
     }
   }
@@ -2450,7 +2451,7 @@ extern "C" int xk_debug_persist_stamps(xk_handle *h, long long *out, int n_out) 
   if (!h || !out || !h->d_pdbg) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  HIPCHK(h, hipMemcpy(out, h->d_pdbg, sizeof(long long) * (size_t)std::min(n_out, 256 + 64 * 256), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(out, h->d_pdbg, sizeof(long long) * (size_t)std::min(n_out, XK_PDBG_WORDS), hipMemcpyDeviceToHost));
   return XK_OK;
 }
 #endif   // XK_LAB

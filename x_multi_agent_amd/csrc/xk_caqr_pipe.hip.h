@@ -809,6 +809,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
       }
       if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q + 1] = wall_clock64();
       if (a.dbg && tid == 0 && q == 0) a.dbg[4096 + ((xcc * NG + grp) * NM + item) * 32 + 16 + k] = wall_clock64();
+      if (a.dbg && tid == 0 && q < 4) a.dbg[16640 + (((xcc * NG + grp) * NM + item) * 16 + k) * 4 + q] = wall_clock64();   // (skew_trace: every phase)
     };
     phase(std::integral_constant<int, 0>{});
     if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
@@ -902,6 +903,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
         if (*s_ok == 0u) { ok = false; return; }
         if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q] = wall_clock64();
         if (a.dbg && tid == 0 && q < 2) a.dbg[8192 + lidx * 64 + 16 * q + k] = wall_clock64();
+        if (a.dbg && tid == 0 && q < 4) a.dbg[32768 + ((lidx * 16 + k) * 4 + q) * 2] = wall_clock64();                       // roots of phase q in
         (void)loaded;
       }
 #else
@@ -926,6 +928,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
       xk_pipe_range<0, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), -1, RL>(b, ncl > 1 ? &b2 : nullptr, panel ? cidx : 16, mine, mine2, part, nsteps, ubuf, sc, false, []() {});
       if (panel) __builtin_amdgcn_s_setprio(0);
       if (stamp && q < 4) a.dbg[1024 + 16 * k + 2 * q + 1] = wall_clock64();
+      if (a.dbg && tid == 0 && q < 4) a.dbg[32768 + ((lidx * 16 + k) * 4 + q) * 2 + 1] = wall_clock64();                     // phase q done
     };
     phase(std::integral_constant<int, 0>{});
     if constexpr (NPH >= 2) phase(std::integral_constant<int, 1>{});
