@@ -13,6 +13,8 @@ best = None
 for rep in range(3):
     eng = engine.Engine(N, M, K, lib_path=lib)
     eng.set_option("pipe_split", mode)
+    if os.environ.get("XK_AB_HLITE") is not None:
+        eng.set_option("caqr_hlite", int(os.environ["XK_AB_HLITE"]))    # 0: tiles in HBM (as before round 5), 1: factor records
     eng.stage(sc)
     eng.run_steps(sc["sigma_img"], 50)
     t0 = time.perf_counter()

@@ -41,6 +41,9 @@ if mode == "pipe":
     for k in range(npan):
         print(f"{k:3d}  " + "  ".join(f"{us(L[k,i]-T[k,0]):6.2f}" for i in range(9) if L[k, i] > 0))
     print(f"start-up: entry -> rows gathered {us(w[1537]-w[1536]):.2f} us; tile workgroup leaves {us(w[1538]-w[1536]):.2f} us after its entry, last level {us(w[1539]-w[1536]):.2f} us")
+    if w[1544] > 0:
+        print("gather from factor records, us after entry: start %.2f, slot range %.2f, records staged %.2f, blocks done %s" % (
+            us(w[1544]-w[1536]), us(w[1545]-w[1536]), us(w[1546]-w[1536]), " ".join("%.2f" % us(x-w[1536]) for x in w[1547:1552] if x > 0)))
     np.save("/tmp/pipe_P.npy", got["P"]); np.save("/tmp/pipe_c.npy", got["correction"])
     eng.close()
     for m in ("multi",):

@@ -45,6 +45,10 @@ struct xk_handle {
   double *d_fq;           // f_d, q_d of xk_cov_propagate
   double *d_chi95, *d_chi90;
   double *d_A;
+  double *d_Hc;            // factor records of the MSCKF tracks (xk_feature.hip.h: XkFeatArgs::Hc), hc_stride doubles each, 64-row slots only
+  int hc_stride;
+  int opt_hlite;           // 1 (default): the per-feature kernel leaves factor records when the single launch is expected to run
+  bool rows_compact;       // the last build left records, not tiles, for slots [0, K)
   int *d_tile_rows;
   double *d_panel[2];   // CAQR: 16 x 16 panel blocks of the even (tiles, level 2, ..) / odd merge levels
   int *d_inl, *d_inl_s, *d_gn;
@@ -250,6 +254,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, hipMemcpy(h->d_chi95, XK_CHI2_095, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
+  h->hc_stride = XK_HC_VR + XK_HC_WC * h->C1P;
+  h->opt_hlite = env_int("XK_HLITE", 1);
+  h->rows_compact = false;
+  if (h->DB == 64) HIPCHK(h, dalloc(&h->d_Hc, (size_t)std::max(k_max, 1) * h->hc_stride));
   HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
   for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max + 10) * 256));
   HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
@@ -386,6 +394,7 @@ extern "C" int xk_destroy(xk_handle *h) {
     if (p2) hipFree(p2);
   free(h->h_trk2_off);
   if (h->d_csr_v) hipFree(h->d_csr_v);
+  if (h->d_Hc) hipFree(h->d_Hc);
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_Psnap2) hipFree(h->d_Psnap2);
   if (h->d_fq) hipFree(h->d_fq);
@@ -748,6 +757,12 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.trk_off = h->d_trk_off; a.obs = h->d_obs; a.K = h->K;
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
+    // factor records instead of tiles when the single launch (which forms its entries from them) is armed: H0 never visits HBM.
+    // Should the compression take the multi-launch schedule after all, xk_expand_records writes the tiles first (launch_compress).
+    // (narrow systems only: next to the wide geometry's 80-row tiles and 2 lanes per column forming the entries costs more than
+    //  the tiles' trip through HBM -- config 2: 1546 -> 1521 updates/s)
+    h->rows_compact = h->opt_hlite && h->d_Hc && h->opt_resident && h->persist_ok && !h->feat_dbg && h->C1 <= XkPipeNarrow::COLS;
+    a.Hc = h->rows_compact ? h->d_Hc : nullptr; a.hs = h->hc_stride;
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
     a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
     a.inlier_h = h->h_flag_i; a.gamma_h = h->h_flag_d;     // gate results also straight into the pinned flag cache
@@ -898,6 +913,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     if (R_nom >= 64 * 8 && ntiles <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
       XkCaqrPipeArgs pa;
       pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = ntiles;
+      pa.Hc = h->d_Hc; pa.hs = h->hc_stride; pa.nhc = h->rows_compact ? h->K : 0;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
       pa.status = h->d_status;
       if (h->xsync_dirty) {
@@ -945,6 +961,11 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
       return XK_OK;
     }
+  }
+  if (h->rows_compact && h->K > 0) {   // the multi-launch schedule works on tiles: multiply the records out
+    XkExpandArgs ea{h->d_Hc, h->hc_stride, h->d_A, h->DB, h->C1P, h->d_tile_rows};
+    hipLaunchKernelGGL(xk_expand_records, dim3(h->K), dim3(256), 0, h->stream, ea);
+    h->rows_compact = false;
   }
   // 128-row slots whose tallest tile has <= 104 rows: 26 rows per lane (two workgroups per CU), see xk_caqr_tile
   const int tall26_env = h->opt_tall26;
@@ -1899,6 +1920,7 @@ extern "C" int xk_msckf_ci_track(xk_handle *h, const double *obs, int L, const d
     const int toff[2] = {0, L_i};
     HIPCHK(h, hipMemcpyAsync(dint + 8, toff, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
     XkFeatArgs a;
+    memset(&a, 0, sizeof(a));
     a.q = aq; a.p = ap; a.n_poses = np_i; a.n_poses_max = npm_i; a.trk_off = dint + 8; a.obs = aobs; a.K = 1;
     a.P = aP; a.n = n_i; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = nullptr; a.DB = 0; a.C1P = 0; a.na = n_i - XK_CORE;
@@ -2428,6 +2450,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
   else if (!strcmp(name, "caqr_tall26")) h->opt_tall26 = value;
   else if (!strcmp(name, "pipe_kalman")) h->opt_kalman = value;
   else if (!strcmp(name, "pipe_split")) { if (h->opt_split >= 0) h->opt_split = value; }
+  else if (!strcmp(name, "caqr_hlite")) h->opt_hlite = value;
 #endif
   else return fail(h, XK_EINVAL, "xk_set_option: unknown option");
   return XK_OK;

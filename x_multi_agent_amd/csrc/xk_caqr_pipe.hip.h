@@ -146,6 +146,8 @@ enum {
 
 struct XkCaqrPipeArgs {
   const double *A;        // tiles [ntiles][64][C1P] row-major as the per-feature kernels wrote them (read once)
+  const double *Hc;       // factor records of slots [0, nhc) instead of their tiles (xk_feature.hip.h: XkFeatArgs::Hc), hs doubles each;
+  int hs, nhc;            // nhc = 0: every slot is a tile in A
   const int *tile_rows;   // valid rows per 64-row slot (0 = rejected track), [nslots]: the stack is COMPACTED on the device --
   int nslots;             // fat tile j takes rows [j TR, (j + 1) TR) of the rows that passed the gates, TR = ceil(rows / tiles)
   int C1P, C1;
@@ -532,7 +534,7 @@ __device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, i
 
 template <class G, int RPL>
 __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, long long t_entry, double *ubuf, double *sc, unsigned *s_ok,
-                                          const int *myrows) {
+                                          const int *myrows, double *hbuf, int hcap_doubles, int nvalid) {
   constexpr int NT = G::NT, LPC = G::LPC, NPH = G::NPH, GS = 16 / NPH, ARRD = XK_PIPE_ARRD;
   static_assert(ARRD < xk_pbn<NPH>(1) && ARRD < 16 - xk_pbn<NPH>(NPH - 1), "a phase is counted in before the next one is published");
   const XkCaqrPipeArgs a = xk_pipe_args(ap);
@@ -544,6 +546,100 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
   const int npanels = (a.C1 + 15) / 16;
   const bool stamp = a.dbg && xcc == 0 && slot == 1 && tid == 0;
   double b[RPL];
+  if (a.nhc > 0) {
+    // My rows from the FACTOR RECORDS of their tracks (H0 itself never exists in HBM).  The records of the slots
+    // my rows come from -- a tile's rows are consecutive accepted rows, so consecutive slots, rejected ones in between -- are
+    // staged in LDS (as many as fit at a time: one chunk unless the tracks are very short).  The entries are formed in the layout
+    // that makes the track of a row WAVE-UNIFORM -- thread (fp, fc) = rows of lane-part fp, column fc: the row part {v0, v1, v2,
+    // r'} is one broadcast read, the column part {w0, w1, w2, x0, x1, r0} is re-read when the track changes, 3 multiply-adds
+    // (xk_h0_entry) -- eight registers' worth of rows at a time into an LDS block, from where the factorisation's lanes (column
+    // cabs, part part_) take theirs.  Rows of slots >= nhc (SLAM features, tracks that become features) are tiles in A.
+    constexpr int BR = 8, CG = XK_PIPE_THREADS / LPC;
+    const int hs = a.hs, C1P = a.C1P, ccl = min(cabs, C1P - 1);
+    double *Tb = hbuf, *recs = hbuf + LPC * BR * C1P;
+    const int hcap = (hcap_doubles - LPC * BR * C1P) / hs;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) b[r] = 0.0;
+    if (stamp) a.dbg[1544] = wall_clock64();
+    const int s_lo = myrows[0] >> 6, s_hi = nvalid > 0 ? myrows[nvalid - 1] >> 6 : -1;   // (an empty tile: nothing below runs)
+    const int fp = __builtin_amdgcn_readfirstlane(tid / CG), fc = tid % CG;
+    if (stamp) a.dbg[1545] = wall_clock64();
+    for (int lo = max(s_lo, 0); lo <= s_hi && lo < a.nhc; lo += hcap) {
+      const int hi = min(min(lo + hcap, s_hi + 1), a.nhc);
+      {
+        // (loads first, stores behind them: six 16-byte pieces per thread in flight -- one record is 700 of them)
+        const xk_d2 *src = reinterpret_cast<const xk_d2 *>(a.Hc + (size_t)lo * hs);
+        xk_d2 *dst = reinterpret_cast<xk_d2 *>(recs);
+        const int tot = (hi - lo) * (hs / 2);
+        for (int base = 0; base < tot; base += 6 * XK_PIPE_THREADS) {
+          xk_d2 t[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) t[i] = src[min(base + i * XK_PIPE_THREADS + tid, tot - 1)];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int e = base + i * XK_PIPE_THREADS + tid;
+            if (e < tot) dst[e] = t[i];
+          }
+        }
+      }
+      __syncthreads();
+      if (stamp) a.dbg[1546] = wall_clock64();
+      int kcur = -1, r0 = -2;
+      double w0 = 0.0, w1 = 0.0, w2 = 0.0, x0 = 0.0, x1 = 0.0;
+#pragma unroll
+      for (int rb = 0; rb < (RPL + BR - 1) / BR; ++rb) {
+        if (fc < C1P) {
+#pragma unroll
+          for (int j = 0; j < BR; ++j) {
+            if (rb * BR + j < RPL) {
+              const int ph = __builtin_amdgcn_readfirstlane(myrows[fp * RPL + rb * BR + j]), sl = ph >> 6;
+              if (ph >= 0 && sl >= lo && sl < hi) {        // (wave-uniform)
+                const double *rec = recs + (sl - lo) * hs;
+                if (sl != kcur) {
+                  const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * fc);
+                  const xk_d2 q0 = wc[0], q1 = wc[1], q2 = wc[2];
+                  w0 = q0[0]; w1 = q0[1]; w2 = q1[0]; x0 = q1[1]; x1 = q2[0]; r0 = (int)q2[1];
+                  kcur = sl;
+                }
+                const int rr = (ph & 63) + 3;
+                const xk_d2 va = reinterpret_cast<const xk_d2 *>(rec + 4 * rr)[0], vb = reinterpret_cast<const xk_d2 *>(rec + 4 * rr)[1];
+                Tb[(fp * BR + j) * C1P + fc] = xk_h0_entry(w0, w1, w2, x0, x1, r0, va[0], va[1], vb[0], vb[1], rr);
+              }
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+          if (rb * BR + j < RPL) {
+            const int ph = myrows[part_ * RPL + rb * BR + j], sl = ph >> 6;
+            const double v = Tb[(part_ * BR + j) * C1P + ccl];
+            if (ph >= 0 && sl >= lo && sl < hi) b[rb * BR + j] = mine ? v : 0.0;
+          }
+        }
+        __syncthreads();                                   // (the block is rewritten; after the last one: hbuf and ubuf have other users)
+        if (stamp) a.dbg[1547 + rb] = wall_clock64();
+      }
+    }
+    if (s_hi >= a.nhc) {                                   // (workgroup-uniform) rows that are tiles
+      const double *Ac = a.A + ccl;
+#pragma unroll
+      for (int h0 = 0; h0 < RPL; h0 += 16) {
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (h0 + r < RPL) x[r] = Ac[(size_t)max(myrows[part_ * RPL + h0 + r], 0) * C1P];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (h0 + r < RPL) {
+            const int ph = myrows[part_ * RPL + h0 + r];
+            if (mine && ph >= 0 && (ph >> 6) >= a.nhc) b[h0 + r] = x[r];
+          }
+        }
+      }
+    }
+  } else
   {   // The one pass over the stack: my rows, through the physical row numbers xk_pipe_rowplan left in LDS (-1: no row).  Branch-free
       // and in batches -- every index clamped into range, every load issued whether or not its value is used -- so that 16 loads are
       // in flight at a time: with a branch per row the compiler waited for each row's data before the next, 22 us of the launch.
@@ -1365,6 +1461,11 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __shared__ __attribute__((aligned(16))) double pfbuf[XK_PIPE_PF ? (XK_PIPE_THREADS / 64) * 24 * 16 : 2];
   constexpr bool KAL = G::COLS <= 192;                     // the Kalman role keeps [P | d] in registers: n <= 206
   __shared__ __attribute__((aligned(16))) double kbuf[KAL ? XK_KAL_LDS : 2];
+  // tile workgroups: landing area of the factor records their rows are formed from (the Kalman role's LDS where there is one)
+  constexpr int HB_OWN = KAL ? 2 : 16 * 1024;
+  __shared__ __attribute__((aligned(16))) double hbuf_own[HB_OWN];
+  double *hbuf = KAL ? kbuf : hbuf_own;
+  constexpr int HB = KAL ? XK_KAL_LDS : HB_OWN;
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const XkPipeArgsPtr ap = (XkPipeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const unsigned xcc = xk_xcc_id();
@@ -1408,12 +1509,13 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
     const int TR = xk_pipe_rowplan<G>(a, (int)xcc * NT + slot, rp_pre, rp_rows, &rows_acc);
     // how many rows passed the gates: the host picks the next launch's geometry by it (status word 2, pinned host memory)
     if (xcc == 0 && slot == 0 && threadIdx.x == 0) __hip_atomic_store(a.status + 2, rows_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int nvalid = min(max(rows_acc - ((int)xcc * NT + slot) * TR, 0), TR);   // rows of my tile that exist
     if (TR == 0) {                                         // more accepted rows than the tiles hold: everybody learns it from the abort word
       if (threadIdx.x == 0) { __hip_atomic_store(ab, 9u, XK_RLX_AGENT); a.status[1] = 9; }
       ok = false;
-    } else if (G::RPLT < G::RPLS && TR <= LPC * G::RPLT) ok = xk_pipe_tile<G, G::RPLT>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
-    else if (G::RPLS < RPL && TR <= LPC * G::RPLS) ok = xk_pipe_tile<G, G::RPLS>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
-    else ok = xk_pipe_tile<G, RPL>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows);
+    } else if (G::RPLT < G::RPLS && TR <= LPC * G::RPLT) ok = xk_pipe_tile<G, G::RPLT>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows, hbuf, HB, nvalid);
+    else if (G::RPLS < RPL && TR <= LPC * G::RPLS) ok = xk_pipe_tile<G, G::RPLS>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows, hbuf, HB, nvalid);
+    else ok = xk_pipe_tile<G, RPL>(ap, (int)xcc, slot, t_entry, ubuf, sc, &s_ok, rp_rows, hbuf, HB, nvalid);
   }
   else if (slot < NT + NM) ok = xk_pipe_first<G>(ap, (int)xcc, slot - NT, ubuf, sc, &s_ok, pfbuf);
   else {

@@ -50,6 +50,11 @@ struct XkFeatArgs {
   const double *chi95;  // chi-square 0.95 quantile, indexed by dof
   double *A;            // tiles [ntiles][DB][C1P] row-major
   int DB, C1P, na;      // na active columns, residual in column na
+  // FACTOR RECORDS instead of the tile (Hc != nullptr; 64-row slots only): what the rows 3.. of Q^T [J | res] are made of --
+  // per row {v0, v1, v2, r'} (XK_HC_VR doubles), per column {w0, w1, w2, x0, x1, r0} (xk_h0_entry) -- hs doubles per track, a tenth
+  // of its tile.  xk_caqr_pipe forms the entries from them; the multi-launch schedule has xk_expand_records write the tiles first.
+  double *Hc;
+  int hs;
   int *tile_rows;       // rows of tile k that hold data (0 = skip)
   int *inlier;
   double *gamma;
@@ -72,6 +77,21 @@ struct XkFeatBatch {
   int n_poses, n_poses_max, n, L;
   double *up_out;
 };
+
+// Entry (row r, column c) of Q^T [J | res], Q = H0 H1 H2 = I - V T V^T, from the track's factor record: column c of [J | res]
+// has two non-zero entries x0, x1 in rows r0, r0 + 1 (the observation of c's pose), w = T^T V^T J[:, c]; r0 = -1: the residual
+// column (the entry is r'[r]), r0 = -2: a column the track does not touch.  (msckf_update.cpp:423-432)
+#define XK_HC_ROWS 68               // rows a record holds: 2 L <= 66 next to 64-row slots
+#define XK_HC_VR (4 * XK_HC_ROWS)   // doubles of its per-row part {v0, v1, v2, r'}; the per-column part follows,
+#define XK_HC_WC 6                  // doubles per column: {w0, w1, w2, x0, x1, r0}
+__device__ __forceinline__ int xk_hc_stride(int C1P) { return XK_HC_VR + XK_HC_WC * C1P; }
+__device__ __forceinline__ double xk_h0_entry(double w0, double w1, double w2, double x0, double x1, int r0, double v0, double v1, double v2,
+                                              double rres, int r) {
+  double v = -w0 * v0 - w1 * v1 - w2 * v2;
+  if (r == r0) v += x0;
+  if (r == r0 + 1) v += x1;
+  return (r0 == -1) ? rres : (r0 == -2 ? 0.0 : v);
+}
 
 __device__ __forceinline__ void xk_quat_to_rot(const double *q, double *r /*row-major 3x3*/) {
   // q.normalized().toRotationMatrix(), camera -> world (msckf_update.cpp:339)
@@ -914,12 +934,41 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
       const double w0 = tau0 * a0;
       const double w1 = tau1 * (a1 - w0 * g01);
       const double w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
-      for (int r = 3; r < m2; ++r) {
-        double v = -w0 * V[r] - w1 * V[m2 + r] - w2 * V[2 * m2 + r];
-        if (r == r0) v += x0;
-        if (r == r0 + 1) v += x1;
-        tile[(size_t)(r - 3) * a.C1P + c] = v;
+      for (int r = 3; r < m2; ++r) tile[(size_t)(r - 3) * a.C1P + c] = xk_h0_entry(w0, w1, w2, x0, x1, r0, V[r], V[m2 + r], V[2 * m2 + r], 0.0, r);
+    }
+  };
+  // ---- or the factor record of the track (a.Hc): the same numbers, not multiplied out
+  auto record_write = [&](int t0, int nthr) {
+    double *rec = a.Hc + (size_t)k * a.hs;
+    for (int r = t0; r < m2; r += nthr) {
+      xk_d2 p0v = {V[r], V[m2 + r]}, p1v = {V[2 * m2 + r], res[r]};
+      reinterpret_cast<xk_d2 *>(rec + 4 * r)[0] = p0v;
+      reinterpret_cast<xk_d2 *>(rec + 4 * r)[1] = p1v;
+    }
+    const int N3 = 3 * a.n_poses_max;
+    for (int c = t0; c < a.C1P; c += nthr) {
+      double w0 = 0.0, w1 = 0.0, w2 = 0.0, x0 = 0.0, x1 = 0.0;
+      int r0 = -2;
+      if (c == a.na) r0 = -1;
+      else {
+        int i = -1, comp = 0;
+        const double *blk = nullptr;
+        if (c < N3) { i = c / 3 - p0; comp = c % 3; blk = Jp; }
+        else if (c < 2 * N3) { i = (c - N3) / 3 - p0; comp = (c - N3) % 3; blk = Ja; }
+        if (c < a.na && i >= 0 && i < L) {
+          x0 = blk[6 * i + comp]; x1 = blk[6 * i + 3 + comp];
+          r0 = 2 * i;
+          const double a0 = V[r0] * x0 + V[r0 + 1] * x1;
+          const double a1 = V[m2 + r0] * x0 + V[m2 + r0 + 1] * x1;
+          const double a2 = V[2 * m2 + r0] * x0 + V[2 * m2 + r0 + 1] * x1;
+          w0 = tau0 * a0;
+          w1 = tau1 * (a1 - w0 * g01);
+          w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
+        }
       }
+      xk_d2 *wc = reinterpret_cast<xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * c);
+      xk_d2 q0 = {w0, w1}, q1 = {w2, x0}, q2 = {x1, (double)r0};
+      wc[0] = q0; wc[1] = q1; wc[2] = q2;
     }
   };
   // ---- Cholesky of S = M[3:,3:] (d x d) with the residual as an extra row d (:457-458):
@@ -935,6 +984,7 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
     double *work = scal + 32 + 12 * Lmax + 64;
     work += ((size_t)work >> 3) & 1;
     if (tid < 64) xk_chol_gate_blocked<PACKED>(Mm, ldm, d, tid, scal, work);
+    else if (a.Hc) record_write(tid - 64, XK_FEAT_THREADS - 64);
     else if (a.A) tile_write(tid - 64, XK_FEAT_THREADS - 64);   // the other three waves write the tile meanwhile: a
                                                                  // rejected track's tile is masked by tile_rows = 0
   } else if (PACKED) {
@@ -999,9 +1049,12 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
     }
     if (tid < 3) ur[tid] = res[tid];
   }
-  if (scal[11] == 0.0 || !a.A) { XK_WG_END(); return; }
+  if (scal[11] == 0.0 || (!a.A && !a.Hc)) { XK_WG_END(); return; }
 
-  if (d >= 64) tile_write(tid, XK_FEAT_THREADS);   // (shorter windows wrote the tile next to the single-wave gate)
+  if (d >= 64) {                                   // (shorter windows wrote the tile next to the single-wave gate)
+    if (a.Hc) record_write(tid, XK_FEAT_THREADS);
+    else tile_write(tid, XK_FEAT_THREADS);
+  }
   XK_STAMP(7);
   XK_WG_END();
 }
@@ -1009,6 +1062,31 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
   xk_msckf_feature_body<false>(a_in);
 }
+// The tiles of the tracks that passed, from their factor records -- for the multi-launch schedule when the single launch that
+// would have formed the entries itself gave up or was not taken (rare: the records are only written when it is expected to run).
+struct XkExpandArgs {
+  const double *Hc;
+  int hs;
+  double *A;
+  int DB, C1P;
+  const int *tile_rows;
+};
+__global__ __launch_bounds__(256) void xk_expand_records(XkExpandArgs a) {
+  const int k = blockIdx.x, d = a.tile_rows[k];
+  if (d <= 0) return;
+  const double *rec = a.Hc + (size_t)k * a.hs;
+  double *tile = a.A + (size_t)k * a.DB * a.C1P;
+  for (int c = threadIdx.x; c < a.C1P; c += 256) {
+    const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * c);
+    const xk_d2 q0 = wc[0], q1 = wc[1], q2 = wc[2];
+    const int r0 = (int)q2[1];
+    for (int r = 3; r < d + 3; ++r) {
+      const xk_d2 va = reinterpret_cast<const xk_d2 *>(rec + 4 * r)[0], vb = reinterpret_cast<const xk_d2 *>(rec + 4 * r)[1];
+      tile[(size_t)(r - 3) * a.C1P + c] = xk_h0_entry(q0[0], q0[1], q1[0], q1[1], q2[0], r0, va[0], va[1], vb[0], vb[1], r);
+    }
+  }
+}
+
 // windows of 34..64 poses: the gate matrix as a packed triangle (two workgroups per CU instead of one)
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature_packed(XkFeatArgs a_in) {
   xk_msckf_feature_body<true>(a_in);
