@@ -778,6 +778,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     double b[RM], b2[NCM > 1 ? RM : 2];
     // the pending strip: what the last level left of this XCD's root of the previous panel (XCD 0's root is its pivot strip)
     b[0] = 0.0;
+    b2[0] = 0.0;
     int ncl_prev, lchalf_prev, lsplit_prev;                 // last-level workgroups of panel k - 1
     xk_pipe_lastcut(a.C1 - c0, NCL, ncl_prev, lchalf_prev, lsplit_prev);
     lsplit_prev = min(XK_PIPE_NLW, lsplit_prev);
@@ -785,11 +786,15 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     if (k >= 1 && has_pending) {
 #if XK_DATA_POLL
       // the slots say themselves when the last level has written them (xk_xcd_sync.hip.h): no counter, no barrier in front of the load
-      double pb1[1] = {0.0};
+      double pb1[1] = {0.0}, pb2[1] = {0.0};
       if (!xk_poll_slots<1>(pb1, a.X2 + pslab * SS + xk_blk(min(col, a.C1P - 1), part), 0, mine, ab, 4u)) *s_ok = 0u;
+      if constexpr (NCM > 1) {
+        if (!xk_poll_slots<1>(pb2, a.X2 + pslab * SS + xk_blk(min(col2, a.C1P - 1), part), 0, mine2, ab, 4u)) *s_ok = 0u;
+      }
       __syncthreads();
       if (*s_ok == 0u) return false;                         // (s_ok: 1 on entry, only ever cleared -- uniform verdict, no second barrier)
       if (mine) b[0] = pb1[0];
+      if constexpr (NCM > 1) b2[0] = mine2 ? pb2[0] : 0.0;
       if (a.dbg && tid == 0) a.dbg[4096 + ((xcc * NG + grp) * NM + item) * 32 + k] = wall_clock64();
 #else
       if (!xk_pipe_wait(sync + (XP_P_CNT + k - 1) * 16, (unsigned)lsplit_prev, ab, 4u, s_ok)) return false;
@@ -800,8 +805,10 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
     for (int s = 1; s < RM; ++s) b[s] = 0.0;
     if constexpr (NCM > 1) {
 #pragma unroll
-      for (int s = 0; s < RM; ++s) b2[s] = 0.0;
+      for (int s = 1; s < RM; ++s) b2[s] = 0.0;
+#if !XK_DATA_POLL
       if (k >= 1 && has_pending && mine2) b2[0] = xk_ld_sc1(a.X2 + pslab * SS + xk_blk(col2, part));
+#endif
     }
     double *g02 = a.S + (size_t)base * SS + xk_blk(min(col2, a.C1P - 1), part);
     double *x12 = a.X1 + slab * SS + xk_blk(min(col2, a.C1P - 1), part);
