@@ -42,6 +42,10 @@ class Updater {
   bool resident_{false};
   xk_handle *xk_{nullptr};                   // device engine (include/xk.h), owned by the concrete updater
   double prof_us_[4] = {0, 0, 0, 0};
+  // The pass Updater::update is about to run (updater.cpp:99-110): what applyUpdate will be called with is known before
+  // constructUpdate, so a subclass can queue the whole pass at once (xk_build_compress_update_pass_async)
+  const double *pass_correction_total_{nullptr};   // n doubles, the corrections of the passes so far (:140); nullptr outside the loop
+  bool pass_cov_update_{true};
   bool compressed_on_device_{false};         // constructUpdate left [T_H|z] (and, unless CI ran, the prior) resident
 
   void applyUpdate(State &state, const Matrix &H, const Matrix &res, const Matrix &R, Matrix &correction_total,

@@ -59,7 +59,10 @@ void Updater::update(State &state) {                   // updater.cpp:39-115
       for (int i = 0; i < iekf_iter_; i++) {
         const bool is_last_iter = i == iekf_iter_ - 1;
         t0 = std::chrono::steady_clock::now();
+        pass_correction_total_ = correction.data();
+        pass_cov_update_ = is_last_iter;
         constructUpdate(state, h, res, r);
+        pass_correction_total_ = nullptr;
         prof_us_[1] += usSince(t0);
         t0 = std::chrono::steady_clock::now();
         if (h.size() > 0) applyUpdate(state, h, res, r, correction, is_last_iter);

@@ -124,10 +124,14 @@ void VioUpdater::buildAndCompress(const State &state, const TrackList &tr, bool 
     // for Updater::update.
     // Single agent, one pass (updater.cpp:99-110 with iekf_iter = 1): nothing comes between constructUpdate and
     // applyUpdate(correction_total = 0, cov_update = true), so the Kalman update is queued with the rows -- inside the compression
-    // launch where the geometry allows it.  The MULTI_UAV order (applyCI entries rewrite the covariance in between, :84-97) and
-    // IEKF passes (correction_total, cov_update known only at applyUpdate) keep the two-call form.
+    // launch where the geometry allows it.  IEKF passes (iekf_iter > 1): Updater::update says before constructUpdate what the
+    // pass's applyUpdate will be called with (correction_total so far, cov_update = last pass), so they are queued whole too.
+    // Only the MULTI_UAV order (applyCI entries rewrite the covariance in between, :84-97) keeps the two-call form.
     if (!multi_uav_ && (iekf_iter_ == 1 || !with_slam))   // (the short-track update, with_slam = false, is always one pass: updater.cpp:50-74)
       check(xk_, xk_build_compress_update_async(xk_, sigma_img_), "xk_build_compress_update_async");
+    else if (!multi_uav_ && pass_correction_total_)
+      check(xk_, xk_build_compress_update_pass_async(xk_, sigma_img_, pass_correction_total_, pass_cov_update_ ? 1 : 0),
+            "xk_build_compress_update_pass_async");
     else
       check(xk_, xk_build_compress_async(xk_, sigma_img_), "xk_build_compress_async");
     flags_pending_ = true;

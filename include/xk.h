@@ -318,6 +318,13 @@ int xk_build_compress_async(xk_handle *h, double sigma_img);
  * correction_total / cov_update there is XK_EINVAL.  For the single-agent order with iekf_iter = 1 (updater.cpp:99-110); NOT for
  * the MULTI_UAV order, whose applyCI entries replace the covariance between constructUpdate and applyUpdate (:84-97). */
 int xk_build_compress_update_async(xk_handle *h, double sigma_img);
+
+/* The same for ONE PASS of the iterated update (updater.cpp:99-110, iekf_iter > 1): both arguments of the applyUpdate that
+ * follows are known when constructUpdate is called -- correction_total is what the passes so far accumulated (:140), cov_update is
+ * "this is the last pass" -- so the pass is queued whole: corr = K (res + H corr_total) - corr_total (:126-128), the covariance
+ * updated only if cov_update.  corr_total: n doubles on the host, NULL = zeros.  xk_apply_update(h, the same corr_total, the same
+ * cov_update, correction) then only waits; other arguments there are XK_EINVAL and leave the queued pass collectable. */
+int xk_build_compress_update_pass_async(xk_handle *h, double sigma_img, const double *corr_total, int cov_update);
 /* The gate results of the last build (any pointer may be NULL); synchronises the stream if it is still busy. */
 int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam);
 

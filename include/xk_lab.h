@@ -6,14 +6,16 @@
  *
  * Environment switches the lab build reads (once each; defaults in parentheses):
  *   at xk_create     XK_CAQR_RESIDENT (1)  XK_CAQR_RESIDENT_POISON (0)  XK_CAQR_TEST_STALL (0)  XK_CAQR_TALL26 (1)  XK_CAQR_REARM (64)
- *                    XK_PIPE_KALMAN (1)  XK_QUIET (0)
+ *                    XK_PIPE_KALMAN (1)  XK_PIPE_SPLIT (1)  XK_HLITE (1)  XK_QUIET (0)
  *   compression      XK_CAQR_WT (0)  XK_CAQR_ARITY1 (auto)  XK_CAQR_CHALF (8)  XK_CAQR_OVERLAP (1)  XK_CAQR_SKIP_REJECTED (1)
  *                    XK_CAQR_PERSIST_DBG (0)  XK_CAQR_LCHALF (auto)  XK_CAQR_ADAPT (1)  XK_CAQR_CUS (256)  XK_CAQR_M32 (1)  XK_CAQR_STREAM (1)
  *   Kalman stage     XK_GEMM_STRUCT (1)  XK_CHOL_WHOLE (1)  XK_CHOL_SPLIT (1)  XK_SPIN_DONE (1)
  *   CI round         XK_CI_SIDE_STREAMS (1)        replay: XK_GRAPH (0)
  * xk_set_option names of the lab build, besides the release ones: "caqr_poison" (1: raise the abort word before every single
  * launch -- it gives up, the host redoes the update), "caqr_test_stall" (1: one workgroup of the single launch never shows up),
- * "caqr_tall26", "pipe_kalman".
+ * "caqr_tall26", "pipe_kalman", "pipe_split" (0: 184 tiles always, 1: the adaptive default, 2: 152 tiles when the nominal rows fit,
+ * 3: always), "caqr_hlite" (0: the per-feature kernel writes 64-row tiles of H0 as before round 5; 1, default: factor records for the
+ * narrow single launch, csrc/xk_feature.hip.h XkFeatArgs::Hc).
  */
 #ifndef XK_LAB_H_
 #define XK_LAB_H_

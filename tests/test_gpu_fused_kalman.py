@@ -103,3 +103,53 @@ def test_launch_that_gives_up_with_the_update_inside(xk, oracle_c):
     with pytest.raises(RuntimeError):
         eng.apply_update(np.ones(eng.n), True)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["headline_n195", "cfg1_n75", "n31_k90_n201", "slam_n24_m8_n183", "ragged_n30"])
+def test_iterated_pass_inside_the_launch(xk, name):
+    """One pass of the iterated update (updater.cpp:99-110, iekf_iter > 1) queued whole: correction_total != 0 enters the Kalman
+    role as the start value of its correction column (d = -ct: the block recurrence d += K_k (z_k - T_k d) then ends at
+    K (res + H ct) - ct, updater.cpp:126-128), cov_update = 0 sends the role's posterior to a scratch matrix and leaves the
+    prior.  Against the separate Kalman launches and against NumPy on the compressed system the device itself produced."""
+    sc = SHAPES[name]()
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
+    rng = np.random.default_rng(77)
+    eng = xk.LabEngine(N, M, max(K, 1))
+    n = eng.n
+    ct = 1e-3 * rng.standard_normal(n)
+    # the compressed system and the prior, as the device has them
+    eng.stage(sc)
+    P0 = eng.download_P()
+    eng.msckf_build(sc["sigma_img"])
+    T, z = eng.qr_compress()
+    S = T @ P0 @ T.T + sc["sigma_img"] ** 2 * np.eye(n)
+    Kg = np.linalg.solve(S, T @ P0).T
+    want_corr = Kg @ (z + T @ ct) - ct
+    want_P = (np.eye(n) - Kg @ T) @ P0
+    want_P = 0.5 * (want_P + want_P.T)
+    for kalman in (1, 0):
+        eng.set_option("pipe_kalman", kalman)
+        for cov in (False, True):
+            eng.stage(sc)
+            eng.build_compress_update_pass_async(sc["sigma_img"], ct, cov)
+            with pytest.raises(RuntimeError):
+                eng.apply_update(2.0 * ct, cov)                         # not the pass that was queued: refused, still collectable
+            with pytest.raises(RuntimeError):
+                eng.apply_update(ct, not cov)
+            corr = eng.apply_update(ct, cov)
+            P = eng.download_P()
+            assert eng.caqr_status()["schedule"] == 2 and eng.caqr_status()["giveups"] == 0
+            assert rel(corr, want_corr) <= 1e-7, (kalman, cov, rel(corr, want_corr))
+            assert rel(P, want_P if cov else P0) <= (1e-8 if cov else 0.0), (kalman, cov)
+    # zero correction_total through the pass entry point == the one-pass entry point
+    eng.set_option("pipe_kalman", 1)
+    eng.stage(sc)
+    eng.build_compress_update_pass_async(sc["sigma_img"], np.zeros(n), True)
+    c0 = eng.apply_update(None, True)
+    Pa = eng.download_P()
+    eng.stage(sc)
+    assert eng.L.xk_build_compress_update_async(eng.h, C.c_double(sc["sigma_img"])) == 0
+    c1 = eng.apply_update(np.zeros(n), True)
+    assert np.array_equal(c0, c1) and np.array_equal(Pa, eng.download_P())
+    eng.close()

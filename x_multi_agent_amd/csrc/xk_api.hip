@@ -85,6 +85,9 @@ struct xk_handle {
   int opt_resident, opt_poison, opt_test_stall, opt_tall26;
   int opt_kalman;          // the Kalman update inside the single launch (xk_pipe_kalman) where the geometry allows it
   bool last_fused;         // the last launch_compress also queued the Kalman update (posterior in d_Pout, correction written)
+  int fused_cov_update;    // what the queued pass was asked for (xk_build_compress_update[_pass]_async): xk_apply_update must ask the same
+  bool fused_ct_zero;
+  std::vector<double> *fused_ct;
   bool fused_pending;      // xk_build_compress_update_async ran: xk_apply_update only has to wait
   unsigned long long fused_seq;   // ... for this completion marker (0: for the stream)
   bool xsync_dirty;     // a pipelined launch gave up: its counters are mid-count, clear both sets before the next one
@@ -395,6 +398,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   free(h->h_trk2_off);
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Hc) hipFree(h->d_Hc);
+  delete h->fused_ct;
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_Psnap2) hipFree(h->d_Psnap2);
   if (h->d_fq) hipFree(h->d_fq);
@@ -943,10 +947,12 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
       pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
       pa.test_stall = h->opt_test_stall;
-      pa.kal = 0; pa.kn = h->n; pa.Pin = nullptr; pa.Pout = nullptr; pa.sigma2 = 0.0; pa.corr = nullptr; pa.done_flag = nullptr; pa.done_seq = 0;
-      if (fuse && narrow && h->opt_kalman && fuse->cov_update && !fuse->ct && !fuse->S && !fuse->rdiag && fuse->T == h->d_R &&
+      pa.kal = 0; pa.kn = h->n; pa.Pin = nullptr; pa.Pout = nullptr; pa.sigma2 = 0.0; pa.corr = nullptr; pa.ct = nullptr; pa.done_flag = nullptr; pa.done_seq = 0;
+      if (fuse && narrow && h->opt_kalman && !fuse->S && !fuse->rdiag && fuse->T == h->d_R &&
           h->n <= 206 && h->n_cu == 256) {
-        pa.kal = 1; pa.Pin = fuse->Pin; pa.Pout = fuse->Pout; pa.sigma2 = fuse->rscalar;
+        // (a pass that leaves the covariance alone, cov_update = 0: the role needs the block-by-block posterior to get the
+        //  correction right, so it runs as ever and its posterior goes to a scratch matrix; Pout becomes a copy of the prior below)
+        pa.kal = 1; pa.Pin = fuse->Pin; pa.Pout = fuse->cov_update ? fuse->Pout : h->d_tmpP; pa.sigma2 = fuse->rscalar; pa.ct = fuse->ct;
         pa.corr = fuse->corr ? fuse->corr : h->d_corr;
         pa.done_flag = fuse->done_flag; pa.done_seq = fuse->done_seq;
         h->last_fused = true;
@@ -955,6 +961,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       if (split) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow2>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeWide>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      if (pa.kal && !fuse->cov_update && fuse->Pout != fuse->Pin &&
+          hipMemcpyAsync(fuse->Pout, fuse->Pin, sizeof(double) * (size_t)h->n * h->n, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+        return fail(h, XK_EDEVICE, "prior copy");
       if (mid) hipEventRecord(mid, h->stream);
       h->nleaf = NTP; h->nlevels = 1; h->have_R = true; h->last_resident = true; h->last_pipe = true;
       hipError_t e = hipGetLastError();
@@ -1347,13 +1356,24 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
 // then only waits for the result.  For callers that know at construction time that nothing comes between constructUpdate and
 // applyUpdate (single agent, iekf_iter = 1: updater.cpp:99-110 with one pass) -- not the MULTI_UAV order, whose applyCI entries
 // replace the covariance in between (updater.cpp:84-97).
-extern "C" int xk_build_compress_update_async(xk_handle *h, double sigma_img) {
+static int build_compress_update_pass(xk_handle *h, double sigma_img, const double *corr_total, int cov_update) {
   if (!h || !(sigma_img > 0.0)) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
+  bool ct_zero = true;
+  if (corr_total)
+    for (int i = 0; i < h->n && ct_zero; ++i) ct_zero = corr_total[i] == 0.0;
+  const double *dct = nullptr;
+  if (!ct_zero) {
+    double *st = (double *)stage_slot(h, sizeof(double) * h->n);
+    if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");
+    memcpy(st, corr_total, sizeof(double) * h->n);
+    HIPCHK(h, hipMemcpyAsync(h->d_ct, st, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    dct = h->d_ct;
+  }
   int rc = launch_build(h, sigma_img);
   if (rc != XK_OK) return rc;
   if ((rc = cache_flags(h)) != XK_OK) return rc;
-  UpdateSpec u = compressed_spec(h, nullptr, 1);
+  UpdateSpec u = compressed_spec(h, dct, cov_update ? 1 : 0);
   u.corr = h->h_out;
   static const int spin_env = env_int("XK_SPIN_DONE", 1);
   if (spin_env) { u.done_flag = reinterpret_cast<unsigned long long *>(h->h_out + h->n + 2); u.done_seq = ++h->done_seq; }
@@ -1362,7 +1382,15 @@ extern "C" int xk_build_compress_update_async(xk_handle *h, double sigma_img) {
   h->async_pending = true;
   h->fused_pending = true;
   h->fused_seq = spin_env ? u.done_seq : 0;
+  h->fused_cov_update = cov_update ? 1 : 0;
+  h->fused_ct_zero = ct_zero;
+  if (!h->fused_ct) h->fused_ct = new std::vector<double>();
+  if (ct_zero) h->fused_ct->clear(); else h->fused_ct->assign(corr_total, corr_total + h->n);
   return XK_OK;
+}
+extern "C" int xk_build_compress_update_async(xk_handle *h, double sigma_img) { return build_compress_update_pass(h, sigma_img, nullptr, 1); }
+extern "C" int xk_build_compress_update_pass_async(xk_handle *h, double sigma_img, const double *corr_total, int cov_update) {
+  return build_compress_update_pass(h, sigma_img, corr_total, cov_update);
 }
 
 extern "C" int xk_fetch_flags(xk_handle *h, int *inlier_msckf, double *gamma_msckf, int *inlier_slam, double *gamma_slam) {
@@ -1396,8 +1424,11 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     for (int i = 0; i < h->n && ct_zero; ++i) ct_zero = corr_total[i] == 0.0;
   // arguments first, before any state of the handle is touched: a mismatch with what xk_build_compress_update_async queued leaves the
   // queued update (posterior in d_Pout, marker, retry bookkeeping) exactly as it was -- the matching call can still collect it
-  if (h->fused_pending && (!ct_zero || !cov_update))
-    return fail(h, XK_EINVAL, "xk_build_compress_update_async queued applyUpdate(correction_total = 0, cov_update = true)");
+  if (h->fused_pending) {
+    bool same = (cov_update ? 1 : 0) == h->fused_cov_update && ct_zero == h->fused_ct_zero;
+    if (same && !ct_zero) same = memcmp(corr_total, h->fused_ct->data(), sizeof(double) * h->n) == 0;
+    if (!same) return fail(h, XK_EINVAL, "xk_apply_update: not the correction_total / cov_update the queued pass was built with");
+  }
   if (corr_total && !ct_zero) {
     double *st = (double *)stage_slot(h, sizeof(double) * h->n);
     if (!st) return fail(h, XK_ECAPACITY, "staging slot too small");

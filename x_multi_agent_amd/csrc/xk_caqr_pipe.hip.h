@@ -162,13 +162,14 @@ struct XkCaqrPipeArgs {
   int *status;
   long long *dbg;
   int test_stall;         // test hook: one tile workgroup leaves at once -- everybody else runs into the bound of their spins
-  // Kalman role (xk_pipe_kalman; narrow geometry): Updater::applyUpdate (updater.cpp:117-141, correction_total = 0, cov_update)
+  // Kalman role (xk_pipe_kalman; narrow geometry): Updater::applyUpdate (updater.cpp:117-141, cov_update)
   // inside this launch.  kal = 0: the compressed [T_H | z] is all the launch leaves behind.
   int kal, kn;            // on / off, n = error states
   const double *Pin;      // prior, n x n column-major
   double *Pout;           // posterior
   double sigma2;          // sigma_img^2 (vio_updater.cpp:508-509)
   double *corr;           // [n] correction (device or pinned host memory)
+  const double *ct;       // [n] correction_total of the IEKF passes (updater.cpp:128: K (res + H ct) - ct), nullptr = 0: d starts at -ct
   unsigned long long *done_flag;   // optional completion marker (pinned host memory) ...
   unsigned long long done_seq;     // ... and its value
 };
@@ -1074,7 +1075,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
 }
 
 
-// ---- role K: the Kalman update (Updater::applyUpdate, src/x/ekf/updater.cpp:117-141, with correction_total = 0 and cov_update)
+// ---- role K: the Kalman update (Updater::applyUpdate, src/x/ekf/updater.cpp:117-141, cov_update; correction_total through d's start)
 // INSIDE the compression launch, on the one workgroup the last level does not need (XCD 7's).  The 16 rows of R that panel k
 // finishes are rows 16 k .. 16 k + 15 of the compressed measurement matrix T -- final from then on -- and the compressed rows
 // all carry the same noise sigma^2 I (vio_updater.cpp:508-509), so the update can be applied BLOCK BY BLOCK as the panels
@@ -1303,7 +1304,10 @@ __device__ __noinline__ bool xk_pipe_kalman(XkPipeArgsPtr ap, xk_ldsd *kb, unsig
   unsigned *sync = a.sync, *ab = sync + XP_ABORT * 16;
   const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = a.kn, na = a.C1 - 1, npanels = (a.C1 + 15) / 16;
-  auto ldsym = [&](int row, int col) {                     // the prior, symmetrised
+  // the prior, symmetrised; column 207 = d, the correction so far.  The blocks run d += K_k (z_k - T_k d); started at -correction_total
+  // that recurrence ends at K (res + H ct) - ct, which is what updater.cpp:128 asks of an IEKF pass (ct = 0: the plain update)
+  auto ldsym = [&](int row, int col) {
+    if (col == XK_KAL_DC) return (a.ct && row < n) ? -a.ct[row] : 0.0;
     return (row < n && col < n) ? 0.5 * (a.Pin[(size_t)row + (size_t)col * n] + a.Pin[(size_t)col + (size_t)row * n]) : 0.0;
   };
   // what a block starts with: the rows of R the last level has just finished, by STATE index -- Tl[m][15 + c] = R[c0 + m][c],

@@ -31,7 +31,7 @@ SYMBOLS = [
     "xk_ci_round_device", "xk_cov_congruence", "xk_cov_propagate",
     "xk_stage_msckf_slam", "xk_msckf_slam_results", "xk_init_msckf_slam_features", "xk_init_standard_slam_features",
     "xk_payload_doubles", "xk_pack_payload", "xk_bench_staged", "xk_run_steps",
-    "xk_apply_ci_resident", "xk_snapshot_P", "xk_caqr_status", "xk_set_option", "xk_build_compress_async", "xk_build_compress_update_async", "xk_fetch_flags",
+    "xk_apply_ci_resident", "xk_snapshot_P", "xk_caqr_status", "xk_set_option", "xk_build_compress_async", "xk_build_compress_update_async", "xk_build_compress_update_pass_async", "xk_fetch_flags",
     "xk_pr_create", "xk_pr_destroy", "xk_pr_vlad_bytes", "xk_pr_size", "xk_pr_compute_vlad", "xk_pr_add_keyframe",
     "xk_pr_find_candidate", "xk_pr_keyframe", "xk_pr_copy_keyframe", "xk_pr_knn_match",
 ]
@@ -184,6 +184,14 @@ class Engine:
         self._chk(self.L.xk_qr_compress(self.h, T.ctypes.data_as(c_dp), C.c_int(self.n), z.ctypes.data_as(c_dp)),
                   "xk_qr_compress")
         return np.ascontiguousarray(T), z
+
+    def build_compress_update_pass_async(self, sigma_img, corr_total=None, cov_update=True):
+        """One pass of the iterated update queued whole (include/xk.h); collect it with apply_update(the same arguments)."""
+        ctp = None
+        if corr_total is not None:
+            ct, ctp = _d(corr_total)
+        self._chk(self.L.xk_build_compress_update_pass_async(self.h, C.c_double(sigma_img), ctp, C.c_int(int(cov_update))),
+                  "xk_build_compress_update_pass_async")
 
     def apply_update(self, corr_total=None, cov_update=True):
         corr = np.zeros(self.n)
