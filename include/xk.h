@@ -308,7 +308,12 @@ int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned
 /* xk_msckf_build + xk_qr_compress queued on the handle's stream with NO host synchronisation and no host outputs:
  * together with the non-blocking staging calls and xk_cov_congruence / xk_cov_propagate, a whole frame -- covariance
  * propagation, StateManager::manage, per-feature build, QR compression, Kalman update -- is queued back to back and
- * xk_apply_update's single synchronisation brings the correction, the status and the gate results back. */
+ * xk_apply_update's single synchronisation brings the correction, the status and the gate results back.
+ * For callers that have something between constructUpdate and applyUpdate that rewrites the covariance -- the applyCI entries of
+ * the MULTI_UAV order (updater.cpp:84-97).  [T_H | z] does not depend on the covariance once the gates have read the prior (the
+ * per-feature kernel, queued here), so where the single launch can take the Kalman update along (narrow systems, n <= 206) the
+ * compression itself is queued by xk_apply_update, behind those entries, with the update inside: one launch there instead of one
+ * here and five there.  xk_qr_compress / xk_fetch_flags behave as before. */
 int xk_build_compress_async(xk_handle *h, double sigma_img);
 
 /* xk_build_compress_async with the Kalman update of Updater::applyUpdate(correction_total = 0, cov_update = true)

@@ -153,3 +153,39 @@ def test_iterated_pass_inside_the_launch(xk, name):
     c1 = eng.apply_update(np.zeros(n), True)
     assert np.array_equal(c0, c1) and np.array_equal(Pa, eng.download_P())
     eng.close()
+
+
+@pytest.mark.parametrize("poison", [0, 1])
+def test_two_call_form_defers_the_compression_behind_what_rewrites_the_covariance(xk, poison):
+    """MULTI_UAV order (updater.cpp:84-97): constructUpdate, then applyCI entries that REPLACE the covariance, then applyUpdate on
+    the [T_H | z] that was linearised and gated at the prior.  xk_build_compress_async queues the rows only where the single launch
+    can take the Kalman update along; xk_apply_update queues the compression with the Kalman role on the covariance of that
+    moment -- and, if that launch gives up, redoes the compression WITHOUT rebuilding the rows (they belong to the old prior)."""
+    sc = synth.make_config(4)
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    eng = xk.LabEngine(N, 0, K)
+    n = eng.n
+    eng.stage(sc)
+    P0 = eng.download_P()
+    flags = eng.msckf_build(sc["sigma_img"])
+    T, z = eng.qr_compress()                                            # gated and linearised at P0
+    rng = np.random.default_rng(3)
+    A = np.eye(n) + 0.05 * rng.standard_normal((n, n)) / np.sqrt(n)
+    P1 = A @ P0 @ A.T                                                    # what the CI entries leave: another SPD matrix
+    P1 = 0.5 * (P1 + P1.T)
+    S = T @ P1 @ T.T + sc["sigma_img"] ** 2 * np.eye(n)
+    Kg = np.linalg.solve(S, T @ P1).T
+    want_corr = Kg @ z
+    want_P = (np.eye(n) - Kg @ T) @ P1
+    want_P = 0.5 * (want_P + want_P.T)
+    eng.set_option("caqr_poison", poison)
+    eng.stage(sc)
+    assert eng.L.xk_build_compress_async(eng.h, C.c_double(sc["sigma_img"])) == 0
+    eng.upload_P(P1)                                                     # (xk_apply_ci_resident ends with the same pointer swap)
+    corr = eng.apply_update(None, True)
+    P = eng.download_P()
+    st = eng.caqr_status()
+    assert st["giveups"] == poison and (st["schedule"] == 2) == (poison == 0), st
+    assert rel(corr, want_corr) <= 1e-7 and rel(P, want_P) <= 1e-8, (rel(corr, want_corr), rel(P, want_P))
+    eng.set_option("caqr_poison", 0)
+    eng.close()

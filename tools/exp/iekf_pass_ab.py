@@ -14,7 +14,11 @@ eng.stage(sc)
 eng.snapshot_P(0) if hasattr(eng, "snapshot_P") else None
 ct = 1e-3 * np.random.default_rng(5).standard_normal(eng.n)
 out = {}
+eng.close()
+eng = engine.LabEngine(N, M, K)       # (the two-call form of today defers the compression and fuses as well: "pipe_kalman" 0 = as before round 5)
+eng.stage(sc)
 for form in ("pass", "two-call"):
+    eng.set_option("pipe_kalman", 1 if form == "pass" else 0)
     for cov in (0, 1):
         ts = []
         for rep in range(reps + 20):

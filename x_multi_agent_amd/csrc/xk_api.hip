@@ -85,6 +85,8 @@ struct xk_handle {
   int opt_resident, opt_poison, opt_test_stall, opt_tall26;
   int opt_kalman;          // the Kalman update inside the single launch (xk_pipe_kalman) where the geometry allows it
   bool last_fused;         // the last launch_compress also queued the Kalman update (posterior in d_Pout, correction written)
+  bool compress_deferred;  // xk_build_compress_async queued the rows only: the compression waits for xk_apply_update, where the Kalman
+                           // role can ride along on the covariance the applyCI entries in between have left (MULTI_UAV order)
   int fused_cov_update;    // what the queued pass was asked for (xk_build_compress_update[_pass]_async): xk_apply_update must ask the same
   bool fused_ct_zero;
   std::vector<double> *fused_ct;
@@ -816,6 +818,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
   h->sigma_img = sigma_img;
   h->have_rows = true;
   h->have_R = false;
+  h->compress_deferred = false;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "build launch", e);
   return XK_OK;
@@ -1346,7 +1349,15 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
   int rc = launch_build(h, sigma_img);
   if (rc != XK_OK) return rc;
   if ((rc = cache_flags(h)) != XK_OK) return rc;
-  if ((rc = launch_compress(h)) != XK_OK) return rc;
+  // Who calls this instead of xk_build_compress_update[_pass]_async has something between constructUpdate and applyUpdate that
+  // rewrites the covariance (the applyCI entries of the MULTI_UAV order, updater.cpp:84-97).  [T_H | z] does not depend on the
+  // covariance -- the gates have read the prior in the per-feature kernel above -- so where the single launch can take the Kalman
+  // update along (narrow geometry, n <= 206) the compression is not queued now but by xk_apply_update, behind those entries, with
+  // the Kalman role on the covariance they left: one launch there instead of one here and five there.
+  h->compress_deferred = h->opt_resident && h->persist_ok && h->opt_kalman && h->C1 <= XkPipeNarrow::COLS && h->n <= 206 && h->n_cu == 256 &&
+                         h->K + h->K2 + h->M > 0;
+  if (h->compress_deferred) h->have_R = true;     // (as far as xk_apply_update's precondition goes: it runs the compression itself)
+  else if ((rc = launch_compress(h)) != XK_OK) return rc;
   h->async_pending = true;
   return XK_OK;
 }
@@ -1436,14 +1447,23 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     HIPCHK(h, hipMemcpyAsync(h->d_ct, st, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
     dct = h->d_ct;
   }
-  const bool async = h->async_pending, queued = h->fused_pending;
+  const bool deferred = h->compress_deferred;
+  const bool async = h->async_pending || deferred, queued = h->fused_pending;
   h->async_pending = false;
   h->fused_pending = false;
+  h->compress_deferred = false;
   int rc = XK_OK;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (attempt == 1) {   // the single-launch CAQR of xk_build_compress_async gave up: rows, compression and update again
-      if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
-      if ((rc = cache_flags(h)) != XK_OK) return rc;
+      if (deferred) {
+        // ... NOT the rows: they were linearised and gated at the prior, which the applyCI entries have replaced since -- and they
+        // are still there (the single launch only reads the tiles / factor records; it is the multi-launch schedule that works
+        // on the tiles in place, and it has not run)
+        h->have_rows = true;
+      } else {
+        if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
+        if ((rc = cache_flags(h)) != XK_OK) return rc;
+      }
       if ((rc = launch_compress(h)) != XK_OK) return rc;
     }
     UpdateSpec u = compressed_spec(h, dct, cov_update);
@@ -1457,7 +1477,10 @@ extern "C" int xk_apply_update(xk_handle *h, const double *corr_total, int cov_u
     if (waiting_only) u.done_seq = h->fused_seq;
     else {
       if (spin_env) { u.done_flag = done; u.done_seq = ++h->done_seq; }
-      rc = launch_update(h, u);
+      if (deferred && attempt == 0) {                      // the compression xk_build_compress_async left for now, Kalman role inside
+        if ((rc = launch_compress(h, nullptr, &u)) != XK_OK) return rc;
+        rc = h->last_fused ? XK_OK : launch_update(h, u);
+      } else rc = launch_update(h, u);
       if (rc != XK_OK) return rc;
     }
     bool seen = false;
