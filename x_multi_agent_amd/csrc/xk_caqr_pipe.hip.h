@@ -586,7 +586,9 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
       __syncthreads();
       if (stamp) a.dbg[1546] = wall_clock64();
       int kcur = -1, r0 = -2;
-      double w0 = 0.0, w1 = 0.0, w2 = 0.0, x0 = 0.0, x1 = 0.0;
+      double nw0 = 0.0, nw1 = 0.0, nw2 = 0.0, wres = 0.0, x0 = 0.0, x1 = 0.0;
+      // (every row of the tile comes from a record of this chunk -- the usual case: a row exists iff its index is < nvalid, no lookups)
+      const bool whole = lo <= s_lo && s_hi < hi;
 #pragma unroll
       for (int rb = 0; rb < (RPL + BR - 1) / BR; ++rb) {
         if (fc < C1P) {
@@ -599,23 +601,37 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
                 if (sl != kcur) {
                   const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * fc);
                   const xk_d2 q0 = wc[0], q1 = wc[1], q2 = wc[2];
-                  w0 = q0[0]; w1 = q0[1]; w2 = q1[0]; x0 = q1[1]; x1 = q2[0]; r0 = (int)q2[1];
+                  nw0 = -q0[0]; nw1 = -q0[1]; nw2 = -q1[0]; x0 = q1[1]; x1 = q2[0]; r0 = (int)q2[1];
+                  wres = (r0 == -1) ? 1.0 : 0.0;             // the residual column: w = x = 0, the entry is r'
                   kcur = sl;
                 }
-                const int rr = (ph & 63) + 3;
+                // xk_h0_entry without its selects: r0 = -1 / -2 never meet a row (rows start at 3), an untouched column is all
+                // zeros, and + 0.0 comes last (so it is +0.0 whatever the signs of v0..v2)
+                const int rr = (ph & 63) + 3, dd = rr - r0;
                 const xk_d2 va = reinterpret_cast<const xk_d2 *>(rec + 4 * rr)[0], vb = reinterpret_cast<const xk_d2 *>(rec + 4 * rr)[1];
-                Tb[(fp * BR + j) * C1P + fc] = xk_h0_entry(w0, w1, w2, x0, x1, r0, va[0], va[1], vb[0], vb[1], rr);
+                const double add = (dd == 0) ? x0 : ((dd == 1) ? x1 : 0.0);
+                Tb[(fp * BR + j) * C1P + fc] = fma(wres, vb[1], fma(nw2, vb[0], fma(nw1, va[1], nw0 * va[0]))) + add;
               }
             }
           }
         }
         __syncthreads();
+        if (whole) {
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-          if (rb * BR + j < RPL) {
-            const int ph = myrows[part_ * RPL + rb * BR + j], sl = ph >> 6;
-            const double v = Tb[(part_ * BR + j) * C1P + ccl];
-            if (ph >= 0 && sl >= lo && sl < hi) b[rb * BR + j] = mine ? v : 0.0;
+          for (int j = 0; j < BR; ++j) {
+            if (rb * BR + j < RPL) {
+              const double v = Tb[(part_ * BR + j) * C1P + ccl];
+              b[rb * BR + j] = (mine && part_ * RPL + rb * BR + j < nvalid) ? v : 0.0;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < BR; ++j) {
+            if (rb * BR + j < RPL) {
+              const int ph = myrows[part_ * RPL + rb * BR + j], sl = ph >> 6;
+              const double v = Tb[(part_ * BR + j) * C1P + ccl];
+              if (ph >= 0 && sl >= lo && sl < hi) b[rb * BR + j] = mine ? v : 0.0;
+            }
           }
         }
         __syncthreads();                                   // (the block is rewritten; after the last one: hbuf and ubuf have other users)
