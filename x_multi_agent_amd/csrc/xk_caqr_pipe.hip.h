@@ -1517,17 +1517,21 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
     // The workgroups that have nothing to do until the tiles publish their first rows re-arm the OTHER set of cross-XCD slabs
     // for the next launch: X1 | X2 ([panel][16 strips][16 x C1P]: panel k is only ever read at columns >= 16 k, i.e. from offset
     // 256 k of a strip on) then X1P ([panel][16][256]).  Plain stores: the kernel boundary publishes them.
-    const long SSl = 16L * a.C1P, per_panel = (long)XK_PIPE_RLS * SSl, npl = (a.C1 + 15) / 16, x12 = 2 * npl * per_panel;
-    const long nw = 8L * (32 - NT) * XK_PIPE_THREADS, me = ((long)xcc * (32 - NT) + (slot - NT)) * XK_PIPE_THREADS + threadIdx.x;
+    // Strip by strip (2 x panels x 16 of them, dealt over these workgroups), 16 bytes per store, 32-bit index arithmetic: the flat
+    // loop this replaces decided per element, with a 64-bit division and a remainder, whether it is ever read -- 20 us per
+    // workgroup, which the first level of panels 0..2 started late by (LAB round 5).
+    const int SSl = 16 * a.C1P, npl = (a.C1 + 15) / 16, nseg = 2 * npl * XK_PIPE_RLS;
+    const int nwg = 8 * (32 - NT), wg = (int)xcc * (32 - NT) + (slot - NT), tid = (int)threadIdx.x;
     const double ny = xk_notyet();
-    for (long i = me; i < a.xnext_doubles; i += nw) {
-      bool live = true;
-      if (i < x12) {
-        const long j = i < npl * per_panel ? i : i - npl * per_panel;
-        live = (j % SSl) >= 256 * (j / per_panel);
-      }
-      if (live) a.Xnext[i] = ny;
+    const xk_d2 ny2 = {ny, ny};
+    for (int sg = wg; sg < nseg; sg += nwg) {
+      const int k = (sg / XK_PIPE_RLS) % npl;               // the strip's panel
+      double *p = a.Xnext + (size_t)sg * SSl;
+      for (int e = 256 * k + 2 * tid; e < SSl; e += 2 * XK_PIPE_THREADS) *reinterpret_cast<xk_d2 *>(p + e) = ny2;
     }
+    double *pp = a.Xnext + (size_t)nseg * SSl;
+    const int n1p = npl * XK_PIPE_RLS * 256;
+    for (int e = 2 * (wg * XK_PIPE_THREADS + tid); e < n1p; e += 2 * nwg * XK_PIPE_THREADS) *reinterpret_cast<xk_d2 *>(pp + e) = ny2;
   }
 #endif
   bool ok;
