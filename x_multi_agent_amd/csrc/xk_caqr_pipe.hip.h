@@ -692,12 +692,14 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     const unsigned epoch = (unsigned)(k + 1);
     if (stamp) { a.dbg[16 * k + 0] = wall_clock64(); a.dbg[16 * k + 8] = clock64(); }
     if (a.dbg && slot == 0 && tid == 0) a.dbg[12288 + xcc * 32 + k] = wall_clock64();       // (skew_trace: every XCD's panel start)
+    if (a.dbg && tid == 0 && k < 2) a.dbg[40960 + 256 * k + j] = wall_clock64();                 // (every tile's start of panels 0 and 1)
+    if (a.dbg && tid == 0 && k == 0) a.dbg[40960 + 512 + j] = t_entry;
     if (hot) __builtin_amdgcn_s_setprio(3);
     // phase q: steps [q GS, (q + 1) GS), then rows [q GS, (q + 1) GS) of the pivot strip are final and go out; they are counted in
     // ARRD steps into the next phase (their stores drain behind those steps), the last phase after the panel
     auto phase = [&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      auto hook = [&]() { xk_pipe_arrive(sync + (XP_TQ_CNT + (q - 1) * 8 + xcc) * 16); };
+      auto hook = [&]() { xk_pipe_arrive(sync + (XP_TQ_CNT + (q - 1) * 8 + xcc) * 16); if (a.dbg && k == 0 && q == 1) a.dbg[47104 + j] = wall_clock64(); };
       xk_pipe_range<LPC, xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1), (q > 0 ? xk_pbn<NPH>(q) + ARRD : -1), RPL>(b, nullptr, rel, mine, false, part, nsteps, ubuf, sc, full, hook);
       if (pub) {
         if (rel < 16) {
@@ -871,6 +873,7 @@ __device__ __noinline__ bool xk_pipe_first(XkPipeArgsPtr ap, int xcc, int item, 
 #endif
         if (av == 0) { ok = false; return; }
         if (stamp && q < 4) a.dbg[512 + 16 * k + 2 * q] = wall_clock64();
+        if (a.dbg && tid == 0 && k == 0 && q == 0) a.dbg[46080 + (xcc * NG + grp) * NM + item] = wall_clock64();
         XK_INV_LOC();
         if constexpr (PF) {
           // (a first level that runs behind finds several phases complete: one round per phase, the LDS area holds one)
@@ -1512,6 +1515,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   const int slot = __builtin_amdgcn_readfirstlane((int)s_slot);
   __syncthreads();
   if (a.test_stall && xcc == 3 && slot == 5) return;
+  if (a.dbg && slot >= NT && threadIdx.x == 0) a.dbg[45056 + ((int)xcc * 32 + slot) * 2] = wall_clock64();
 #if XK_DATA_POLL
   if (slot >= NT && a.Xnext) {
     // The workgroups that have nothing to do until the tiles publish their first rows re-arm the OTHER set of cross-XCD slabs
@@ -1534,6 +1538,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
     for (int e = 2 * (wg * XK_PIPE_THREADS + tid); e < n1p; e += 2 * nwg * XK_PIPE_THREADS) *reinterpret_cast<xk_d2 *>(pp + e) = ny2;
   }
 #endif
+  if (a.dbg && slot >= NT && threadIdx.x == 0) a.dbg[45056 + ((int)xcc * 32 + slot) * 2 + 1] = wall_clock64();
   bool ok;
   if (slot < NT) {
     int rows_acc;
