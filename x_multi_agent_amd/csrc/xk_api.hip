@@ -259,10 +259,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, hipMemcpy(h->d_chi95, XK_CHI2_095, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
-  h->hc_stride = XK_HC_VR + XK_HC_WC * h->C1P;
+  h->hc_stride = xk_hc_stride(h->DB, h->C1P);
   h->opt_hlite = env_int("XK_HLITE", 1);
   h->rows_compact = false;
-  if (h->DB == 64) HIPCHK(h, dalloc(&h->d_Hc, (size_t)std::max(k_max, 1) * h->hc_stride));
+  HIPCHK(h, dalloc(&h->d_Hc, (size_t)std::max(k_max, 1) * h->hc_stride));
   HIPCHK(h, dalloc(&h->d_tile_rows, (size_t)h->ntiles_max));
   for (auto &pp : h->d_panel) HIPCHK(h, dalloc(&pp, (size_t)(h->ntiles_max + 10) * 256));
   HIPCHK(h, dalloc(&h->d_inl, (size_t)k_max));
@@ -763,12 +763,14 @@ static int launch_build(xk_handle *h, double sigma_img) {
     a.trk_off = h->d_trk_off; a.obs = h->d_obs; a.K = h->K;
     a.P = h->d_P; a.n = h->n; a.var_img = sigma_img * sigma_img; a.chi95 = h->d_chi95;
     a.A = h->d_A; a.DB = h->DB; a.C1P = h->C1P; a.na = h->na;
-    // factor records instead of tiles when the single launch (which forms its entries from them) is armed: H0 never visits HBM.
-    // Should the compression take the multi-launch schedule after all, xk_expand_records writes the tiles first (launch_compress).
-    // (narrow systems only: next to the wide geometry's 80-row tiles and 2 lanes per column forming the entries costs more than
-    //  the tiles' trip through HBM -- config 2: 1546 -> 1521 updates/s)
-    h->rows_compact = h->opt_hlite && h->d_Hc && h->opt_resident && h->persist_ok && !h->feat_dbg && h->C1 <= XkPipeNarrow::COLS;
-    a.Hc = h->rows_compact ? h->d_Hc : nullptr; a.hs = h->hc_stride;
+    // factor records instead of tiles: H0 never visits HBM.  Whoever compresses forms its rows from them -- the tile workgroups
+    // of the single launch (narrow systems; next to the wide geometry's 80-row tiles and 2 lanes per column forming the entries
+    // costs more than the tiles' trip through HBM -- config 2: 1546 -> 1521 updates/s -- so those keep their tiles), or the
+    // first pass of the multi-launch schedule (128-row slots: always; 64-row slots: when the single launch was armed and then
+    // not taken or gave up).
+    h->rows_compact = h->opt_hlite && h->d_Hc && !h->feat_dbg &&
+                      (h->DB == 128 || (h->opt_resident && h->persist_ok && h->C1 <= XkPipeNarrow::COLS));
+    a.Hc = h->rows_compact ? h->d_Hc : nullptr; a.hs = h->hc_stride; a.hcvr = xk_hc_vr(h->DB);
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
     a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
     a.inlier_h = h->h_flag_i; a.gamma_h = h->h_flag_d;     // gate results also straight into the pinned flag cache
@@ -974,11 +976,9 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       return XK_OK;
     }
   }
-  if (h->rows_compact && h->K > 0) {   // the multi-launch schedule works on tiles: multiply the records out
-    XkExpandArgs ea{h->d_Hc, h->hc_stride, h->d_A, h->DB, h->C1P, h->d_tile_rows};
-    hipLaunchKernelGGL(xk_expand_records, dim3(h->K), dim3(256), 0, h->stream, ea);
-    h->rows_compact = false;
-  }
+  // (the tiles of the tracks may be factor records: the first tile pass below forms its rows from them and leaves tiles behind)
+  a.Hc = h->d_Hc; a.hs = h->hc_stride; a.hcvr = xk_hc_vr(h->DB); a.nhc = (h->rows_compact && h->K > 0) ? h->K : 0;
+  h->rows_compact = false;
   // 128-row slots whose tallest tile has <= 104 rows: 26 rows per lane (two workgroups per CU), see xk_caqr_tile
   const int tall26_env = h->opt_tall26;
   auto tile_geom = [&](int c0, int &tsplit, int &tchalf, int &tthreads) {

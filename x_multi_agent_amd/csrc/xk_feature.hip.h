@@ -52,9 +52,10 @@ struct XkFeatArgs {
   int DB, C1P, na;      // na active columns, residual in column na
   // FACTOR RECORDS instead of the tile (Hc != nullptr; 64-row slots only): what the rows 3.. of Q^T [J | res] are made of --
   // per row {v0, v1, v2, r'} (XK_HC_VR doubles), per column {w0, w1, w2, x0, x1, r0} (xk_h0_entry) -- hs doubles per track, a tenth
-  // of its tile.  xk_caqr_pipe forms the entries from them; the multi-launch schedule has xk_expand_records write the tiles first.
+  // of its tile.  xk_caqr_pipe's tile workgroups and the first pass of the multi-launch schedule (xk_caqr_tile, panel 0) form the
+  // entries from them.
   double *Hc;
-  int hs;
+  int hs, hcvr;         // doubles per record / of its per-row part (xk_hc_vr(DB))
   int *tile_rows;       // rows of tile k that hold data (0 = skip)
   int *inlier;
   double *gamma;
@@ -81,10 +82,11 @@ struct XkFeatBatch {
 // Entry (row r, column c) of Q^T [J | res], Q = H0 H1 H2 = I - V T V^T, from the track's factor record: column c of [J | res]
 // has two non-zero entries x0, x1 in rows r0, r0 + 1 (the observation of c's pose), w = T^T V^T J[:, c]; r0 = -1: the residual
 // column (the entry is r'[r]), r0 = -2: a column the track does not touch.  (msckf_update.cpp:423-432)
-#define XK_HC_ROWS 68               // rows a record holds: 2 L <= 66 next to 64-row slots
-#define XK_HC_VR (4 * XK_HC_ROWS)   // doubles of its per-row part {v0, v1, v2, r'}; the per-column part follows,
+#define XK_HC_ROWS 68               // rows a record holds next to 64-row slots (2 L <= 66); DB + 4 in general (xk_hc_vr)
+#define XK_HC_VR (4 * XK_HC_ROWS)   // doubles of its per-row part {v0, v1, v2, r'} there; the per-column part follows,
 #define XK_HC_WC 6                  // doubles per column: {w0, w1, w2, x0, x1, r0}
-__device__ __forceinline__ int xk_hc_stride(int C1P) { return XK_HC_VR + XK_HC_WC * C1P; }
+static inline int xk_hc_vr(int DB) { return 4 * (DB + 4); }
+static inline int xk_hc_stride(int DB, int C1P) { return xk_hc_vr(DB) + XK_HC_WC * C1P; }
 __device__ __forceinline__ double xk_h0_entry(double w0, double w1, double w2, double x0, double x1, int r0, double v0, double v1, double v2,
                                               double rres, int r) {
   double v = -w0 * v0 - w1 * v1 - w2 * v2;
@@ -966,7 +968,7 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
           w2 = tau2 * (a2 - w0 * g02 - w1 * g12);
         }
       }
-      xk_d2 *wc = reinterpret_cast<xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * c);
+      xk_d2 *wc = reinterpret_cast<xk_d2 *>(rec + a.hcvr + XK_HC_WC * c);
       xk_d2 q0 = {w0, w1}, q1 = {w2, x0}, q2 = {x1, (double)r0};
       wc[0] = q0; wc[1] = q1; wc[2] = q2;
     }
@@ -1062,31 +1064,6 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature(XkFeatArgs a_in) {
   xk_msckf_feature_body<false>(a_in);
 }
-// The tiles of the tracks that passed, from their factor records -- for the multi-launch schedule when the single launch that
-// would have formed the entries itself gave up or was not taken (rare: the records are only written when it is expected to run).
-struct XkExpandArgs {
-  const double *Hc;
-  int hs;
-  double *A;
-  int DB, C1P;
-  const int *tile_rows;
-};
-__global__ __launch_bounds__(256) void xk_expand_records(XkExpandArgs a) {
-  const int k = blockIdx.x, d = a.tile_rows[k];
-  if (d <= 0) return;
-  const double *rec = a.Hc + (size_t)k * a.hs;
-  double *tile = a.A + (size_t)k * a.DB * a.C1P;
-  for (int c = threadIdx.x; c < a.C1P; c += 256) {
-    const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * c);
-    const xk_d2 q0 = wc[0], q1 = wc[1], q2 = wc[2];
-    const int r0 = (int)q2[1];
-    for (int r = 3; r < d + 3; ++r) {
-      const xk_d2 va = reinterpret_cast<const xk_d2 *>(rec + 4 * r)[0], vb = reinterpret_cast<const xk_d2 *>(rec + 4 * r)[1];
-      tile[(size_t)(r - 3) * a.C1P + c] = xk_h0_entry(q0[0], q0[1], q1[0], q1[1], q2[0], r0, va[0], va[1], vb[0], vb[1], r);
-    }
-  }
-}
-
 // windows of 34..64 poses: the gate matrix as a packed triangle (two workgroups per CU instead of one)
 __global__ __launch_bounds__(XK_FEAT_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void xk_msckf_feature_packed(XkFeatArgs a_in) {
   xk_msckf_feature_body<true>(a_in);

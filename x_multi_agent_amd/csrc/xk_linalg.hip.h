@@ -708,6 +708,10 @@ struct XkCaqrArgs {
   int wt;                 // experiment: write-through (sc1) stores for the rows a launch hands to the next one
   int lead_stride;        // tile kernel: tiles t % lead_stride == 0 receive merged rows (first-level group leaders); the other
                           // tiles of rejected tracks stay all-zero and are skipped (0 = skip nothing)
+  // panel 0 only: tiles [0, nhc) do not exist yet -- the per-feature kernel left the FACTOR RECORDS of their tracks instead
+  // (xk_feature.hip.h: XkFeatArgs::Hc; hs doubles per record, the first hcvr of them per row) and the first pass forms its rows
+  const double *Hc;
+  int hs, hcvr, nhc;
 };
 
 __device__ __forceinline__ void xk_store_wt(double *p, double v, int wt) {
@@ -907,12 +911,32 @@ __device__ __forceinline__ void xk_caqr_tile_body(const XkCaqrArgs &a, int t, in
 #ifdef XK_CAQR_PROBE
   const long long t0 = clock64();
 #endif
+  if (a.c0 == 0 && t < a.nhc) {
+    // H0 never existed in HBM: the rows of this track from its factor record (xk_h0_entry, written without its selects as in
+    // xk_caqr_pipe.hip.h: r0 = -1 / -2 never meet a row, an untouched column is all zeros, + 0.0 last).  A tile is a track here, so
+    // the column part is read once per lane; rows past the track's are masked (the record holds nothing there).
+    const double *rec = a.Hc + (size_t)t * a.hs;
+    const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + a.hcvr + XK_HC_WC * min(col, a.C1P - 1));
+    const xk_d2 q0 = wc[0], q1 = wc[1], q2 = wc[2];
+    const int r0 = (int)q2[1], nvalid = a.tile_rows[t] - part * RPL, rtop = a.hcvr / 4 - 1;
+    const double nw0 = -q0[0], nw1 = -q0[1], nw2 = -q1[0], x0 = q1[1], x1 = q2[0], wres = (r0 == -1) ? 1.0 : 0.0;
 #pragma unroll
-  for (int r = 0; r < RPL; ++r) b[r] = (mine && r < rlim && r >= rlo) ? rowp[(size_t)r * a.C1P] : 0.0;
-  if (a.c0 == 0) {
-    const int nvalid = a.tile_rows[t] - part * RPL;
+    for (int r = 0; r < RPL; ++r) {
+      const int rr = prow + r + 3, dd = rr - r0;
+      const xk_d2 *vr = reinterpret_cast<const xk_d2 *>(rec + 4 * min(rr, rtop));
+      const xk_d2 va = vr[0], vb = vr[1];
+      const double add = (dd == 0) ? x0 : ((dd == 1) ? x1 : 0.0);
+      const double v = fma(wres, vb[1], fma(nw2, vb[0], fma(nw1, va[1], nw0 * va[0]))) + add;
+      b[r] = (mine && r < nvalid) ? v : 0.0;
+    }
+  } else {
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) b[r] = (r < nvalid) ? b[r] : 0.0;
+    for (int r = 0; r < RPL; ++r) b[r] = (mine && r < rlim && r >= rlo) ? rowp[(size_t)r * a.C1P] : 0.0;
+    if (a.c0 == 0) {
+      const int nvalid = a.tile_rows[t] - part * RPL;
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) b[r] = (r < nvalid) ? b[r] : 0.0;
+    }
   }
 #ifdef XK_CAQR_PROBE
   double sink = 0; for (int r = 0; r < RPL; ++r) sink += b[r];
