@@ -15,7 +15,8 @@
  * launch -- it gives up, the host redoes the update), "caqr_test_stall" (1: one workgroup of the single launch never shows up),
  * "caqr_tall26", "pipe_kalman", "pipe_split" (0: 184 tiles always, 1: the adaptive default, 2: 152 tiles when the nominal rows fit,
  * 3: always), "caqr_hlite" (0: the per-feature kernel writes 64-row tiles of H0 as before round 5; 1, default: factor records for the
- * narrow single launch, csrc/xk_feature.hip.h XkFeatArgs::Hc).
+ * narrow single launch and the multi-launch schedule, csrc/xk_feature.hip.h XkFeatArgs::Hc; 2: for the wide single launch too -- measured
+ * slower, config 2: 1546 -> 1524 updates/s).
  */
 #ifndef XK_LAB_H_
 #define XK_LAB_H_

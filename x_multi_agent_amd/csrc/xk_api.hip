@@ -769,7 +769,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     // first pass of the multi-launch schedule (128-row slots: always; 64-row slots: when the single launch was armed and then
     // not taken or gave up).
     h->rows_compact = h->opt_hlite && h->d_Hc && !h->feat_dbg &&
-                      (h->DB == 128 || (h->opt_resident && h->persist_ok && h->C1 <= XkPipeNarrow::COLS));
+                      (h->DB == 128 || (h->opt_resident && h->persist_ok && (h->C1 <= XkPipeNarrow::COLS || h->opt_hlite >= 2)));   // (lab: 2 = the wide geometry too)
     a.Hc = h->rows_compact ? h->d_Hc : nullptr; a.hs = h->hc_stride; a.hcvr = xk_hc_vr(h->DB);
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
     a.gpf_in = nullptr; a.up_out = nullptr; a.batch = nullptr; a.dbg = h->feat_dbg;
