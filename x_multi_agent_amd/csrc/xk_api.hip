@@ -869,6 +869,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
   }
   // (d_R was zeroed at creation; the merges rewrite the whole upper trapezoid every update and nothing else)
   XkCaqrArgs a;
+  memset(&a, 0, sizeof(a));
   a.A = h->d_A; a.tile_rows = h->d_tile_rows; a.ntiles = ntiles; a.TS = h->DB;
   a.C1P = h->C1P; a.C1 = h->C1; a.Rout = h->d_R; a.dbg = nullptr;
   static const int wt_env = env_int("XK_CAQR_WT", 0);
