@@ -35,13 +35,15 @@ for it in range(n_cases):
     eng = engine.Engine(N, M, max(K, 1))
     got = eng.visual_update(sc)
     again = eng.visual_update(sc)      # same handle, second call: stale device state must not leak
-    eng.close()
+    third = eng.visual_update(sc)      # (the first single launch of a handle takes 184 tiles, the later ones may take 152: equal to
+    eng.close()                        #  rounding; from the second call on the posterior is the same bits)
     ok = (np.array_equal(got["inlier"], ref["inlier"]) and np.array_equal(got["inlier_slam"], ref["inlier_slam"]))
     rp = rel(got["P"], ref["P"]); rc = rel(got["correction"], ref["correction"]) if np.linalg.norm(ref["correction"]) > 0 else 0.0
     rr = rel(again["P"], got["P"])
+    r3 = rel(third["P"], again["P"])
     worst = max(worst, rp)
-    if not ok or rp > 1e-8 or rc > 1e-6 or rr != 0.0:
-        bad.append((N, K, M, kw, ok, rp, rc, rr))
+    if not ok or rp > 1e-8 or rc > 1e-6 or rr > 1e-11 or r3 != 0.0 or not np.array_equal(third["inlier"], ref["inlier"]):
+        bad.append((N, K, M, kw, ok, rp, rc, rr, r3))
         print("MISMATCH", bad[-1], flush=True)
 print(f"{n_cases} cases in {time.time() - t0:.0f} s: worst rel dP {worst:.2e}; mismatches {len(bad)}")
 sys.exit(1 if bad else 0)
