@@ -902,11 +902,11 @@ __device__ __forceinline__ void xk_msckf_feature_body(XkFeatArgs a_in) {
   }
   __syncthreads();
   // rank-6 update of the lower triangle (rows >= 3 are all the Cholesky reads)
-  for (int idx = tid; idx < m2 * m2; idx += XK_FEAT_THREADS) {
-    const int i = idx / m2, j = idx - i * m2;
-    if (j > i || i < 3) continue;
-    Mm[xk_gm<PACKED>(i, j, ldm)] -= V[i] * Zv[j] + Zv[i] * V[j] + V[m2 + i] * Zv[m2 + j] + Zv[m2 + i] * V[m2 + j] +
-                               V[2 * m2 + i] * Zv[2 * m2 + j] + Zv[2 * m2 + i] * V[2 * m2 + j];
+  // (four threads per row, each every fourth column up to the diagonal: no index division, the row's six factors read once)
+  for (int i = 3 + (tid >> 2); i < m2; i += XK_FEAT_THREADS / 4) {
+    const double vi0 = V[i], vi1 = V[m2 + i], vi2 = V[2 * m2 + i], zi0 = Zv[i], zi1 = Zv[m2 + i], zi2 = Zv[2 * m2 + i];
+    for (int j = tid & 3; j <= i; j += 4)
+      Mm[xk_gm<PACKED>(i, j, ldm)] -= vi0 * Zv[j] + zi0 * V[j] + vi1 * Zv[m2 + j] + zi1 * V[m2 + j] + vi2 * Zv[2 * m2 + j] + zi2 * V[2 * m2 + j];
   }
   __syncthreads();
   XK_STAMP(5);
