@@ -131,7 +131,9 @@ std::optional<State> Ekf::processImu(double timestamp, unsigned int seq, const V
     for (int k = 0; k < 225; ++k) deferred_q_.m[k] = fq.m[k] + q_d_[to].m[k];
     deferred_phi_ = mul15(f_d_[to], deferred_phi_);
     cov_target_ = to;
-  } else if (resident_ && next == cov_idx_ && !advanceDeviceCovariance((cov_idx_ + 1) % sz_ring)) {
+  } else if (resident_ && !update_in_flight_ && next == cov_idx_ && !advanceDeviceCovariance((cov_idx_ + 1) % sz_ring)) {
+    // (only with no update in flight: once an update has been invalidated, cov_slot is cov_target_ and cov_idx_ says nothing any
+    //  more -- advancing the device covariance from this thread would use the handle the update thread is inside of)
     throw std::runtime_error("Ekf: cannot advance the resident covariance past the slot the ring overwrites");
   }
   State &next_state = buffer_[next];

@@ -313,7 +313,9 @@ int xk_pr_knn_match(xk_pr *p, const unsigned char *query, int nq, const unsigned
  * the MULTI_UAV order (updater.cpp:84-97).  [T_H | z] does not depend on the covariance once the gates have read the prior (the
  * per-feature kernel, queued here), so where the single launch can take the Kalman update along (narrow systems, n <= 206) the
  * compression itself is queued by xk_apply_update, behind those entries, with the update inside: one launch there instead of one
- * here and five there.  xk_qr_compress / xk_fetch_flags behave as before. */
+ * here and five there.  xk_qr_compress / xk_fetch_flags behave as before: an xk_qr_compress between this call and xk_apply_update
+ * runs the compression then and there, and xk_apply_update applies the [T_H | z] it left (no second compression).  No STAGING call
+ * (xk_stage_*, xk_msckf_build) may come between the two: it would replace the rows the deferred compression is to read. */
 int xk_build_compress_async(xk_handle *h, double sigma_img);
 
 /* xk_build_compress_async with the Kalman update of Updater::applyUpdate(correction_total = 0, cov_update = true)

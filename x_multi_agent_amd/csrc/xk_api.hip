@@ -67,6 +67,7 @@ struct xk_handle {
   // The expectation is the acceptance ratio the last single launch reported (status word 2) applied to this update's nominal rows.
   int opt_split;           // 0 never, 1 adaptive (default); lab: 2 whenever the NOMINAL rows fit, 3 always
   double acc_ratio;        // accepted / nominal rows of the last single launch (0: none yet)
+  int pipe_tag;            // tag of the last single launch's accepted-rows word (status word 2)
   bool last_split;         // the last single launch used that geometry
   int split_backoff;       // updates for which it stays off after it found more rows than it holds
   int overflow_rows;       // a single launch of that many nominal rows found more accepted rows than its tiles hold: not tried again at that size
@@ -301,7 +302,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     h->opt_test_stall = env_int("XK_CAQR_TEST_STALL", 0);
     h->opt_tall26 = env_int("XK_CAQR_TALL26", 1);
     h->opt_kalman = env_int("XK_PIPE_KALMAN", 1);
-    h->opt_split = env_int("XK_PIPE_SPLIT", 1);
+    if (h->opt_split >= 0) h->opt_split = env_int("XK_PIPE_SPLIT", 1);   // (-1: the 152-tile kernel does not fit a CU on this device -- stays off)
     if (!h->fast_capable && h->DB == 64 && h->C1 <= XkPipeWide::COLS) {
       // Say so once, where an operator sees it: every update of this handle takes the multi-launch schedule (~1.6x slower).
       snprintf(h->err, sizeof(h->err), "single-launch CAQR unavailable on device %d: %s; the multi-launch schedule serves every update",
@@ -859,6 +860,10 @@ static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
 // correction_total = 0, covariance update, no external S), h->last_fused says so and the caller must NOT queue launch_update.
 static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateSpec *fuse = nullptr) {
   h->last_fused = false;
+  // A compression that xk_build_compress_async left for xk_apply_update is no longer pending once ANY compression runs (xk_apply_update
+  // takes the flag down before it comes here; an xk_qr_compress in between does the work now, and xk_apply_update then applies d_R as
+  // it stands instead of compressing rows the multi-launch schedule has already reduced in place).
+  h->compress_deferred = false;
   if (!h->have_rows) return fail(h, XK_EINVAL, "xk_msckf_build has not run on the staged inputs");
   const int slam_tiles = (2 * h->M + h->DB - 1) / h->DB;
   const int ntiles = h->K + h->K2 + slam_tiles;
@@ -953,6 +958,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
       pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
       pa.test_stall = h->opt_test_stall;
+      h->pipe_tag = (h->pipe_tag % 0x7fff) + 1;               // 1 .. 32767: tags the accepted-rows word of THIS launch (eval_status)
+      pa.acc_tag = h->pipe_tag;
       pa.kal = 0; pa.kn = h->n; pa.Pin = nullptr; pa.Pout = nullptr; pa.sigma2 = 0.0; pa.corr = nullptr; pa.ct = nullptr; pa.done_flag = nullptr; pa.done_seq = 0;
       if (fuse && narrow && h->opt_kalman && !fuse->S && !fuse->rdiag && fuse->T == h->d_R &&
           h->n <= 206 && h->n_cu == 256) {
@@ -1221,9 +1228,12 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
 
 #define XK_RETRY_CLASSIC 1000   // internal: the single-launch CAQR gave up, the multi-launch schedule must redo the update
 static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
-  if (h->last_pipe && h->pipe_rows_nominal > 0 && h->d_status[2] > 0) {   // what the last single launch found (status word 2)
-    h->acc_ratio = (double)h->d_status[2] / h->pipe_rows_nominal;
-    h->d_status[2] = 0;
+  // What the last single launch found (status word 2): accepted rows in the low 15 bits, the launch's tag above them.  The word is a
+  // relaxed system-scope store of a tile workgroup, not ordered with the completion marker (another workgroup's store): a count that
+  // carries another launch's tag is a late arrival and is left alone -- it must not be divided by THIS launch's nominal rows.
+  if (h->last_pipe && h->pipe_rows_nominal > 0) {
+    const int w2 = h->d_status[2];
+    if (w2 > 0 && (w2 >> 15) == h->pipe_tag) h->acc_ratio = (double)(w2 & 0x7fff) / h->pipe_rows_nominal;
   }
   if (st != 0 || pst != 0) {
     hipStreamSynchronize(h->stream);
@@ -2189,6 +2199,7 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   // running into workspace and pinned words the next call reuses.
   for (int j = 0; j < n_tracks; ++j) {
     const int st = self_track[j];
+    if (st < 0 || st >= h->K) return fail(h, XK_EINVAL, "shared track index outside the staged tracks");
     int Ltot = h->h_trk_off[st + 1] - h->h_trk_off[st];
     for (int r = 0; r < world; ++r) {
       if (r == self_rank) continue;

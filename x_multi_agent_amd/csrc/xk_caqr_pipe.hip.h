@@ -162,6 +162,7 @@ struct XkCaqrPipeArgs {
   int *status;
   long long *dbg;
   int test_stall;         // test hook: one tile workgroup leaves at once -- everybody else runs into the bound of their spins
+  int acc_tag;            // 1 .. 32767: written above the accepted-rows count in status word 2, so that the host can tell a late word of the launch before
   // Kalman role (xk_pipe_kalman; narrow geometry): Updater::applyUpdate (updater.cpp:117-141, cov_update)
   // inside this launch.  kal = 0: the compressed [T_H | z] is all the launch leaves behind.
   int kal, kn;            // on / off, n = error states
@@ -1544,7 +1545,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
     int rows_acc;
     const int TR = xk_pipe_rowplan<G>(a, (int)xcc * NT + slot, rp_pre, rp_rows, &rows_acc);
     // how many rows passed the gates: the host picks the next launch's geometry by it (status word 2, pinned host memory)
-    if (xcc == 0 && slot == 0 && threadIdx.x == 0) __hip_atomic_store(a.status + 2, rows_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (xcc == 0 && slot == 0 && threadIdx.x == 0) __hip_atomic_store(a.status + 2, (a.acc_tag << 15) | min(rows_acc, 0x7fff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int nvalid = min(max(rows_acc - ((int)xcc * NT + slot) * TR, 0), TR);   // rows of my tile that exist
     if (TR == 0) {                                         // more accepted rows than the tiles hold: everybody learns it from the abort word
       if (threadIdx.x == 0) { __hip_atomic_store(ab, 9u, XK_RLX_AGENT); a.status[1] = 9; }
