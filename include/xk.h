@@ -371,7 +371,8 @@ int xk_bench_staged(xk_handle *h, double sigma_img, int warmup, int steps, xk_ti
 int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 
 /* Which schedule compressed the last update -- 0 the multi-launch CAQR, 2 the pipelined single launch (1 was round 2's
- * register-resident kernel, no longer built) -- whether the single-launch path is armed for the next update, how many launches have given up on
+ * register-resident kernel, no longer built), 3 the multi-launch CAQR for the first panels of a tall system (windows of 34..64
+ * poses) and ONE single launch for its last <= 96 columns -- whether the single-launch path is armed for the next update, how many launches have given up on
  * this handle so far (workgroups not co-resident: another process on the GPU, a CU mask) and the reason code of the last one
  * (2 XCD-local hand-off, 3 uneven XCD placement, 4 / 5 / 6 waiting for the last level / the roots / the tiles, 8 the Kalman role
  * waiting for rows of R, 9 more rows passed the gates than the tiles of the launch hold -- not a co-residency problem: the fast
@@ -383,7 +384,8 @@ int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, 
 
 /* Operational switches of the compression on a live handle.  "caqr_resident": 0 = the multi-launch schedule serves every update
  * (e.g. a GPU this process knowingly shares), 1 (default) = the single launch where the shape allows it; "caqr_rearm": clean
- * multi-launch updates after which a single-launch path that gave up is tried again (default 64, doubling at every further give-up).
+ * multi-launch updates after which a single-launch path that gave up is tried again (default 64, doubling at every further give-up);
+ * "caqr_tail": 0 = tall systems are factored by the multi-launch schedule to the last panel, 1 (default) = their last columns by one launch.
  * Unknown name: XK_EINVAL.  The release library reads nothing from the environment; the experiment switches, test hooks, debug
  * exports and probe kernels of the lab build are declared in xk_lab.h.  No counterpart in the reference. */
 int xk_set_option(xk_handle *h, const char *name, int value);

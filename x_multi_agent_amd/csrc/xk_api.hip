@@ -73,6 +73,13 @@ struct xk_handle {
   int overflow_rows;       // a single launch of that many nominal rows found more accepted rows than its tiles hold: not tried again at that size
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
   bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
+  // Tall systems (128-row slots: windows of 34..64 poses, BASELINE config 3): the multi-launch schedule factors the first panels,
+  // ONE launch of xk_caqr_pipe<XkPipeTail> the last <= 96 columns with every row in registers (round 6)
+  bool tail_capable;    // decided at xk_create: 128-row slots, 256 CUs, the kernel fits a CU
+  bool tail_ok;         // armed (cleared when a tail launch gave up; re-armed like the fast path)
+  bool last_tail;       // the last launch_compress ended in such a launch
+  int tail_clean, tail_backoff, opt_tail;   // opt_tail: 0 off, 1 (default) the plan that fits (192 columns in one or two launches, else 96 in one), 2 the 96-column launch only
+  bool tail_four;       // the plan of this compression uses the 4-lanes-per-column geometry (<= 192 columns)
   long long *d_pdbg;
   long long *feat_dbg;  // probe builds only: per-workgroup phase stamps of xk_msckf_feature
   bool attr_slaminit, attr_feat_batch;   // hipFuncSetAttribute done for this handle's device
@@ -259,7 +266,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, dalloc(&h->d_chi90, (size_t)XK_CHI2_LEN));
   HIPCHK(h, hipMemcpy(h->d_chi95, XK_CHI2_095, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->d_chi90, XK_CHI2_090, sizeof(double) * XK_CHI2_LEN, hipMemcpyHostToDevice));
-  HIPCHK(h, dalloc(&h->d_A, (size_t)h->ntiles_max * h->DB * h->C1P));
+  // (+ 256 rows behind the slots: where the first of two tail launches leaves its R for the second one, XkCaqrPipeArgs::extra_row0 --
+  //  zero outside the trapezoid the launch writes, like d_R)
+  HIPCHK(h, dalloc(&h->d_A, ((size_t)h->ntiles_max * h->DB + 256) * h->C1P));
+  HIPCHK(h, hipMemset(h->d_A + (size_t)h->ntiles_max * h->DB * h->C1P, 0, sizeof(double) * 256 * h->C1P));
   h->hc_stride = xk_hc_stride(h->DB, h->C1P);
   h->opt_hlite = env_int("XK_HLITE", 1);
   h->rows_compact = false;
@@ -296,6 +306,16 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       (void)hipGetLastError();
     }
     h->fast_capable = h->persist_ok;
+    h->tail_capable = h->DB == 128 && h->n_cu == 256 && h->C1 > 32;
+    if (h->tail_capable) {
+      int nbt = 0, nbt4 = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbt, (const void *)xk_caqr_pipe<XkPipeTail>, XK_PIPE_THREADS, 0) != hipSuccess) nbt = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbt4, (const void *)xk_caqr_pipe<XkPipeTail4>, XK_PIPE_THREADS, 0) != hipSuccess) nbt4 = 0;
+      h->tail_capable = nbt >= 1 && nbt4 >= 1;
+      (void)hipGetLastError();
+    }
+    h->tail_ok = h->tail_capable;
+    h->opt_tail = env_int("XK_CAQR_TAIL", 1);
     h->rearm_after = env_int("XK_CAQR_REARM", 64);
     h->opt_resident = env_int("XK_CAQR_RESIDENT", 1);
     h->opt_poison = env_int("XK_CAQR_RESIDENT_POISON", 0);
@@ -311,10 +331,11 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
       static const int quiet = env_int("XK_QUIET", 0);
       if (!quiet) fprintf(stderr, "xk: %s (n_cu = %d)\n", h->err, h->n_cu);
     }
-    if (h->persist_ok) {
+    if (h->persist_ok || h->tail_capable) {
       // cross-XCD slabs of the single launch, TWO sets (a launch works on one and re-arms the other for its successor with the
       // NOT-YET pattern of the data-polled hand-offs, xk_xcd_sync.hip.h): per set X1 | X2 ([panels][16 strips][16 x C1P]) | X1P
-      const size_t np = (size_t)(h->C1 + 15) / 16, strips = np * XK_PIPE_RLS;
+      // (the tail launch of a tall system runs the last XkPipeTail::COLS / 16 panels only)
+      const size_t np = h->persist_ok ? (size_t)(h->C1 + 15) / 16 : (size_t)XkPipeTail4::COLS / 16, strips = np * XK_PIPE_RLS;
       h->xslab_doubles = strips * 16 * h->C1P * 2 + strips * 256;
       HIPCHK(h, dalloc(&h->d_x1, 2 * h->xslab_doubles));
       HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)h->d_x1, (int)(XK_NOTYET_BITS & 0xffffffffu), 2 * 2 * h->xslab_doubles, h->stream));
@@ -858,8 +879,57 @@ static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
 // QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
 // fuse: (optional) the Kalman update that follows this compression.  If the single launch takes it along (narrow geometry,
 // correction_total = 0, covariance update, no external S), h->last_fused says so and the caller must NOT queue launch_update.
+// The last columns [ccut, C1) of a tall system in ONE launch or TWO (xk_caqr_pipe<XkPipeTail> / <XkPipeTail4>): the rows of slots
+// [slot0, slot0 + nslots) -- as the multi-launch schedule left them after the panels before ccut: R's rows zeroed where they were
+// taken out, the leaders' first 32 rows holding merged rows -- plus `nextra` rows from behind the slots (the R of the launch before)
+// are gathered into registers once, the panels run as in the single launch of the narrow systems, and rows ccut.. of R go to Rout
+// (row stride C1P, column ccut at Rout[0]).
+static int launch_pipe_tail(xk_handle *h, bool four, int ccut, int slot0, int nslots, int arity1, int nextra, double *Rout) {
+  XkCaqrPipeArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.A = h->d_A + (size_t)slot0 * h->DB * h->C1P + ccut; pa.tile_rows = h->d_tile_rows + slot0; pa.nslots = nslots; pa.slot_rows = h->DB;
+  pa.lead_stride = arity1;                        // (slot0 is a multiple of it)
+  pa.nextra = nextra; pa.extra_row0 = (long)(h->ntiles_max - slot0) * h->DB;
+  pa.Hc = nullptr; pa.hs = 0; pa.nhc = 0;
+  pa.C1P = h->C1P; pa.C1 = h->C1 - ccut; pa.Rout = Rout; pa.S = h->d_rs; pa.PB = h->d_rpb;
+  pa.status = h->d_status;
+  if (h->xsync_dirty) {
+    if (hipMemsetAsync(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
+    if (hipMemsetD32Async((hipDeviceptr_t)h->d_x1, (int)(XK_NOTYET_BITS & 0xffffffffu), 2 * 2 * h->xslab_doubles, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "slabs");
+    h->xsync_dirty = false; h->xsync_phase = 0;
+  }
+  {
+    const size_t np_ = (size_t)(pa.C1 + 15) / 16, strips_ = np_ * XK_PIPE_RLS, x1n = strips_ * 16 * h->C1P;
+    double *set = h->d_x1 + (size_t)h->xsync_phase * h->xslab_doubles;
+    pa.X1 = set; pa.X2 = set + x1n; pa.X1P = set + 2 * x1n;
+    pa.Xnext = h->d_x1 + (size_t)(h->xsync_phase ^ 1) * h->xslab_doubles;
+    pa.xnext_doubles = (long)h->xslab_doubles;
+  }
+  pa.sync = h->d_xsync + (size_t)h->xsync_phase * XP_WORDS * 16;
+  pa.sync_next = h->d_xsync + (size_t)(h->xsync_phase ^ 1) * XP_WORDS * 16;
+  h->xsync_phase ^= 1;
+  if (h->opt_poison) {   // test hook, as in the single launch of the narrow systems: every workgroup gives up at its first spin
+    const unsigned seven = 7u;
+    if (hipMemcpyAsync(pa.sync + XP_ABORT * 16, &seven, sizeof(unsigned), hipMemcpyHostToDevice, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "poison");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "poison");
+  }
+  static const int pdbg2 = env_int("XK_CAQR_PERSIST_DBG", 0);
+  pa.dbg = pdbg2 ? h->d_pdbg : nullptr;
+  pa.test_stall = h->opt_test_stall;
+  h->pipe_tag = (h->pipe_tag % 0x7fff) + 1;
+  pa.acc_tag = h->pipe_tag;
+  h->pipe_rows_nominal = 0;                       // (the acceptance ratio belongs to the narrow geometries)
+  if (four) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeTail4>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+  else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeTail>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+  h->last_tail = true;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr tail launch", e);
+  return XK_OK;
+}
+
 static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateSpec *fuse = nullptr) {
   h->last_fused = false;
+  h->last_tail = false;
   // A compression that xk_build_compress_async left for xk_apply_update is no longer pending once ANY compression runs (xk_apply_update
   // takes the flag down before it comes here; an xk_qr_compress in between does the work now, and xk_apply_update then applies d_R as
   // it stands instead of compressing rows the multi-launch schedule has already reduced in place).
@@ -1010,6 +1080,43 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(xk_caqr_tile<32, true>), tgrid, tblock, 0, h->stream, t);
     }
   };
+  // Tall systems: the LAST columns in one launch with every row in registers (xk_caqr_pipe<XkPipeTail>, xk_caqr_pipe.hip.h).  ccut =
+  // first column the tail takes (a panel boundary; 0: no tail).  Like the single launch of the narrow systems it is queued on the
+  // nominal row count up to 5/4 of its capacity -- the launch counts the rows that passed the gates itself and gives up at once
+  // (reason 9) when they do not fit -- and only reads the stack: a tail that gives up is redone from the rows as they stand.
+  int ccut = 0, tail_half = 0;                    // tail_half > 0: two launches, slots [0, tail_half) then [tail_half, ntiles) + the first one's R
+  if (h->tail_capable && !h->tail_ok && h->opt_resident && h->opt_tail && h->rearm_after > 0 && h->tail_backoff == 0 && ++h->tail_clean > h->rearm_after) {
+    h->tail_ok = true;
+    h->tail_clean = 0;
+  }
+  if (h->tail_backoff > 0) --h->tail_backoff;
+  else if (overlap && h->tail_ok && h->opt_resident && h->opt_tail && ntiles <= XK_PIPE_SLOTS_MAX && h->K2 == 0 && h->M == 0) {
+    // nominal rows (every track accepted) of the slots before each group boundary; a leader's first 32 rows count whatever its track's length
+    std::vector<long> pre((size_t)groups1 + 1, 0);
+    for (int g = 0; g < groups1; ++g) {
+      long r = 0;
+      for (int t = g * arity1; t < std::min(ntiles, (g + 1) * arity1); ++t) {
+        const int v = 2 * (h->h_trk_off[t + 1] - h->h_trk_off[t]) - 3;
+        r += (t % arity1 == 0) ? std::max(v, 32) : v;
+      }
+      pre[g + 1] = pre[g] + r;
+    }
+    const long R_nom = pre[groups1];
+    if (R_nom >= 64 * 8) {
+    const int cc4 = 16 * std::max(1, (h->C1 - XkPipeTail4::COLS + 15) / 16), cc8 = 16 * ((h->C1 - XkPipeTail::COLS + 15) / 16);
+    const int nx = h->C1 - cc4;                   // rows of the first launch's R
+    int gh = 0;                                   // groups in the first half: the boundary that balances first half against second half + R
+    for (int g = 1; g < groups1; ++g)
+      if (std::labs(2 * pre[g] - R_nom - nx) < std::labs(2 * pre[gh] - R_nom - nx) || gh == 0) gh = g;
+    const long capq = (long)XkPipeTail4::ROWS * 5 / 4;
+    h->tail_four = false;
+    if (h->opt_tail != 2 && R_nom * 4 <= (long)XkPipeTail4::ROWS * 5) { ccut = cc4; tail_half = 0; h->tail_four = true; }   // (the whole stack fits one 192-column launch)
+    else if (h->opt_tail != 2 && gh > 0 && pre[gh] <= capq && R_nom - pre[gh] + nx <= capq) { ccut = cc4; tail_half = gh * arity1; h->tail_four = true; }
+    else if (cc8 >= 16 && R_nom * 4 <= (long)XkPipeTail::ROWS * 5) { ccut = cc8; tail_half = 0; }
+    if (ccut >= h->C1) ccut = 0;
+    }
+  }
+  h->last_tail = false;
   if (overlap) {
     a.rows_max = std::max(a.rows_max, 32);        // a leader's pivot strip alternates between rows 0..15 and 16..31
     for (int c0 = 0, k = 0; c0 < h->C1; c0 += 16, ++k) {
@@ -1051,6 +1158,21 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       XkCaqrArgs l = a;                            // last level: the leaders' pivot strips -> 16 rows of R
       l.c0 = c0; l.stride = arity1; l.final_level = 1; l.pin = h->d_panel[1]; l.pout = h->d_panel[0]; l.chalf = lchalf;
       l.lead_off = lead_off; l.lead_all = 1; l.pend = 0;
+      if (ccut > 0 && c0 + 16 == ccut) {
+        // the last panel of the multi-launch part: its last level alone, then the tail launch takes the stack as it stands
+        launch_merge<20>(h, l, 1, lsplit);
+        ++launches;
+        int rct;
+        if (tail_half > 0) {
+          double *Ra = h->d_A + (size_t)h->ntiles_max * h->DB * h->C1P + ccut;           // the first launch's R: behind the slots
+          rct = launch_pipe_tail(h, true, ccut, 0, tail_half, arity1, 0, Ra);
+          if (rct == XK_OK) rct = launch_pipe_tail(h, true, ccut, tail_half, ntiles - tail_half, arity1, h->C1 - ccut, h->d_R + (size_t)ccut * h->C1P + ccut);
+          ++launches;
+        } else rct = launch_pipe_tail(h, h->tail_four, ccut, 0, ntiles, arity1, 0, h->d_R + (size_t)ccut * h->C1P + ccut);
+        if (rct != XK_OK) return rct;
+        ++launches;
+        break;
+      }
       if (c0 + 16 < h->C1) {
         XkCaqrArgs t = a;                          // ... next to the tile step of the next panel
         t.c0 = c0 + 16; t.stride = 1; t.final_level = 0; t.pin = nullptr; t.pout = h->d_panel[0];
@@ -1102,7 +1224,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
   h->nleaf = ntiles;
   h->nlevels = launches;
   h->have_R = true;
-  h->last_resident = false; h->last_pipe = false;
+  h->last_resident = false; h->last_pipe = h->last_tail;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, XK_EDEVICE, "caqr launch", e);
   return XK_OK;
@@ -1244,6 +1366,17 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
     // The fast path steps aside, but not for the life of the handle: after `rearm_after` clean multi-launch updates it is
     // tried again (the other tenant of the GPU may be gone); every further give-up doubles that distance, so a permanently
     // shared GPU costs one bounded retry (<= 2 ms, xk_spin_ge) every few thousand updates at most.
+    if (h->last_tail) {
+      // the tail launch of a tall system gave up: it only READ the stack, but the retry below rebuilds the rows anyway (one code path);
+      // reason 9 = more rows passed the gates than its tiles hold -- off for the next 64 updates; anything else = co-residency
+      if (pst == 9) h->tail_backoff = 64;
+      else { h->tail_ok = false; h->tail_clean = -1; if (h->fast_giveups >= 1) h->rearm_after = std::min(4096, std::max(1, h->rearm_after) * 2); }
+      h->fast_giveups++; h->fast_reason = pst;
+      h->xsync_dirty = true;
+      h->have_rows = h->have_R = false;
+      snprintf(h->err, sizeof(h->err), "single-launch CAQR tail gave up (reason %d); the multi-launch schedule finishes the factorisation", pst);
+      return allow_retry ? XK_RETRY_CLASSIC : XK_EDEVICE;
+    }
     if (pst == 9 && h->last_split) {
       // the 152-tile geometry was chosen on the LAST update's acceptance ratio and this update passed more: not a co-residency
       // problem and not a capacity cliff of the fast path -- the 184-tile launch redoes the update, the split geometry stays off
@@ -2509,6 +2642,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
   // operational switches of the release library: the schedule of the compression and how soon a fast path that gave up is retried
   if (!strcmp(name, "caqr_resident")) h->opt_resident = value;
   else if (!strcmp(name, "caqr_rearm")) h->rearm_after = value;
+  else if (!strcmp(name, "caqr_tail")) h->opt_tail = value;
 #ifdef XK_LAB
   // test hooks and A/B switches (include/xk_lab.h)
   else if (!strcmp(name, "caqr_poison")) h->opt_poison = value;
@@ -2524,8 +2658,8 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
 
 extern "C" int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason) {
   if (!h) return XK_EINVAL;
-  if (schedule) *schedule = !h->last_resident ? 0 : (h->last_pipe ? 2 : 1);
-  if (armed) *armed = h->persist_ok ? 1 : 0;
+  if (schedule) *schedule = h->last_tail ? 3 : (!h->last_resident ? 0 : (h->last_pipe ? 2 : 1));
+  if (armed) *armed = (h->persist_ok || h->tail_ok) ? 1 : 0;
   if (giveups) *giveups = h->fast_giveups;
   if (last_reason) *last_reason = h->fast_reason;
   return XK_OK;

@@ -73,9 +73,26 @@ using XkPipeNarrow2 = XkPipeGeom<XK_PIPE_NARROW2>;         // the same columns, 
 #define XK_PIPE_WIDE 2, 40, 19, 12, 2, 1, 32, 28, 1, 4
 #endif
 using XkPipeWide = XkPipeGeom<XK_PIPE_WIDE>;               // C1 <= 384 (SLAM features, BASELINE config 2): 152 tiles of 80 rows
+// TAIL geometry (round 6): the LAST <= 96 columns of a system whose stack does not fit the register files at its full width
+// (BASELINE config 3: 62 565 rows x 301 columns).  The multi-launch schedule sweeps the stack in HBM once per panel whatever the
+// panel's width; once the columns still to be factored are few enough that ALL rows fit the registers at 8 lanes per column
+// (184 fat tiles of 8 x 44 = 352 rows: 64 768 rows x 96 columns), one launch of this kernel finishes the factorisation: the rows are
+// read once more and never written back (the launch only reads the stack, so a launch that gives up is redone by the schedule it
+// took over from, on the same rows).  No Kalman role: these systems have n > 206.
+// The same at 4 lanes per column: <= 192 columns, 32 384 rows a launch -- for stacks of up to twice that, TWO launches in a row, the
+// second taking the first one's R (its <= 192 rows, XkCaqrPipeArgs::nextra) on top of the other half of the stack: a flat TSQR tree at
+// launch granularity.  Two passes of ~26 us a panel beat the multi-launch schedule's 80..130 us a panel.
+#ifndef XK_PIPE_TAIL
+#define XK_PIPE_TAIL 8, 44, 23, 8, 1, 1, 44, 44, 1, 4
+#endif
+using XkPipeTail = XkPipeGeom<XK_PIPE_TAIL>;
+#ifndef XK_PIPE_TAIL4
+#define XK_PIPE_TAIL4 4, 44, 23, 8, 1, 1, 44, 44, 1, 4
+#endif
+using XkPipeTail4 = XkPipeGeom<XK_PIPE_TAIL4>;
 #define XK_PIPE_RLS 16              // strips per panel of the cross-XCD slabs X1 / X1P / X2, whatever the geometry uses of them
 #define XK_PIPE_NT_MAX 23
-#define XK_PIPE_ROWS_MAX 24320
+#define XK_PIPE_ROWS_MAX 24320      // (of the geometries that take their rows from 64-row slots)
 #define XK_PIPE_SLOTS_MAX 1536      // 64-row slots (tracks + packed SLAM rows) a launch can compact
 // Phase boundaries: phase q = reflector steps / strip rows [xk_pbn<NPH>(q), xk_pbn<NPH>(q + 1)); equal phases unless NPH = 4 and XK_PIPE_PB says
 // otherwise.  (Measured, round 4: a short first phase -- the level above starts when the level below has published its first
@@ -150,6 +167,11 @@ struct XkCaqrPipeArgs {
   int hs, nhc;            // nhc = 0: every slot is a tile in A
   const int *tile_rows;   // valid rows per 64-row slot (0 = rejected track), [nslots]: the stack is COMPACTED on the device --
   int nslots;             // fat tile j takes rows [j TR, (j + 1) TR) of the rows that passed the gates, TR = ceil(rows / tiles)
+  int slot_rows;          // rows of a slot of A (64; 128 next to the multi-launch schedule's tall slots: the tail geometry)
+  int lead_stride;        // > 0 (tail geometry): slots t % lead_stride == 0 led a merge group of the multi-launch schedule -- their first 32
+                          // rows hold merged rows whatever their track's own row count was (xk_caqr_merge_body: pivot strip + hole)
+  int nextra;             // tail geometry, second launch of two: rows [extra_row0, extra_row0 + nextra) of A (row stride C1P) -- the R the first
+  long extra_row0;        // launch left -- join the stack behind the slots' rows
   int C1P, C1;
   double *Rout;           // [C1P][C1P] row-major
   double *S;              // [8 NT][16 x C1P] pivot strips, block layout (xk_blk), XCD-local
@@ -497,6 +519,7 @@ __device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, i
   for (int base = 0; base < a.nslots; base += XK_PIPE_THREADS) {
     const int t = base + tid;
     int v = t < a.nslots ? a.tile_rows[t] : 0;
+    if (a.lead_stride > 0 && t < a.nslots && t % a.lead_stride == 0) v = max(v, 32);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {                    // inclusive scan inside the wave
       const int u = __shfl_up(v, o, 64);
@@ -513,20 +536,21 @@ __device__ __forceinline__ int xk_pipe_rowplan(const XkCaqrPipeArgs &a, int j, i
     __syncthreads();
   }
   if (tid == 0) pre[0] = 0;
-  const int R = carry, TR = (R + NTP - 1) / NTP;
+  const int Rs = carry, R = Rs + a.nextra, TR = (R + NTP - 1) / NTP;
   *rows_accepted = R;
   __syncthreads();
   if (TR > CAP) return 0;
   if (tid < CAP) {
     const int g = j * TR + tid;
     int phys = -1;
-    if (tid < TR && g < R) {
+    if (tid < TR && g >= Rs && g < R) phys = (int)a.extra_row0 + (g - Rs);
+    else if (tid < TR && g < Rs) {
       int lo = 0, hi = a.nslots;                           // largest slot with pre[slot] <= g
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (pre[mid] <= g) lo = mid; else hi = mid;
       }
-      phys = lo * 64 + (g - pre[lo]);
+      phys = lo * a.slot_rows + (g - pre[lo]);
     }
     myrows[tid] = phys;
   }
@@ -1490,7 +1514,7 @@ __global__ __launch_bounds__(XK_PIPE_THREADS) void xk_caqr_pipe(XkCaqrPipeArgs a
   __shared__ int rp_pre[XK_PIPE_SLOTS_MAX + 1], rp_rows[LPC * RPL];   // tile workgroups: prefix sums of the accepted rows, my rows
   // landing area of the first level's load-to-LDS prefetch: per wave (4 columns) 24 strips x 4 rows x 4 columns
   __shared__ __attribute__((aligned(16))) double pfbuf[XK_PIPE_PF ? (XK_PIPE_THREADS / 64) * 24 * 16 : 2];
-  constexpr bool KAL = G::COLS <= 192;                     // the Kalman role keeps [P | d] in registers: n <= 206
+  constexpr bool KAL = G::COLS <= 192 && G::LPC == 4 && G::RPL <= 40;   // the Kalman role keeps [P | d] in registers: n <= 206 (not the tail geometries)
   __shared__ __attribute__((aligned(16))) double kbuf[KAL ? XK_KAL_LDS : 2];
   // tile workgroups: landing area of the factor records their rows are formed from (the Kalman role's LDS where there is one)
   constexpr int HB_OWN = KAL ? 2 : 16 * 1024;
