@@ -243,7 +243,7 @@ def cpu_baseline(sc, budget_s=20.0):
 NOMINAL_KW = dict(err_scale=0.3, outlier_frac=0.0)   # the headline shape with (nearly) every track passing the gate: see nominal_rows()
 
 
-def nominal_rows(engine, synth, cfg, dev, steps, with_cpu=True):
+def nominal_rows(engine, synth, cfg, dev, steps, with_cpu=True, with_frame_loop=True):
     """The headline at NOMINAL work.  The default scenario plants 5 % outliers and draws the window error
     from the prior at full size; the gate's covariance is built from observability-constrained Jacobians that do not model all of
     that error, so only ~82 % of the tracks pass and 18 639 of the nominal 22 800 rows are stacked.  Here: the same shape, window
@@ -291,6 +291,15 @@ def nominal_rows(engine, synth, cfg, dev, steps, with_cpu=True):
                                "sample": "median of 3 updates after 1 warm-up, oracle/xk_oracle.c (prebuilt flags), same inputs"}
         out["speedup_vs_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
     eng.close()
+    if with_frame_loop:
+        try:                                  # whole frames through the C++ mirror on the same (nominal-rows) scenario
+            fl = frame_loop(sc, frames=400)
+            if fl and "ms_per_frame" in fl:
+                fl["ratio_to_replay"] = fl["ms_per_frame"] / out["ms_per_step"]
+                fl.pop("what", None)
+            out["frame_loop"] = fl
+        except Exception as ex:
+            out["frame_loop"] = {"error": repr(ex)[:200]}
     return out
 
 
@@ -696,7 +705,12 @@ def main():
         nominal = None
         if world == 1 and args.config in (4, 5) and not args.no_other_configs:
             try:
-                nominal = nominal_rows(engine, synth, args.config, dev, max(100, min(args.steps, 1000)), with_cpu=not args.no_cpu)
+                nominal = nominal_rows(engine, synth, args.config, dev, max(100, min(args.steps, 1000)), with_cpu=not args.no_cpu,
+                                       with_frame_loop=not args.no_frame_loop)
+                # (the nominal-rows scenario is the one to read against BASELINE.md's F_alg = 2.008 GFLOP)
+                roof["frac_at_nominal_rows"] = nominal.get("roofline_frac_dominant_launch")
+                roof["achieved_at_nominal_rows"] = (nominal["roofline_frac_dominant_launch"] * FP64_PEAK_TFLOPS
+                                                    if nominal.get("roofline_frac_dominant_launch") is not None else None)
             except Exception as ex:      # an extra must not take the headline line down
                 nominal = {"error": repr(ex)[:300]}
         cpu = None

@@ -11,8 +11,13 @@
 // pose (stationary IMU), so that manage() slides it into exactly the window the tracks were generated for; the covariance
 // is brought back by a device-side copy (xk_snapshot_P), not an upload.
 //   in : N K frames imu_per_frame mode sigma_img | q[4N] p[3N] | L_k[K] | obs[2*sum L] | P[n*n]
+//        optionally behind it (round 6: a tracker whose outlier rate MOVES from frame to frame -- the acceptance ratio the handle picks
+//        the single launch's geometry by): nsets | obs[nsets][2*sum L] | set_of_frame[frames]  (set 0 = the obs above)
 //   out: P_post[n*n] (tail covariance after the last frame) | p_array[3N] q_array[4N] | core16 | ms_per_frame[frames]
+//        with measurement sets: | per frame {set, inliers, give-ups so far, schedule of the compression, rel ||P - P_first(set)||_F}
+//                               | P_first[nsets + 1][n*n] (the posterior of every set's first frame)
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -55,6 +60,27 @@ int main(int argc, char **argv) {
   }
   Matrix P0(n, n);
   for (size_t i = 0; i < (size_t)n * n; ++i) P0.data()[i] = in[at + i];
+  at += (size_t)n * n;
+  // optional: more measurement sets (same tracks, other observations) and which one every frame sees
+  std::vector<VioMeasurement> sets(1, meas);
+  std::vector<int> set_of_frame(frames, 0);
+  if (at < in.size()) {
+    const int nsets = (int)in[at++];
+    for (int s = 0; s < nsets; ++s) {
+      VioMeasurement m2;
+      for (int k = 0; k < K; ++k) {
+        Track t;
+        t.setId(k);
+        for (int i = 0; i < L[k]; ++i) { t.emplace_back(in[at], in[at + 1]); at += 2; }
+        m2.msckf_tracks.push_back(t);
+      }
+      sets.push_back(m2);
+    }
+    for (int f = 0; f < frames; ++f) set_of_frame[f] = (int)in[at++];
+  }
+  const bool moving = sets.size() > 1;
+  std::vector<std::vector<double>> P_first(sets.size());
+  std::vector<double> per_frame;
 
   // the state BEFORE manage(): window shifted by one slot, core pose = newest camera pose, at rest
   State s0(N, 0);
@@ -100,7 +126,7 @@ int main(int argc, char **argv) {
     updater.setWindow(N, {}, true);
     ekf.initializeFromState(init);
     ekf.processImu(t0, seq++, w_rest, a_rest);                         // first message: stand-by -> initialised
-    VioMeasurement frame_meas = meas;                                  // what the tracker would hand over this frame
+    VioMeasurement frame_meas = sets[set_of_frame[f]];                 // what the tracker would hand over this frame
     frame_meas.timestamp = t0 + imu_per_frame * dt_imu;
     const auto c0 = std::chrono::steady_clock::now();
     // ---- one frame
@@ -116,6 +142,21 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 4; ++i) prof[i] += updater.profileUs()[i];
     if (!post) { fprintf(stderr, "frame %d: no update applied\n", f); return 3; }
     ms[f] = std::chrono::duration<double, std::milli>(c1 - c0).count();
+    if (moving) {                                                      // (not timed)
+      const Matrix Pf = resident ? ekf.covarianceAt(-1) : post->cov_;
+      const int sidx = set_of_frame[f];
+      double dev = 0.0;
+      if (P_first[sidx].empty()) P_first[sidx].assign(Pf.data(), Pf.data() + (size_t)n * n);
+      else {
+        double num = 0, den = 0;
+        for (size_t i = 0; i < (size_t)n * n; ++i) { const double d = Pf.data()[i] - P_first[sidx][i]; num += d * d; den += P_first[sidx][i] * P_first[sidx][i]; }
+        dev = std::sqrt(num / den);
+      }
+      int inl_f = 0, sched = 0, armed = 0, giveups = 0, reason = 0;
+      for (int v : updater.getMsckfInlierFlags()) inl_f += v;
+      xk_caqr_status(xk, &sched, &armed, &giveups, &reason);
+      per_frame.insert(per_frame.end(), {(double)sidx, (double)inl_f, (double)giveups, (double)sched, dev});
+    }
   }
   const Matrix P = resident ? ekf.covarianceAt(-1) : post->cov_;
   FILE *fo = fopen(argv[2], "wb");
@@ -126,6 +167,11 @@ int main(int argc, char **argv) {
   post->getDynamicStates(dyn);
   fwrite(dyn, sizeof(double), 16, fo);
   fwrite(ms.data(), sizeof(double), frames, fo);
+  if (moving) {
+    fwrite(per_frame.data(), sizeof(double), per_frame.size(), fo);
+    const std::vector<double> none((size_t)n * n, 0.0);
+    for (const auto &pf : P_first) fwrite(pf.empty() ? none.data() : pf.data(), sizeof(double), (size_t)n * n, fo);
+  }
   fclose(fo);
   int inl = 0;
   for (int v : updater.getMsckfInlierFlags()) inl += v;

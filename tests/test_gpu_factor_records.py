@@ -98,7 +98,7 @@ def test_records_next_to_128_row_slots(xk, oracle_c, name, mk):
         eng = xk.LabEngine(N, 0, K)
         eng.set_option("caqr_hlite", hl)
         r, P = _run(eng, sc)
-        assert eng.caqr_status()["schedule"] == 0
+        assert eng.caqr_status()["schedule"] == 3    # (round 6: the multi-launch schedule for the first panels, the last <= 192 columns in single launches)
         assert np.array_equal(r["inlier"], ref["inlier"])
         assert rel(P, ref["P"]) <= 1e-8 and rel(r["correction"], ref["correction"]) <= 1e-6, (hl, rel(P, ref["P"]))
         out[hl] = (P, r["correction"])

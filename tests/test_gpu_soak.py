@@ -164,10 +164,11 @@ def test_random_wide_windows_against_the_oracle(xk, oracle_c):
             if (not np.array_equal(got["inlier"], ref["inlier"]) or not np.array_equal(got["inlier_slam"], ref["inlier_slam"])
                     or not (rp <= 1e-8) or not (rel(got["gamma"][fin], ref["gamma"][fin]) <= 1e-8)):
                 bad.append((N, K, M, kw, rep, rp))
-        assert eng.caqr_status()["schedule"] == 0
+        sched = eng.caqr_status()["schedule"]
+        assert sched in (0, 3)            # 3 (round 6): the last <= 192 columns in one or two single launches (MSCKF rows only, > 20 tracks)
         P_last = eng.download_P()
         eng.close()
-        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], 0, updates=2)      # (multi-launch schedule: no in-launch hand-offs, the two builds must agree trivially)
+        _strict_twin(xk, N, M, K, sc, P_last, got["correction"], sched, updates=2)   # (schedule 0 has no in-launch hand-offs: the two builds agree trivially; 3 has the tail's)
     assert not bad, bad
     print(f"soak: 12 wide windows, worst rel dP {worst:.2e}")
 

@@ -997,7 +997,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     h->pipe_rows_nominal = R_nom;
     if (R_nom >= 64 * 8 && ntiles <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
       XkCaqrPipeArgs pa;
-      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = ntiles;
+      memset(&pa, 0, sizeof(pa));
+      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = ntiles; pa.slot_rows = 64;   // (no leaders, no extra rows: lead_stride = nextra = 0)
       pa.Hc = h->d_Hc; pa.hs = h->hc_stride; pa.nhc = h->rows_compact ? h->K : 0;
       pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
       pa.status = h->d_status;
