@@ -43,7 +43,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector = fp64 matrix dense peak (AMD public spec)
-ROUND_TAG = "r05"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
+ROUND_TAG = "r06"         # profiles/<tag>_pmc_traffic.json is the PMC file this bench line may quote
 CI_EVERY = 10             # BASELINE.json config 4: CI fusion messages every 10 updates
 CI_TRACKS = 2             # shared MSCKF tracks fused per CI round
 PR_SCORE_THR = 0.6        # pr_score_thr (vio.cpp:670): minimum VLAD similarity for a keyframe to be sent back

@@ -25,6 +25,7 @@ SHAPES = {
     "n64_half_rejected": (lambda: synth.make_scenario(64, 420, 0, seed=3403, outlier_frac=0.5), 2),
     "n48_partial_window": (lambda: synth.make_scenario(48, 260, 0, seed=3404, n_poses=37), 1),
     "n36_few_tracks": (lambda: synth.make_scenario(36, 45, 0, seed=3405), 1),
+    "n40_with_slam_features": (lambda: synth.make_scenario(40, 180, 8, seed=3406), 1),      # SLAM rows packed 128 to a slot behind the tracks
 }
 
 
@@ -34,9 +35,10 @@ def test_tail_launch_against_the_oracle_and_the_multi_launch_schedule(xk, oracle
     sc = make()
     ref = oracle_c.visual_update(sc)
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
     out = {}
     for tail in (1, 2, 0):
-        eng = xk.Engine(N, 0, K)
+        eng = xk.Engine(N, M, K)
         eng.set_option("caqr_tail", tail)
         r, P = _update(eng, sc)
         st = eng.caqr_status()
@@ -105,4 +107,24 @@ def test_repeated_updates_with_the_tail_are_bit_identical(xk):
     for _ in range(6):
         r, P = _update(eng, sc)
         assert np.array_equal(P, P0) and np.array_equal(r["correction"], r0["correction"])
+    eng.close()
+
+
+def test_more_accepted_rows_than_the_tail_holds(xk, oracle_c):
+    """BASELINE config 3's shape with (nearly) every track passing the gates: 77 600 nominal rows are within a quarter of what two
+    launches hold (64 768), so the tail is queued -- and finds ~75 000 rows: it gives up at once (reason 9), the update is redone by the
+    multi-launch schedule to the last panel, and the tail stays off for the next updates instead of giving up every time."""
+    sc = synth.make_config(3, err_scale=0.3, outlier_frac=0.0)
+    ref = oracle_c.visual_update(sc)
+    assert int(ref["inlier"].sum()) * 97 > 64768
+    N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
+    eng = xk.Engine(N, 0, K)
+    r, P = _update(eng, sc)
+    st = eng.caqr_status()
+    assert st["giveups"] == 1 and st["last_reason"] == 9 and st["schedule"] == 0, st
+    assert np.array_equal(r["inlier"], ref["inlier"]) and rel(P, ref["P"]) <= 1e-8
+    r2, P2 = _update(eng, sc)
+    st = eng.caqr_status()
+    assert st["giveups"] == 1 and st["schedule"] == 0, st
+    assert np.array_equal(P2, P)
     eng.close()

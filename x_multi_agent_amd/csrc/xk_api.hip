@@ -78,6 +78,7 @@ struct xk_handle {
   bool tail_capable;    // decided at xk_create: 128-row slots, 256 CUs, the kernel fits a CU
   bool tail_ok;         // armed (cleared when a tail launch gave up; re-armed like the fast path)
   bool last_tail;       // the last launch_compress ended in such a launch
+  int tail_backoff_len; // updates the tail stays off after it found more rows than it holds (reason 9): 64, doubling while that keeps happening
   int tail_clean, tail_backoff, opt_tail;   // opt_tail: 0 off, 1 (default) the plan that fits (192 columns in one or two launches, else 96 in one), 2 the 96-column launch only
   bool tail_four;       // the plan of this compression uses the 4-lanes-per-column geometry (<= 192 columns)
   long long *d_pdbg;
@@ -1091,13 +1092,19 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     h->tail_clean = 0;
   }
   if (h->tail_backoff > 0) --h->tail_backoff;
-  else if (overlap && h->tail_ok && h->opt_resident && h->opt_tail && ntiles <= XK_PIPE_SLOTS_MAX && h->K2 == 0 && h->M == 0) {
-    // nominal rows (every track accepted) of the slots before each group boundary; a leader's first 32 rows count whatever its track's length
+  else if (overlap && h->tail_ok && h->opt_resident && h->opt_tail && ntiles <= XK_PIPE_SLOTS_MAX) {
+    // nominal rows (every track accepted) of the slots before each group boundary -- MSCKF tracks, then tracks that become features,
+    // then the SLAM rows packed DB to a slot (vio_updater.cpp:406-422) --; a leader's first 32 rows count whatever its slot holds
     std::vector<long> pre((size_t)groups1 + 1, 0);
+    auto slot_rows_nominal = [&](int t) {
+      if (t < h->K) return 2 * (h->h_trk_off[t + 1] - h->h_trk_off[t]) - 3;
+      if (t < h->K + h->K2) return 2 * (h->h_trk2_off[t - h->K + 1] - h->h_trk2_off[t - h->K]) - 3;
+      return std::min(h->DB, 2 * h->M - (t - h->K - h->K2) * h->DB);
+    };
     for (int g = 0; g < groups1; ++g) {
       long r = 0;
       for (int t = g * arity1; t < std::min(ntiles, (g + 1) * arity1); ++t) {
-        const int v = 2 * (h->h_trk_off[t + 1] - h->h_trk_off[t]) - 3;
+        const int v = slot_rows_nominal(t);
         r += (t % arity1 == 0) ? std::max(v, 32) : v;
       }
       pre[g + 1] = pre[g] + r;
@@ -1358,6 +1365,7 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
     const int w2 = h->d_status[2];
     if (w2 > 0 && (w2 >> 15) == h->pipe_tag) h->acc_ratio = (double)(w2 & 0x7fff) / h->pipe_rows_nominal;
   }
+  if (pst == 0 && h->last_tail) h->tail_backoff_len = 64;      // (a tail that ran through: the next overflow starts at 64 updates off again)
   if (st != 0 || pst != 0) {
     hipStreamSynchronize(h->stream);
     h->d_status[0] = h->d_status[1] = 0;
@@ -1370,7 +1378,7 @@ static int eval_status(xk_handle *h, int st, int pst, bool allow_retry) {
     if (h->last_tail) {
       // the tail launch of a tall system gave up: it only READ the stack, but the retry below rebuilds the rows anyway (one code path);
       // reason 9 = more rows passed the gates than its tiles hold -- off for the next 64 updates; anything else = co-residency
-      if (pst == 9) h->tail_backoff = 64;
+      if (pst == 9) { h->tail_backoff = std::max(64, h->tail_backoff_len); h->tail_backoff_len = std::min(4096, 2 * std::max(64, h->tail_backoff_len)); }
       else { h->tail_ok = false; h->tail_clean = -1; if (h->fast_giveups >= 1) h->rearm_after = std::min(4096, std::max(1, h->rearm_after) * 2); }
       h->fast_giveups++; h->fast_reason = pst;
       h->xsync_dirty = true;
