@@ -11,11 +11,12 @@ from x_multi_agent_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(xk, sc, resident=1):
+def _run(xk, sc, resident=1, slam_split=1):
     N, K = sc["n_poses_max"], len(sc["trk_off"]) - 1
     M = len(sc["slam_anchor_idxs"]) if "slam_anchor_idxs" in sc else 0
     eng = xk.Engine(N, M, K)
     eng.set_option("caqr_resident", resident)
+    eng.set_option("slam_split", slam_split)
     eng.stage(sc)
     r = eng.visual_update_staged(sc["sigma_img"])
     P = eng.download_P()
@@ -44,7 +45,13 @@ def test_accepted_rows_that_do_not_fit_are_found_out_by_the_launch(xk, oracle_c)
     size is not tried again; the fast path stays armed for stacks that fit."""
     sc = synth.make_scenario(30, 260, 50, seed=5102)
     ref = oracle_c.visual_update(sc)
+    # (round 6: with the split compression -- the default where SLAM features keep the update out of the launch -- this stack is a narrow
+    #  one, 14 820 nominal rows in 181 columns, and fits: served by the single launch.  The capacity cliff of the WIDE geometry is what this
+    #  test is about: "slam_split" 0 compresses the whole stack)
     eng, r, P, st = _run(xk, sc)
+    assert st["schedule"] == 2 and st["giveups"] == 0 and rel(P, ref["P"]) <= 1e-8, st
+    eng.close()
+    eng, r, P, st = _run(xk, sc, slam_split=0)
     assert st["schedule"] == 0 and st["giveups"] == 1 and st["last_reason"] == 9 and st["armed"], st
     assert np.array_equal(r["inlier"], ref["inlier"]) and rel(P, ref["P"]) <= 1e-8
     eng.stage(sc)

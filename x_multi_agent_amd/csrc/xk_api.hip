@@ -71,6 +71,15 @@ struct xk_handle {
   bool last_split;         // the last single launch used that geometry
   int split_backoff;       // updates for which it stays off after it found more rows than it holds
   int overflow_rows;       // a single launch of that many nominal rows found more accepted rows than its tiles hold: not tried again at that size
+  // SPLIT compression (round 6; systems with SLAM features whose update cannot ride inside the launch, n > 206: BASELINE config 2).
+  // The rows of MSCKF tracks are zero in the features' columns (msckf_update.cpp:412-416) and the features' own rows are 2 M in number:
+  // only the tracks' rows need compressing, and only in the 6 N pose columns (+ the residual) -- a system of <= 199 columns instead of
+  // 6 N + 3 M + 1.  T = [R1 | 0 | z1 ; H_slam | res_slam] (6 N + 2 M rows, T^T T = H^T H and T^T z = H^T res exactly as for the R of
+  // the whole stack) goes to d_R2; xk_qr_compress, which hands out the reference's upper-triangular T_H, keeps compressing everything.
+  double *d_R2;         // [C1P][C1P] row-major: rows [0, 6 N) = R1 of the tracks' rows, rows [6 N, 6 N + 2 M) = the SLAM rows as built
+  bool split_active;    // the last launch_compress produced d_R2 (compressed_spec follows it)
+  bool want_full_T;     // xk_qr_compress is running: compress everything into d_R
+  int opt_slam_split;
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
   bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
   // Tall systems (128-row slots: windows of 34..64 poses, BASELINE config 3): the multi-launch schedule factors the first panels,
@@ -285,6 +294,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_R, (size_t)h->C1P * h->C1P));
   HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
+  if (n_feat_max > 0 && h->DB == 64) {
+    HIPCHK(h, dalloc(&h->d_R2, (size_t)h->C1P * h->C1P));
+    HIPCHK(h, hipMemset(h->d_R2, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
+  }
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
@@ -317,6 +330,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     }
     h->tail_ok = h->tail_capable;
     h->opt_tail = env_int("XK_CAQR_TAIL", 1);
+    h->opt_slam_split = env_int("XK_SLAM_SPLIT", 1);
     h->rearm_after = env_int("XK_CAQR_REARM", 64);
     h->opt_resident = env_int("XK_CAQR_RESIDENT", 1);
     h->opt_poison = env_int("XK_CAQR_RESIDENT_POISON", 0);
@@ -423,6 +437,7 @@ extern "C" int xk_destroy(xk_handle *h) {
   free(h->h_trk2_off);
   if (h->d_csr_v) hipFree(h->d_csr_v);
   if (h->d_Hc) hipFree(h->d_Hc);
+  if (h->d_R2) hipFree(h->d_R2);
   delete h->fused_ct;
   if (h->d_Psnap) hipFree(h->d_Psnap);
   if (h->d_Psnap2) hipFree(h->d_Psnap2);
@@ -880,6 +895,8 @@ static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
 // QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
 // fuse: (optional) the Kalman update that follows this compression.  If the single launch takes it along (narrow geometry,
 // correction_total = 0, covariance update, no external S), h->last_fused says so and the caller must NOT queue launch_update.
+static bool split_plan(const xk_handle *h);
+static long split_rows_nominal(const xk_handle *h);
 // The last columns [ccut, C1) of a tall system in ONE launch or TWO (xk_caqr_pipe<XkPipeTail> / <XkPipeTail4>): the rows of slots
 // [slot0, slot0 + nslots) -- as the multi-launch schedule left them after the panels before ccut: R's rows zeroed where they were
 // taken out, the leaders' first 32 rows holding merged rows -- plus `nextra` rows from behind the slots (the R of the launch before)
@@ -971,6 +988,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
   // register-resident single launch (xk_caqr_pipe.hip.h): MSCKF tracks only, valid rows <= 184 fat tiles of 128
   const int resident_env = h->opt_resident;
   const bool fast_shape = h->K + h->K2 > 0 || h->M > 0;
+  const bool sp = split_plan(h);                  // (before the re-arming below: what compressed_spec saw)
+  h->split_active = false;
   if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && fast_shape && ++h->clean_classic > h->rearm_after) {
     h->persist_ok = true;                         // (the sync words of a launch that gave up are cleared below)
     h->clean_classic = 0;
@@ -980,9 +999,11 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     // is the rows that PASS the gates -- which the host does not know when it queues the launch.  It queues on the nominal count
     // (every track accepted) up to a quarter over the capacity; a launch that finds more accepted rows than its tiles hold gives
     // up at once (reason 9) and the multi-launch schedule serves the update -- and the following ones of that size.
-    const bool narrow = h->C1 <= XkPipeNarrow::COLS;
+    // (split compression, see xk_handle::d_R2: the tracks' rows only, in the pose columns + the residual)
+    const int C1s = sp ? 6 * h->N + 1 : h->C1, nslots_p = sp ? h->K + h->K2 : ntiles;
+    const bool narrow = C1s <= XkPipeNarrow::COLS;
     const int rows_cap = narrow ? XkPipeNarrow::ROWS : XkPipeWide::ROWS;
-    int R_nom = 2 * h->M;
+    int R_nom = sp ? 0 : 2 * h->M;
     for (int k = 0; k < h->K; ++k) R_nom += 2 * (h->h_trk_off[k + 1] - h->h_trk_off[k]) - 3;
     for (int k = 0; k < h->K2; ++k) R_nom += 2 * (h->h_trk2_off[k + 1] - h->h_trk2_off[k]) - 3;
     // two first-level groups per XCD when the rows expected to pass fit 152 tiles (2 % and half a tile's worth of margin); a launch
@@ -996,12 +1017,14 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     }
     const int NTP = 8 * (narrow ? (split ? XkPipeNarrow2::NT : XkPipeNarrow::NT) : XkPipeWide::NT);
     h->pipe_rows_nominal = R_nom;
-    if (R_nom >= 64 * 8 && ntiles <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
+    if (R_nom >= 64 * 8 && nslots_p <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
       XkCaqrPipeArgs pa;
       memset(&pa, 0, sizeof(pa));
-      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = ntiles; pa.slot_rows = 64;   // (no leaders, no extra rows: lead_stride = nextra = 0)
+      pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = nslots_p; pa.slot_rows = 64;   // (no leaders, no extra rows: lead_stride = nextra = 0)
       pa.Hc = h->d_Hc; pa.hs = h->hc_stride; pa.nhc = h->rows_compact ? h->K : 0;
-      pa.C1P = h->C1P; pa.C1 = h->C1; pa.Rout = h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
+      pa.C1P = h->C1P; pa.C1 = C1s; pa.Rout = sp ? h->d_R2 : h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
+      pa.res_col = sp ? h->na : 0;
+      h->split_active = sp;
       pa.status = h->d_status;
       if (h->xsync_dirty) {
         if (hipMemsetAsync(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
@@ -1010,7 +1033,8 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
         h->xsync_dirty = false; h->xsync_phase = 0;
       }
       {
-        const size_t np_ = (size_t)(h->C1 + 15) / 16, strips_ = np_ * XK_PIPE_RLS, x1n = strips_ * 16 * h->C1P;
+        // (panels of THIS launch's system: the launch re-arms the other set by the same count, xk_caqr_pipe entry)
+        const size_t np_ = (size_t)(C1s + 15) / 16, strips_ = np_ * XK_PIPE_RLS, x1n = strips_ * 16 * h->C1P;
         double *set = h->d_x1 + (size_t)h->xsync_phase * h->xslab_doubles;
         pa.X1 = set; pa.X2 = set + x1n; pa.X1P = set + 2 * x1n;
         pa.Xnext = h->d_x1 + (size_t)(h->xsync_phase ^ 1) * h->xslab_doubles;
@@ -1046,6 +1070,14 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       if (split) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow2>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else if (narrow) hipLaunchKernelGGL(xk_caqr_pipe<XkPipeNarrow>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
       else hipLaunchKernelGGL(xk_caqr_pipe<XkPipeWide>, dim3(h->n_cu), dim3(XK_PIPE_THREADS), 0, h->stream, pa);
+      if (sp) {
+        // the SLAM features' rows go into the compressed system as they were built: 2 M rows behind R1's 6 N (BEHIND the launch: row 6 N
+        // of its output -- the residual column's own row of R, which nobody reads -- is the first of them)
+        const int slam0 = h->K + h->K2;
+        if (hipMemcpyAsync(h->d_R2 + (size_t)6 * h->N * h->C1P, h->d_A + (size_t)slam0 * h->DB * h->C1P, sizeof(double) * 2 * (size_t)h->M * h->C1P,
+                           hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+          return fail(h, XK_EDEVICE, "SLAM rows");
+      }
       if (pa.kal && !fuse->cov_update && fuse->Pout != fuse->Pin &&
           hipMemcpyAsync(fuse->Pout, fuse->Pin, sizeof(double) * (size_t)h->n * h->n, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
         return fail(h, XK_EDEVICE, "prior copy");
@@ -1344,9 +1376,37 @@ static int launch_update(xk_handle *h, const UpdateSpec &u, float *gemm_ms_accum
   return XK_OK;
 }
 
+// Will (did) the compression of the staged update take the split form?  One predicate for compressed_spec -- which callers evaluate
+// BEFORE launch_compress -- and for launch_compress itself, on handle state neither of them changes in between; it repeats the
+// conditions under which the single launch is taken at all (a split system goes nowhere else).
+static int split_geometry_rows(const xk_handle *h) { return 6 * h->N + 1 <= XkPipeNarrow::COLS ? XkPipeNarrow::ROWS : XkPipeWide::ROWS; }
+static long split_rows_nominal(const xk_handle *h) {
+  long r = 0;
+  for (int k = 0; k < h->K; ++k) r += 2 * (h->h_trk_off[k + 1] - h->h_trk_off[k]) - 3;
+  for (int k = 0; k < h->K2; ++k) r += 2 * (h->h_trk2_off[k + 1] - h->h_trk2_off[k]) - 3;
+  return r;
+}
+static bool split_plan(const xk_handle *h) {
+  if (!h->d_R2 || !h->opt_slam_split || h->want_full_T || !h->opt_resident || !h->persist_ok) return false;
+  if (h->M <= 0 || h->K + h->K2 <= 0 || h->n <= 206 || 6 * h->N + 1 > XkPipeWide::COLS) return false;
+  const long R = split_rows_nominal(h);
+  return R >= 64 * 8 && h->K + h->K2 <= XK_PIPE_SLOTS_MAX && R * 4 <= (long)split_geometry_rows(h) * 5 &&
+         (h->overflow_rows == 0 || R < h->overflow_rows);
+}
+
 static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_update) {
   UpdateSpec u;
   memset(&u, 0, sizeof(u));
+  if (h->have_R ? h->split_active : split_plan(h)) {
+    // the split form (d_R2): 6 N rows of R1 over the pose columns, then the 2 M rows of the SLAM features as built
+    u.T = h->d_R2; u.str = h->C1P; u.stc = 1;
+    u.c = 6 * h->N + 2 * h->M; u.kdim = h->na; u.col0 = XK_CORE;
+    u.z = h->d_R2 + h->na; u.sz = h->C1P;
+    u.rdiag = nullptr; u.rscalar = h->sigma_img * h->sigma_img;    // the SLAM rows carry sigma_img^2 too (slam_update.cpp: r = var_img I)
+    u.Pin = h->d_P; u.Pout = h->d_Pout; u.ct = d_ct; u.cov_update = cov_update;
+    u.tri = 0;                                     // (the SLAM rows are not below anybody's diagonal)
+    return u;
+  }
   u.T = h->d_R; u.str = h->C1P; u.stc = 1;      // R[0], rows 0..na-1, active columns
   u.c = h->na; u.kdim = h->na; u.col0 = XK_CORE;
   u.z = h->d_R + h->na; u.sz = h->C1P;           // residual column
@@ -1448,14 +1508,13 @@ extern "C" int xk_msckf_build(xk_handle *h, double sigma_img, int *inlier_msckf,
 extern "C" int xk_qr_compress(xk_handle *h, double *T_H, int ldt, double *z) {
   if (!h) return XK_EINVAL;
   HIPCHK(h, hipSetDevice(h->device));
+  h->want_full_T = true;                         // (this call hands out the reference's upper-triangular T_H: no split compression)
   int rc = launch_compress(h);
-  if (rc != XK_OK) return rc;
-  rc = read_status(h, true);
+  if (rc == XK_OK) rc = read_status(h, true);
   if (rc == XK_RETRY_CLASSIC) {                  // rebuild the rows (the tiles were worked on in place) and compress the slow way
-    if ((rc = launch_build(h, h->sigma_img)) != XK_OK) return rc;
-    if ((rc = launch_compress(h)) != XK_OK) return rc;
-    rc = read_status(h);
+    if ((rc = launch_build(h, h->sigma_img)) == XK_OK && (rc = launch_compress(h)) == XK_OK) rc = read_status(h);
   }
+  h->want_full_T = false;
   if (rc != XK_OK) return rc;
   if (T_H || z) {
     if (T_H && ldt < h->n) return XK_EINVAL;
@@ -2652,6 +2711,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
   if (!strcmp(name, "caqr_resident")) h->opt_resident = value;
   else if (!strcmp(name, "caqr_rearm")) h->rearm_after = value;
   else if (!strcmp(name, "caqr_tail")) h->opt_tail = value;
+  else if (!strcmp(name, "slam_split")) h->opt_slam_split = value;
 #ifdef XK_LAB
   // test hooks and A/B switches (include/xk_lab.h)
   else if (!strcmp(name, "caqr_poison")) h->opt_poison = value;

@@ -170,6 +170,9 @@ struct XkCaqrPipeArgs {
   int slot_rows;          // rows of a slot of A (64; 128 next to the multi-launch schedule's tall slots: the tail geometry)
   int lead_stride;        // > 0 (tail geometry): slots t % lead_stride == 0 led a merge group of the multi-launch schedule -- their first 32
                           // rows hold merged rows whatever their track's own row count was (xk_caqr_merge_body: pivot strip + hole)
+  int res_col;            // > 0: the system is columns [0, C1 - 1) of A plus column res_col as its last one (the residual) -- a stack whose rows
+                          // are zero in the columns in between (MSCKF rows next to SLAM features' columns, vio_updater.cpp:406-422: xk_api.hip,
+                          // split compression); rows of R carry their last entry at column res_col as well
   int nextra;             // tail geometry, second launch of two: rows [extra_row0, extra_row0 + nextra) of A (row stride C1P) -- the R the first
   long extra_row0;        // launch left -- join the stack behind the slots' rows
   int C1P, C1;
@@ -221,6 +224,8 @@ __device__ __forceinline__ int xk_launder(int v) {
 // the merge layout (4 columns x 16 rows) then moves one contiguous 512-byte block per strip; row-major strips cost it sixteen
 // 32-byte pieces per instruction, and the strip loads / stores of a first-level workgroup were 4.6 + 4.5 us of its panel.
 __device__ __forceinline__ size_t xk_blk(int c, int r) { return (size_t)(c >> 2) * 64 + (size_t)r * 4 + (size_t)(c & 3); }
+// column of A / of R that holds column c of the system (XkCaqrPipeArgs::res_col)
+__device__ __forceinline__ int xk_pipe_srccol(const XkCaqrPipeArgs &a, int c) { return (a.res_col > 0 && c == a.C1 - 1) ? a.res_col : c; }
 // How the last level cuts a panel's `trail` trailing columns: chunks of lchalf columns (whole quarter-waves, <= 32), one per
 // workgroup while XK_PIPE_NLW of them cover the range, else (NCL = 2, the first panels of a wide system) two chunks per workgroup --
 // x and x + XK_PIPE_NLW; lsplit = chunks in use.  The first level needs the same numbers for the panel before its own (how many
@@ -624,7 +629,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
               if (ph >= 0 && sl >= lo && sl < hi) {        // (wave-uniform)
                 const double *rec = recs + (sl - lo) * hs;
                 if (sl != kcur) {
-                  const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * fc);
+                  const xk_d2 *wc = reinterpret_cast<const xk_d2 *>(rec + XK_HC_VR + XK_HC_WC * xk_pipe_srccol(a, fc));
                   const xk_d2 q0 = wc[0], q1 = wc[1], q2 = wc[2];
                   nw0 = -q0[0]; nw1 = -q0[1]; nw2 = -q1[0]; x0 = q1[1]; x1 = q2[0]; r0 = (int)q2[1];
                   wres = (r0 == -1) ? 1.0 : 0.0;             // the residual column: w = x = 0, the entry is r'
@@ -664,7 +669,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
       }
     }
     if (s_hi >= a.nhc) {                                   // (workgroup-uniform) rows that are tiles
-      const double *Ac = a.A + ccl;
+      const double *Ac = a.A + xk_pipe_srccol(a, ccl);
 #pragma unroll
       for (int h0 = 0; h0 < RPL; h0 += 16) {
         double x[16];
@@ -688,7 +693,7 @@ __device__ __noinline__ bool xk_pipe_tile(XkPipeArgsPtr ap, int xcc, int slot, l
     int pr[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) pr[r] = myrows[part_ * RPL + r];
-    const double *Ac = a.A + min(cabs, a.C1P - 1);          // (the wide geometry's column slots run to 383, past C1P = 256 / 320: clamped into the row)
+    const double *Ac = a.A + xk_pipe_srccol(a, min(cabs, a.C1P - 1));   // (the wide geometry's column slots run to 383, past C1P = 256 / 320: clamped into the row)
 #pragma unroll
     for (int h0 = 0; h0 < RPL; h0 += 16) {
       double x[16];
@@ -1087,14 +1092,14 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
     auto rout = [&](size_t at, double v) { if (a.kal) xk_st_sc1(a.Rout + at, v); else a.Rout[at] = v; };
     if (mine) {
       if (panel) {
-        if (lidx == 0 && c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col, (part > cidx) ? 0.0 : b[0]);
+        if (lidx == 0 && c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + xk_pipe_srccol(a, col), (part > cidx) ? 0.0 : b[0]);
       } else {
         if (k + 1 < npanels) {
           double *dst = a.X2 + (size_t)k * XK_PIPE_RLS * SS + xk_blk(col, part);
 #pragma unroll
           for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b[s]);
         }
-        if (c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col, b[0]);
+        if (c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + xk_pipe_srccol(a, col), b[0]);
       }
     }
     if (mine2) {
@@ -1103,7 +1108,7 @@ __device__ __noinline__ bool xk_pipe_last(XkPipeArgsPtr ap, int lidx, double *ub
 #pragma unroll
         for (int s = 1; s < RL; ++s) xk_st_sc1(dst + s * SS, b2[s]);
       }
-      if (c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + col2, b2[0]);
+      if (c0 + part < a.C1) rout((size_t)(c0 + part) * a.C1P + xk_pipe_srccol(a, col2), b2[0]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
