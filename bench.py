@@ -339,6 +339,13 @@ def other_configs(engine, synth, with_cpu=True):
                  "qr_frac_of_fp64_peak": f_qr_run / (qr_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                  "qr_alg_flops_of_the_launches": f_qr_run, "qr_alg_flops_whole_stack_dense": f_qr,
                  "split_compression": bool(split)}
+            pmc_c, pmc_state_c = pmc_of_this_round(cfg)
+            if pmc_c and pmc_c.get("qr_bytes_per_update"):
+                # HBM-side view: PMC bytes between the L2s and the fabric per update (QR kernels) over the QR
+                # stage's time, against the 8 TB/s peak -- next to the fp64-side fraction above
+                e["qr_l2_fabric_bytes_per_update"] = pmc_c["qr_bytes_per_update"]
+                e["qr_frac_of_hbm_peak"] = pmc_c["qr_bytes_per_update"] / (qr_ms * 1e-3) / 8.0e12
+            e["pmc_file"] = pmc_state_c
             if with_cpu:
                 from oracle import c_oracle
                 eng.stage(sc)

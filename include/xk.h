@@ -385,7 +385,10 @@ int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, 
 /* Operational switches of the compression on a live handle.  "caqr_resident": 0 = the multi-launch schedule serves every update
  * (e.g. a GPU this process knowingly shares), 1 (default) = the single launch where the shape allows it; "caqr_rearm": clean
  * multi-launch updates after which a single-launch path that gave up is tried again (default 64, doubling at every further give-up);
- * "caqr_tail": 0 = tall systems are factored by the multi-launch schedule to the last panel, 1 (default) = their last columns by one launch.
+ * "caqr_tail": 0 = tall systems (windows of 34..64 poses) are factored by the multi-launch schedule to the last panel, 1 (default) = their
+ * last <= 192 columns by one or two single launches, 2 = their last <= 96 columns by one; "slam_split": 1 (default) = systems with SLAM
+ * features and more than 206 error states compress only the tracks' rows, in the pose columns, and append the features' own rows to the
+ * compressed system as built (same posterior; xk_qr_compress keeps returning the whole stack's upper-triangular T_H), 0 = the whole stack.
  * Unknown name: XK_EINVAL.  The release library reads nothing from the environment; the experiment switches, test hooks, debug
  * exports and probe kernels of the lab build are declared in xk_lab.h.  No counterpart in the reference. */
 int xk_set_option(xk_handle *h, const char *name, int value);
