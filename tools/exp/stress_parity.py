@@ -14,7 +14,7 @@ worst, bad, t0 = 0.0, [], time.time()
 for it in range(n_cases):
     N = int(rng.choice([2, 3, 5, 8, 12, 16, 24, 30, 33, 34, 40, 50, 64]))
     K = int(rng.choice([0, 1, 2, 7, 19, 20, 21, 39, 41, 60, 120, 250, 401]))
-    M = int(rng.choice([0, 0, 0, 1, 4, 11]))
+    M = int(rng.choice([0, 0, 0, 1, 4, 11, 25, 40]))     # (25, 40: round 6 -- the split compression needs n > 206)
     if K == 0 and M == 0:
         K = 3
     if 15 + 6 * N + 3 * M + 1 > 512:
