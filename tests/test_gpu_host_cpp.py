@@ -53,3 +53,33 @@ def test_filter_loop_through_mirrored_api(tmp_path, name):
     assert rel(p_arr, ref["p_array"]) <= 1e-9 and rel(q_arr, ref["q_array"]) <= 1e-9
     if M:
         assert rel(f_arr, ref["f_array"]) <= 1e-9
+
+
+def test_config2_through_the_mirrored_api(tmp_path, oracle_c):
+    """BASELINE config 2 (window 30, 200 MSCKF tracks, 50 SLAM features, n = 345) through x::Ekf -> x::Updater::update -> x::VioUpdater: the
+    compression the mirror queues is the SPLIT one (round 6) -- posterior, gate results and corrected state against the C oracle."""
+    from x_multi_agent_amd import synth
+    exe = os.path.join(PKG, "xk_host_example")
+    sc = synth.make_config(2)
+    exp = oracle_c.visual_update(sc)
+    N, K, M = synth.CONFIGS[2]
+    parts = [np.array([N, M, K, N, sc["sigma_img"]], float), sc["C_q_G"].ravel(), sc["G_p_C"].ravel(), np.diff(sc["trk_off"]).astype(float),
+             sc["obs_xy"].ravel(), sc["slam_feat"], sc["slam_anchor_idxs"].astype(float), sc["slam_z_last"].ravel(),
+             sc["slam_track_sizes"].astype(float), np.asfortranarray(sc["P"]).ravel(order="F")]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    np.concatenate(parts).astype("<f8").tofile(fin)
+    env = dict(os.environ, LD_LIBRARY_PATH=PKG + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = np.fromfile(fout, dtype="<f8")
+    n = sc["P"].shape[0]
+    P = out[:n * n].reshape(n, n, order="F")
+    at = n * n
+    p_arr, q_arr, f_arr = out[at:at + 3 * N], out[at + 3 * N:at + 7 * N], out[at + 7 * N:at + 7 * N + 3 * M]
+    inl = out[at + 7 * N + 3 * M:].astype(int)
+    assert np.array_equal(inl[:K], exp["inlier"])
+    assert rel(P, exp["P"]) <= 1e-9, rel(P, exp["P"])
+    st = dict(p=np.zeros(3), v=np.zeros(3), q=np.array([0, 0, 0, 1.0]), b_w=np.zeros(3), b_a=np.zeros(3),
+              p_array=sc["G_p_C"].ravel(), q_array=sc["C_q_G"].ravel(), f_array=sc["slam_feat"])
+    ref = ref_np.state_correct(st, exp["correction"])
+    assert rel(p_arr, ref["p_array"]) <= 1e-9 and rel(q_arr, ref["q_array"]) <= 1e-9 and rel(f_arr, ref["f_array"]) <= 1e-9
