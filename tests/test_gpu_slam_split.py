@@ -165,3 +165,52 @@ def test_split_launch_that_gives_up(xk, oracle_c):
     r2, P2 = _update(eng, sc)                              # (multi-launch schedule on the whole stack while the fast path is off)
     assert rel(P2, ref["P"]) <= 1e-8
     eng.close()
+
+
+@pytest.mark.parametrize("N,M", [(30, 50), (20, 10), (12, 30), (40, 12)])
+def test_slam_rows_alone_are_not_compressed(xk, oracle_c, N, M):
+    """No track ended this frame: the stack is the features' 2 M rows against n > 3 M columns.  The reference compresses only when rows >
+    columns (vio_updater.cpp:487); neither does this -- no QR launch at all (xk_caqr_status: schedule 4), the rows go to the update as built.
+    Against the C oracle, against the compression the option switches back on, through the queued and the two-call form (at n <= 206 the latter
+    used to DEFER the compression behind xk_apply_update: nothing to defer here)."""
+    sc = synth.make_scenario(N, 0, M, seed=7400 + N)
+    ref = oracle_c.visual_update(sc)
+    out = {}
+    for split in (1, 0):
+        eng = xk.Engine(N, M, 1)
+        eng.set_option("slam_split", split)
+        for rep in range(2):
+            r, P = _update(eng, sc)
+            assert (eng.caqr_status()["schedule"] == 4) == bool(split), (split, eng.caqr_status())
+            assert np.array_equal(r["inlier_slam"], ref["inlier_slam"])
+            assert rel(P, ref["P"]) <= 1e-8 and rel(r["correction"], ref["correction"]) <= 1e-6, (split, rep, rel(P, ref["P"]))
+        out[split] = (P, r["correction"])
+        if split:
+            eng.upload_P(sc["P"]); eng.stage(sc)
+            assert eng.L.xk_build_compress_update_async(eng.h, C.c_double(sc["sigma_img"])) == 0
+            c1 = eng.apply_update(None, True)
+            assert rel(eng.download_P(), P) <= 1e-12 and rel(c1, r["correction"]) <= 1e-10
+            eng.upload_P(sc["P"]); eng.stage(sc)
+            assert eng.L.xk_build_compress_async(eng.h, C.c_double(sc["sigma_img"])) == 0
+            c2 = eng.apply_update(None, True)
+            assert rel(eng.download_P(), P) <= 1e-12 and rel(c2, r["correction"]) <= 1e-10
+            assert eng.caqr_status()["schedule"] == 4
+        eng.close()
+    assert rel(out[1][0], out[0][0]) <= 1e-10 and rel(out[1][1], out[0][1]) <= 1e-8
+
+
+def test_frames_with_and_without_tracks_on_one_handle(xk, oracle_c):
+    """A filter's life: frames whose stack is SLAM rows only between frames that also carry tracks, on one handle (n = 345)."""
+    N, K, M = synth.CONFIGS[2]
+    full = synth.make_config(2)
+    only = synth.make_scenario(N, 0, M, seed=7500)
+    refs = {"full": oracle_c.visual_update(full), "only": oracle_c.visual_update(only)}
+    eng = xk.Engine(N, M, K)
+    for it, which in enumerate(("only", "full", "only", "only", "full", "full", "only")):
+        sc = full if which == "full" else only
+        eng.upload_P(sc["P"])
+        r, P = _update(eng, sc)
+        assert eng.caqr_status()["schedule"] == (2 if which == "full" else 4), (it, eng.caqr_status())
+        assert rel(P, refs[which]["P"]) <= 1e-8 and rel(r["correction"], refs[which]["correction"]) <= 1e-6, (it, which)
+    assert eng.caqr_status()["giveups"] == 0
+    eng.close()

@@ -77,7 +77,8 @@ struct xk_handle {
   // 6 N + 3 M + 1.  T = [R1 | 0 | z1 ; H_slam | res_slam] (6 N + 2 M rows, T^T T = H^T H and T^T z = H^T res exactly as for the R of
   // the whole stack) goes to d_R2; xk_qr_compress, which hands out the reference's upper-triangular T_H, keeps compressing everything.
   double *d_R2;         // [C1P][C1P] row-major: rows [0, 6 N) = R1 of the tracks' rows, rows [6 N, 6 N + 2 M) = the SLAM rows as built
-  bool split_active;    // the last launch_compress produced d_R2 (compressed_spec follows it)
+  int split_active;     // what the last launch_compress left in d_R2 (compressed_spec follows it): 0 nothing, 1 the split compression,
+                        // 2 the SLAM rows alone, uncompressed (no track in the stack: rows <= columns, vio_updater.cpp:487 does not compress either)
   bool want_full_T;     // xk_qr_compress is running: compress everything into d_R
   int opt_slam_split;
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
@@ -294,7 +295,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_R, (size_t)h->C1P * h->C1P));
   HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
-  if (n_feat_max > 0 && h->DB == 64) {
+  if (n_feat_max > 0) {
     HIPCHK(h, dalloc(&h->d_R2, (size_t)h->C1P * h->C1P));
     HIPCHK(h, hipMemset(h->d_R2, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
   }
@@ -895,7 +896,7 @@ static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
 // QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
 // fuse: (optional) the Kalman update that follows this compression.  If the single launch takes it along (narrow geometry,
 // correction_total = 0, covariance update, no external S), h->last_fused says so and the caller must NOT queue launch_update.
-static bool split_plan(const xk_handle *h);
+static int split_plan(const xk_handle *h);
 static long split_rows_nominal(const xk_handle *h);
 // The last columns [ccut, C1) of a tall system in ONE launch or TWO (xk_caqr_pipe<XkPipeTail> / <XkPipeTail4>): the rows of slots
 // [slot0, slot0 + nslots) -- as the multi-launch schedule left them after the panels before ccut: R's rows zeroed where they were
@@ -988,8 +989,18 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
   // register-resident single launch (xk_caqr_pipe.hip.h): MSCKF tracks only, valid rows <= 184 fat tiles of 128
   const int resident_env = h->opt_resident;
   const bool fast_shape = h->K + h->K2 > 0 || h->M > 0;
-  const bool sp = split_plan(h);                  // (before the re-arming below: what compressed_spec saw)
-  h->split_active = false;
+  const int sp_mode = split_plan(h);              // (before the re-arming below: what compressed_spec saw)
+  const bool sp = sp_mode == 1;
+  h->split_active = 0;
+  if (sp_mode == 2) {
+    // SLAM rows only: no compression (see split_plan) -- the rows as built are the system the update applies
+    if (hipMemcpyAsync(h->d_R2 + (size_t)6 * h->N * h->C1P, h->d_A, sizeof(double) * 2 * (size_t)h->M * h->C1P, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+      return fail(h, XK_EDEVICE, "SLAM rows");
+    if (mid) hipEventRecord(mid, h->stream);
+    h->split_active = 2;
+    h->nleaf = 0; h->nlevels = 0; h->have_R = true; h->last_resident = false; h->last_pipe = false;
+    return XK_OK;
+  }
   if (resident_env && !h->persist_ok && h->fast_capable && h->rearm_after > 0 && fast_shape && ++h->clean_classic > h->rearm_after) {
     h->persist_ok = true;                         // (the sync words of a launch that gave up are cleared below)
     h->clean_classic = 0;
@@ -1024,7 +1035,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
       pa.Hc = h->d_Hc; pa.hs = h->hc_stride; pa.nhc = h->rows_compact ? h->K : 0;
       pa.C1P = h->C1P; pa.C1 = C1s; pa.Rout = sp ? h->d_R2 : h->d_R; pa.S = h->d_rs; pa.PB = h->d_rpb;
       pa.res_col = sp ? h->na : 0;
-      h->split_active = sp;
+      h->split_active = sp ? 1 : 0;
       pa.status = h->d_status;
       if (h->xsync_dirty) {
         if (hipMemsetAsync(h->d_xsync, 0, sizeof(unsigned) * 2 * XP_WORDS * 16, h->stream) != hipSuccess) return fail(h, XK_EDEVICE, "sync words");
@@ -1386,22 +1397,28 @@ static long split_rows_nominal(const xk_handle *h) {
   for (int k = 0; k < h->K2; ++k) r += 2 * (h->h_trk2_off[k + 1] - h->h_trk2_off[k]) - 3;
   return r;
 }
-static bool split_plan(const xk_handle *h) {
-  if (!h->d_R2 || !h->opt_slam_split || h->want_full_T || !h->opt_resident || !h->persist_ok) return false;
-  if (h->M <= 0 || h->K + h->K2 <= 0 || h->n <= 206 || 6 * h->N + 1 > XkPipeWide::COLS) return false;
+static int split_plan(const xk_handle *h) {
+  if (!h->d_R2 || !h->opt_slam_split || h->want_full_T || h->M <= 0) return 0;
+  // 2: the stack is the SLAM features' rows and nothing else (no track ended this frame -- the common frame of a filter with persistent
+  // features): 2 M rows against n > 3 M columns.  The reference compresses only when rows > columns (vio_updater.cpp:487); neither does this:
+  // the rows go to the update as built, no QR launch at all (any n, any window).
+  if (h->K + h->K2 == 0) return 2 * h->M <= h->CM ? 2 : 0;
+  if (h->DB != 64 || !h->opt_resident || !h->persist_ok) return 0;
+  if (h->n <= 206 || 6 * h->N + 1 > XkPipeWide::COLS) return 0;
   const long R = split_rows_nominal(h);
-  return R >= 64 * 8 && h->K + h->K2 <= XK_PIPE_SLOTS_MAX && R * 4 <= (long)split_geometry_rows(h) * 5 &&
-         (h->overflow_rows == 0 || R < h->overflow_rows);
+  return (R >= 64 * 8 && h->K + h->K2 <= XK_PIPE_SLOTS_MAX && R * 4 <= (long)split_geometry_rows(h) * 5 &&
+          (h->overflow_rows == 0 || R < h->overflow_rows)) ? 1 : 0;
 }
 
 static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_update) {
   UpdateSpec u;
   memset(&u, 0, sizeof(u));
-  if (h->have_R ? h->split_active : split_plan(h)) {
-    // the split form (d_R2): 6 N rows of R1 over the pose columns, then the 2 M rows of the SLAM features as built
-    u.T = h->d_R2; u.str = h->C1P; u.stc = 1;
-    u.c = 6 * h->N + 2 * h->M; u.kdim = h->na; u.col0 = XK_CORE;
-    u.z = h->d_R2 + h->na; u.sz = h->C1P;
+  if (const int mode = h->have_R ? h->split_active : split_plan(h)) {
+    // the split form (d_R2): 6 N rows of R1 over the pose columns, then the 2 M rows of the SLAM features as built; mode 2: those rows alone
+    const int r0 = mode == 2 ? 6 * h->N : 0;
+    u.T = h->d_R2 + (size_t)r0 * h->C1P; u.str = h->C1P; u.stc = 1;
+    u.c = 6 * h->N + 2 * h->M - r0; u.kdim = h->na; u.col0 = XK_CORE;
+    u.z = u.T + h->na; u.sz = h->C1P;
     u.rdiag = nullptr; u.rscalar = h->sigma_img * h->sigma_img;    // the SLAM rows carry sigma_img^2 too (slam_update.cpp: r = var_img I)
     u.Pin = h->d_P; u.Pout = h->d_Pout; u.ct = d_ct; u.cov_update = cov_update;
     u.tri = 0;                                     // (the SLAM rows are not below anybody's diagonal)
@@ -1567,7 +1584,7 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
   // update along (narrow geometry, n <= 206) the compression is not queued now but by xk_apply_update, behind those entries, with
   // the Kalman role on the covariance they left: one launch there instead of one here and five there.
   h->compress_deferred = h->opt_resident && h->persist_ok && h->opt_kalman && h->C1 <= XkPipeNarrow::COLS && h->n <= 206 && h->n_cu == 256 &&
-                         h->K + h->K2 + h->M > 0;
+                         h->K + h->K2 + h->M > 0 && split_plan(h) != 2;   // (SLAM rows alone are not compressed at all: nothing to defer)
   if (h->compress_deferred) h->have_R = true;     // (as far as xk_apply_update's precondition goes: it runs the compression itself)
   else if ((rc = launch_compress(h)) != XK_OK) return rc;
   h->async_pending = true;
@@ -2727,7 +2744,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
 
 extern "C" int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason) {
   if (!h) return XK_EINVAL;
-  if (schedule) *schedule = h->last_tail ? 3 : (!h->last_resident ? 0 : (h->last_pipe ? 2 : 1));
+  if (schedule) *schedule = h->split_active == 2 ? 4 : (h->last_tail ? 3 : (!h->last_resident ? 0 : (h->last_pipe ? 2 : 1)));
   if (armed) *armed = (h->persist_ok || h->tail_ok) ? 1 : 0;
   if (giveups) *giveups = h->fast_giveups;
   if (last_reason) *last_reason = h->fast_reason;
