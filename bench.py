@@ -398,6 +398,7 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-frame-loop", action="store_true")
+    ap.add_argument("--no-clock-ramp", action="store_true", help="skip the untimed 0.2 s clock ramp in front of the warm-up steps (profiling runs: tools/profile_round.sh counts launches)")
     ap.add_argument("--no-other-configs", action="store_true")
     # First-contact insurance for the multi-GPU run (no multi-GPU node is available to the builder): ONE process walks rank
     # --dry-run-rank of a fleet of --dry-run-ranks agents -- rank-indexed scenario, payload sizes, ring pattern, device-side
@@ -627,7 +628,7 @@ def main():
     # driver's W = 5 warm-up updates are 1.7 ms of work -- the K timed steps would sample the ramp, not the path (round 5: box-to-box
     # spread of the 20-step driver sample 2 %).  The same replayed update for CLOCK_RAMP_S of wall time; stated in the line.
     t_r = time.perf_counter()
-    while time.perf_counter() - t_r < CLOCK_RAMP_S:
+    while not args.no_clock_ramp and time.perf_counter() - t_r < CLOCK_RAMP_S:
         eng.run_steps(sigma, 50)
     eng.run_steps(sigma, args.warmup)
     exchange(0)
@@ -761,7 +762,7 @@ def main():
         out = {"metric": "EKF updates/sec (window=30, 400 MSCKF feats)" if args.config in (4, 5)
                else f"EKF updates/sec (config {args.config})",
                "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "clock_ramp_s_before_warmup": CLOCK_RAMP_S,
+               "clock_ramp_s_before_warmup": (0.0 if args.no_clock_ramp else CLOCK_RAMP_S),
                "process_group": {"backend": (backend if world > 1 else None), "ranks": pg_world,
                                  "launcher": ("bench.py itself (torch.distributed.run)" if os.environ.get("XK_BENCH_SELF_LAUNCHED")
                                               else "external" if launched else None),

@@ -22,7 +22,7 @@ print(json.dumps({'fp64_mfma_tflops': e.probe_fp64_peak(True), 'fp64_fma_tflops'
 " > $OUT/fp64_peak.json 2>$OUT/fp64_peak.err
 cat $OUT/fp64_peak.json
 fi
-B="python bench.py --config $CFG --no-cpu --no-frame-loop --no-other-configs"
+B="python bench.py --config $CFG --no-cpu --no-frame-loop --no-other-configs --no-clock-ramp"
 rm -rf $OUT/prof_${TAG}${SUF}_*
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}${SUF}_trace -o p -- $B --steps 20 --warmup 3 > $OUT/bench_prof${SUF}.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_${TAG}${SUF}_fetch -o p -- $B --steps 5 --warmup 1 > $OUT/bench_fetch.log 2>&1
