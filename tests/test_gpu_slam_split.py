@@ -214,3 +214,84 @@ def test_frames_with_and_without_tracks_on_one_handle(xk, oracle_c):
         assert rel(P, refs[which]["P"]) <= 1e-8 and rel(r["correction"], refs[which]["correction"]) <= 1e-6, (it, which)
     assert eng.caqr_status()["giveups"] == 0
     eng.close()
+
+
+SMALL = {
+    # a handful of tracks ended this frame: nominal rows <= n -> not compressed (vio_updater.cpp:487), schedule 4
+    "three_full_tracks": lambda: synth.make_scenario(30, 3, 0, seed=7601),
+    "eight_short_tracks": lambda: synth.make_scenario(30, 8, 0, seed=7602, track_len=(4, 12)),
+    "short_tracks_and_features": lambda: synth.make_scenario(20, 5, 10, seed=7603, track_len=(3, 10)),
+    "cfg2_window_six_tracks": lambda: synth.make_scenario(30, 6, 50, seed=7604, track_len=(4, 14)),
+    "small_window": lambda: synth.make_scenario(12, 4, 0, seed=7605),
+    "tall_window_two_tracks": lambda: synth.make_scenario(40, 2, 0, seed=7606),                     # 128-row slots
+    "half_rejected": lambda: synth.make_scenario(24, 10, 4, seed=7607, track_len=(3, 8), outlier_frac=0.5),
+    "one_track": lambda: synth.make_scenario(16, 1, 0, seed=7608),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_small_stacks_are_not_compressed(xk, oracle_c, name):
+    sc = SMALL[name]()
+    ref = oracle_c.visual_update(sc)
+    N, M, K = _dims(sc)
+    n = 15 + 6 * N + 3 * M
+    assert sum(2 * (sc["trk_off"][k + 1] - sc["trk_off"][k]) - 3 for k in range(K)) + 2 * M <= n
+    out = {}
+    for split in (1, 0):
+        eng = xk.Engine(N, M, K)
+        eng.set_option("slam_split", split)
+        for rep in range(2):
+            r, P = _update(eng, sc)
+            st = eng.caqr_status()
+            assert (st["schedule"] == 4) == bool(split) and st["giveups"] == 0, (split, st)
+            assert np.array_equal(r["inlier"], ref["inlier"]) and np.array_equal(r["inlier_slam"], ref["inlier_slam"])
+            assert rel(P, ref["P"]) <= 1e-8 and rel(r["correction"], ref["correction"]) <= 1e-6, (split, rep, rel(P, ref["P"]))
+        out[split] = (P, r["correction"])
+        eng.close()
+    assert rel(out[1][0], out[0][0]) <= 1e-10 and rel(out[1][1], out[0][1]) <= 1e-8
+
+
+def test_small_stack_with_tracks_that_become_features(xk):
+    """MSCKF-SLAM tracks' slots sit between the tracks' and the SLAM rows: the uncompressed stack keeps that order (vio_updater.cpp:406-422)."""
+    sc = synth.make_scenario(30, 6, 8, seed=7610, track_len=(4, 10))
+    tr = synth.tracks_as_list(sc)
+    sc2 = dict(sc)
+    sc2["trk_off"] = sc["trk_off"][:5].copy()
+    sc2["obs_xy"] = sc["obs_xy"][:sc["trk_off"][4]].copy()
+    ms = tr[4:6]
+    N, M, _ = _dims(sc)
+    out = {}
+    for split in (1, 0):
+        eng = xk.Engine(N, M, 6)
+        eng.set_option("slam_split", split)
+        r, P = _update(eng, sc2, ms)
+        assert (eng.caqr_status()["schedule"] == 4) == bool(split)
+        out[split] = (P, r["correction"], r["inlier"].copy())
+        eng.close()
+    assert np.array_equal(out[1][2], out[0][2])
+    assert rel(out[1][0], out[0][0]) <= 1e-10 and rel(out[1][1], out[0][1]) <= 1e-8
+
+
+def test_small_and_large_frames_on_one_handle(xk, oracle_c):
+    """Frames with 400 tracks, 3 tracks, 20 short tracks (compressed: 398 rows > n) in turn on one handle -- the single launch with the update
+    inside, the uncompressed stack, the multi-launch schedule -- each against the oracle; and the reference-shaped call still compresses."""
+    N = 30
+    big = synth.make_config(4)
+    small = synth.make_scenario(N, 3, 0, seed=7601)
+    mid = synth.make_scenario(N, 20, 0, seed=4320, track_len=(4, 20))
+    refs = [oracle_c.visual_update(s) for s in (big, small, mid)]
+    eng = xk.Engine(N, 0, 400)
+    for it, i in enumerate((1, 0, 1, 2, 0, 1, 1, 2)):
+        sc = (big, small, mid)[i]
+        eng.upload_P(sc["P"])
+        r, P = _update(eng, sc)
+        assert eng.caqr_status()["schedule"] == (2, 4, 0)[i], (it, eng.caqr_status())
+        assert np.array_equal(r["inlier"], refs[i]["inlier"])
+        assert rel(P, refs[i]["P"]) <= 1e-8 and rel(r["correction"], refs[i]["correction"]) <= 1e-6, (it, i)
+    eng.upload_P(small["P"]); eng.stage(small)
+    eng.msckf_build(small["sigma_img"])
+    T, z = eng.qr_compress()
+    assert np.allclose(np.tril(T[:180, 15:195], -1), 0.0) and eng.caqr_status()["schedule"] != 4
+    corr = eng.apply_update(None, True)
+    assert rel(eng.download_P(), refs[1]["P"]) <= 1e-8 and rel(corr, refs[1]["correction"]) <= 1e-6
+    eng.close()

@@ -295,10 +295,10 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   HIPCHK(h, dalloc(&h->d_gpf, 3 * (size_t)k_max));
   HIPCHK(h, dalloc(&h->d_R, (size_t)h->C1P * h->C1P));
   HIPCHK(h, hipMemset(h->d_R, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
-  if (n_feat_max > 0) {
-    HIPCHK(h, dalloc(&h->d_R2, (size_t)h->C1P * h->C1P));
-    HIPCHK(h, hipMemset(h->d_R2, 0, sizeof(double) * (size_t)h->C1P * h->C1P));
-  }
+  // (d_R2: the measurement systems that are NOT the upper-triangular R of the whole stack -- split compression, uncompressed stacks;
+  //  sized for C1P rows, and CM <= C1P + 16 rows of an uncompressed stack fit because its rows are at most n)
+  HIPCHK(h, dalloc(&h->d_R2, (size_t)(h->C1P + 32) * h->C1P));
+  HIPCHK(h, hipMemset(h->d_R2, 0, sizeof(double) * (size_t)(h->C1P + 32) * h->C1P));
   {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
@@ -404,7 +404,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
   }
   HIPCHK(h, dalloc(&h->d_csr_v, h->csr_cap + XK_CORE * XK_CORE + 9 * (size_t)n_feat_max * n_feat_max + 7 * (size_t)n_poses_max + ((size_t)h->n + 2 + h->csr_cap) / 2 + 1));
   h->d_csr_i = nullptr;   // (the integer part follows the values of each operand)
-  h->h_trk_off = (int *)malloc(sizeof(int) * ((size_t)k_max + 1));
+  h->h_trk_off = (int *)calloc((size_t)k_max + 1, sizeof(int));
   if (!h->h_trk_off) return fail(h, XK_ENOMEM, "host track offsets");
   HIPCHK(h, hipHostMalloc((void **)&h->h_pin_i, sizeof(int) * ((size_t)k_max + n_feat_max + 512)));
   h->stage_bytes = std::max({sizeof(double) * 2 * h->obs_cap + sizeof(int) * ((size_t)k_max + 1), sizeof(double) * 7 * (size_t)n_poses_max,
@@ -788,6 +788,8 @@ extern "C" int xk_download_P(xk_handle *h, double *P, int ldp, int n) {
 // launch helpers (all asynchronous on h->stream)
 // ---------------------------------------------------------------------------
 
+static int split_plan(const xk_handle *h);
+static long split_rows_nominal(const xk_handle *h);
 static int launch_build(xk_handle *h, double sigma_img) {
   if (h->n_poses < 2) return fail(h, XK_EINVAL, "window not staged");
   if (h->K > 0 && h->h_pin_i[0] > h->n_poses) return fail(h, XK_EINVAL, "track longer than the staged window");
@@ -807,7 +809,7 @@ static int launch_build(xk_handle *h, double sigma_img) {
     // costs more than the tiles' trip through HBM -- config 2: 1546 -> 1521 updates/s -- so those keep their tiles), or the
     // first pass of the multi-launch schedule (128-row slots: always; 64-row slots: when the single launch was armed and then
     // not taken or gave up).
-    h->rows_compact = h->opt_hlite && h->d_Hc && !h->feat_dbg &&
+    h->rows_compact = h->opt_hlite && h->d_Hc && !h->feat_dbg && split_plan(h) != 3 &&      // (an uncompressed small stack is copied from tiles)
                       (h->DB == 128 || (h->opt_resident && h->persist_ok && (h->C1 <= XkPipeNarrow::COLS || h->opt_hlite >= 2)));   // (lab: 2 = the wide geometry too)
     a.Hc = h->rows_compact ? h->d_Hc : nullptr; a.hs = h->hc_stride; a.hcvr = xk_hc_vr(h->DB);
     a.tile_rows = h->d_tile_rows; a.inlier = h->d_inl; a.gamma = h->d_gam; a.gpf = h->d_gpf; a.gn_iters = h->d_gn;
@@ -865,6 +867,18 @@ static int launch_build(xk_handle *h, double sigma_img) {
   return XK_OK;
 }
 
+// The stack of an update that is NOT compressed (rows <= columns: vio_updater.cpp:487 compresses only `if (h.rows() > h.cols())`): slot t's rows
+// -- the tile the per-feature kernel left -- go to rows [off_t, off_t + 2 L_t - 3) of T, off_t = 2 trk_off[t] - 3 t (every track counted in:
+// the host queues the update before it knows the gates' verdicts); a rejected track's rows (tile_rows = 0) are zero rows, which the update
+// ignores (a zero row of H with noise sigma^2 moves nothing).  One workgroup per slot.
+__global__ __launch_bounds__(256) void xk_stack_rows(const double *A, const int *tile_rows, const int *trk_off, int DB, int C1P, int row0, double *T) {
+  const int t = blockIdx.x;
+  const int nr = 2 * (trk_off[t + 1] - trk_off[t]) - 3, off = row0 + 2 * trk_off[t] - 3 * t, valid = min(tile_rows[t], nr);
+  const double *src = A + (size_t)t * DB * C1P;
+  double *dst = T + (size_t)off * C1P;
+  for (int e = threadIdx.x; e < nr * C1P; e += blockDim.x) dst[e] = (e / C1P < valid) ? src[e] : 0.0;
+}
+
 __global__ void xk_mark_done(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 struct UpdateSpec {
@@ -896,8 +910,6 @@ static void launch_merge(xk_handle *h, XkCaqrArgs &a, int groups, int csplit) {
 // QR compression of the staged tile stack (vio_updater.cpp:487-512): CAQR, panels of 16 columns.
 // fuse: (optional) the Kalman update that follows this compression.  If the single launch takes it along (narrow geometry,
 // correction_total = 0, covariance update, no external S), h->last_fused says so and the caller must NOT queue launch_update.
-static int split_plan(const xk_handle *h);
-static long split_rows_nominal(const xk_handle *h);
 // The last columns [ccut, C1) of a tall system in ONE launch or TWO (xk_caqr_pipe<XkPipeTail> / <XkPipeTail4>): the rows of slots
 // [slot0, slot0 + nslots) -- as the multi-launch schedule left them after the panels before ccut: R's rows zeroed where they were
 // taken out, the leaders' first 32 rows holding merged rows -- plus `nextra` rows from behind the slots (the R of the launch before)
@@ -992,6 +1004,24 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
   const int sp_mode = split_plan(h);              // (before the re-arming below: what compressed_spec saw)
   const bool sp = sp_mode == 1;
   h->split_active = 0;
+  if (sp_mode == 3) {
+    // a small stack, not compressed (see split_plan): tracks' rows by slot, MSCKF-SLAM tracks' behind them, then the SLAM rows
+    const int Rt = h->K > 0 ? 2 * h->h_trk_off[h->K] - 3 * h->K : 0;   // (h_trk_off holds nothing when no track is staged)
+    if (h->K > 0) hipLaunchKernelGGL(xk_stack_rows, dim3(h->K), dim3(256), 0, h->stream, h->d_A, h->d_tile_rows, h->d_trk_off, h->DB, h->C1P, 0, h->d_R2);
+    if (h->K2 > 0)
+      hipLaunchKernelGGL(xk_stack_rows, dim3(h->K2), dim3(256), 0, h->stream, h->d_A + (size_t)h->K * h->DB * h->C1P, h->d_tile_rows + h->K, h->d_trk2_off, h->DB,
+                         h->C1P, Rt, h->d_R2);
+    const long Rall = split_rows_nominal(h);
+    if (h->M > 0 && hipMemcpyAsync(h->d_R2 + (size_t)Rall * h->C1P, h->d_A + (size_t)(h->K + h->K2) * h->DB * h->C1P, sizeof(double) * 2 * (size_t)h->M * h->C1P,
+                                   hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+      return fail(h, XK_EDEVICE, "SLAM rows");
+    if (mid) hipEventRecord(mid, h->stream);
+    h->split_active = 3;
+    h->nleaf = 0; h->nlevels = 0; h->have_R = true; h->last_resident = false; h->last_pipe = false;
+    hipError_t e3 = hipGetLastError();
+    if (e3 != hipSuccess) return fail(h, XK_EDEVICE, "stack rows", e3);
+    return XK_OK;
+  }
   if (sp_mode == 2) {
     // SLAM rows only: no compression (see split_plan) -- the rows as built are the system the update applies
     if (hipMemcpyAsync(h->d_R2 + (size_t)6 * h->N * h->C1P, h->d_A, sizeof(double) * 2 * (size_t)h->M * h->C1P, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
@@ -1398,7 +1428,14 @@ static long split_rows_nominal(const xk_handle *h) {
   return r;
 }
 static int split_plan(const xk_handle *h) {
-  if (!h->d_R2 || !h->opt_slam_split || h->want_full_T || h->M <= 0) return 0;
+  if (!h->d_R2 || !h->opt_slam_split || h->want_full_T) return 0;
+  // 3: a SMALL stack -- a handful of tracks ended this frame (+ the SLAM rows): nominal rows <= n.  Not compressed either (the same branch of
+  // vio_updater.cpp:487; the reference counts accepted rows, this counts nominal ones: it cannot wait for the verdicts): rows as built -> update.
+  if (h->K + h->K2 > 0) {
+    const long R = split_rows_nominal(h) + 2L * h->M;
+    if (R <= std::min(h->n, h->CM)) return 3;
+  }
+  if (h->M <= 0) return 0;
   // 2: the stack is the SLAM features' rows and nothing else (no track ended this frame -- the common frame of a filter with persistent
   // features): 2 M rows against n > 3 M columns.  The reference compresses only when rows > columns (vio_updater.cpp:487); neither does this:
   // the rows go to the update as built, no QR launch at all (any n, any window).
@@ -1417,7 +1454,8 @@ static UpdateSpec compressed_spec(xk_handle *h, const double *d_ct, int cov_upda
     // the split form (d_R2): 6 N rows of R1 over the pose columns, then the 2 M rows of the SLAM features as built; mode 2: those rows alone
     const int r0 = mode == 2 ? 6 * h->N : 0;
     u.T = h->d_R2 + (size_t)r0 * h->C1P; u.str = h->C1P; u.stc = 1;
-    u.c = 6 * h->N + 2 * h->M - r0; u.kdim = h->na; u.col0 = XK_CORE;
+    u.c = mode == 3 ? (int)split_rows_nominal(h) + 2 * h->M : 6 * h->N + 2 * h->M - r0;   // (3: every track's rows, then the SLAM rows)
+    u.kdim = h->na; u.col0 = XK_CORE;
     u.z = u.T + h->na; u.sz = h->C1P;
     u.rdiag = nullptr; u.rscalar = h->sigma_img * h->sigma_img;    // the SLAM rows carry sigma_img^2 too (slam_update.cpp: r = var_img I)
     u.Pin = h->d_P; u.Pout = h->d_Pout; u.ct = d_ct; u.cov_update = cov_update;
@@ -1584,7 +1622,7 @@ extern "C" int xk_build_compress_async(xk_handle *h, double sigma_img) {
   // update along (narrow geometry, n <= 206) the compression is not queued now but by xk_apply_update, behind those entries, with
   // the Kalman role on the covariance they left: one launch there instead of one here and five there.
   h->compress_deferred = h->opt_resident && h->persist_ok && h->opt_kalman && h->C1 <= XkPipeNarrow::COLS && h->n <= 206 && h->n_cu == 256 &&
-                         h->K + h->K2 + h->M > 0 && split_plan(h) != 2;   // (SLAM rows alone are not compressed at all: nothing to defer)
+                         h->K + h->K2 + h->M > 0 && split_plan(h) < 2;   // (stacks that are not compressed at all: nothing to defer)
   if (h->compress_deferred) h->have_R = true;     // (as far as xk_apply_update's precondition goes: it runs the compression itself)
   else if ((rc = launch_compress(h)) != XK_OK) return rc;
   h->async_pending = true;
@@ -2744,7 +2782,7 @@ extern "C" int xk_set_option(xk_handle *h, const char *name, int value) {
 
 extern "C" int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, int *last_reason) {
   if (!h) return XK_EINVAL;
-  if (schedule) *schedule = h->split_active == 2 ? 4 : (h->last_tail ? 3 : (!h->last_resident ? 0 : (h->last_pipe ? 2 : 1)));
+  if (schedule) *schedule = h->split_active >= 2 ? 4 : (h->last_tail ? 3 : (!h->last_resident ? 0 : (h->last_pipe ? 2 : 1)));
   if (armed) *armed = (h->persist_ok || h->tail_ok) ? 1 : 0;
   if (giveups) *giveups = h->fast_giveups;
   if (last_reason) *last_reason = h->fast_reason;
