@@ -373,7 +373,8 @@ int xk_run_steps(xk_handle *h, double sigma_img, int steps);
 /* Which schedule compressed the last update -- 0 the multi-launch CAQR, 2 the pipelined single launch (1 was round 2's
  * register-resident kernel, no longer built), 3 the multi-launch CAQR for the first panels of a tall system (windows of 34..64
  * poses) and one or two single launches for its last <= 192 columns, 4 no compression at all: the stack was the SLAM features' rows alone
- * (2 M rows against n > 3 M columns; the reference compresses only when rows > columns, vio_updater.cpp:487) -- whether the single-launch path is armed for the next update, how many launches have given up on
+ * (2 M rows against n > 3 M columns) or a small stack whose nominal rows are at most n -- the reference compresses only when rows >
+ * columns, vio_updater.cpp:487, and neither does this: the rows go to the update as built -- whether the single-launch path is armed for the next update, how many launches have given up on
  * this handle so far (workgroups not co-resident: another process on the GPU, a CU mask) and the reason code of the last one
  * (2 XCD-local hand-off, 3 uneven XCD placement, 4 / 5 / 6 waiting for the last level / the roots / the tiles, 8 the Kalman role
  * waiting for rows of R, 9 more rows passed the gates than the tiles of the launch hold -- not a co-residency problem: the fast
@@ -389,7 +390,7 @@ int xk_caqr_status(const xk_handle *h, int *schedule, int *armed, int *giveups, 
  * "caqr_tail": 0 = tall systems (windows of 34..64 poses) are factored by the multi-launch schedule to the last panel, 1 (default) = their
  * last <= 192 columns by one or two single launches, 2 = their last <= 96 columns by one; "slam_split": 1 (default) = systems with SLAM
  * features and more than 206 error states compress only the tracks' rows, in the pose columns, and append the features' own rows to the
- * compressed system as built, and a stack of SLAM rows alone (no track ended this frame) goes to the update uncompressed (same posterior;
+ * compressed system as built, and a stack of SLAM rows alone or of at most n nominal rows goes to the update uncompressed (same posterior;
  * xk_qr_compress keeps returning the whole stack's upper-triangular T_H), 0 = the whole stack is compressed every time.
  * Unknown name: XK_EINVAL.  The release library reads nothing from the environment; the experiment switches, test hooks, debug
  * exports and probe kernels of the lab build are declared in xk_lab.h.  No counterpart in the reference. */
