@@ -273,8 +273,8 @@ def test_small_stack_with_tracks_that_become_features(xk):
 
 
 def test_small_and_large_frames_on_one_handle(xk, oracle_c):
-    """Frames with 400 tracks, 3 tracks, 20 short tracks (compressed: 398 rows > n) in turn on one handle -- the single launch with the update
-    inside, the uncompressed stack, the multi-launch schedule -- each against the oracle; and the reference-shaped call still compresses."""
+    """Frames with 400 tracks, 3 tracks, 20 short tracks (398 rows > n: compressed, by the single launch like every stack that needs it since
+    round 6) in turn on one handle, each against the oracle; and the reference-shaped call still compresses."""
     N = 30
     big = synth.make_config(4)
     small = synth.make_scenario(N, 3, 0, seed=7601)
@@ -285,7 +285,7 @@ def test_small_and_large_frames_on_one_handle(xk, oracle_c):
         sc = (big, small, mid)[i]
         eng.upload_P(sc["P"])
         r, P = _update(eng, sc)
-        assert eng.caqr_status()["schedule"] == (2, 4, 0)[i], (it, eng.caqr_status())
+        assert eng.caqr_status()["schedule"] == (2, 4, 2)[i], (it, eng.caqr_status())
         assert np.array_equal(r["inlier"], refs[i]["inlier"])
         assert rel(P, refs[i]["P"]) <= 1e-8 and rel(r["correction"], refs[i]["correction"]) <= 1e-6, (it, i)
     eng.upload_P(small["P"]); eng.stage(small)

@@ -81,6 +81,7 @@ struct xk_handle {
                         // 2 the SLAM rows alone, uncompressed (no track in the stack: rows <= columns, vio_updater.cpp:487 does not compress either)
   bool want_full_T;     // xk_qr_compress is running: compress everything into d_R
   int opt_slam_split;
+  int opt_pipe_min_rows;   // nominal rows from which the single launch is queued (1; lab: XK_PIPE_MIN_ROWS)
   bool last_resident;   // the last launch_compress took the single-launch resident schedule
   bool last_pipe;       // ... the pipelined one (its sync words: a launch that gave up leaves them dirty)
   // Tall systems (128-row slots: windows of 34..64 poses, BASELINE config 3): the multi-launch schedule factors the first panels,
@@ -332,6 +333,7 @@ static int create_impl(int device, int n_poses_max, int n_feat_max, int k_max, x
     h->tail_ok = h->tail_capable;
     h->opt_tail = env_int("XK_CAQR_TAIL", 1);
     h->opt_slam_split = env_int("XK_SLAM_SPLIT", 1);
+    h->opt_pipe_min_rows = env_int("XK_PIPE_MIN_ROWS", 1);   // (512 until round 6: smaller stacks went to the multi-launch schedule -- 23 launches, 0.45 ms against 0.32)
     h->rearm_after = env_int("XK_CAQR_REARM", 64);
     h->opt_resident = env_int("XK_CAQR_RESIDENT", 1);
     h->opt_poison = env_int("XK_CAQR_RESIDENT_POISON", 0);
@@ -1058,7 +1060,7 @@ static int launch_compress(xk_handle *h, hipEvent_t mid = nullptr, const UpdateS
     }
     const int NTP = 8 * (narrow ? (split ? XkPipeNarrow2::NT : XkPipeNarrow::NT) : XkPipeWide::NT);
     h->pipe_rows_nominal = R_nom;
-    if (R_nom >= 64 * 8 && nslots_p <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
+    if (R_nom >= h->opt_pipe_min_rows && nslots_p <= XK_PIPE_SLOTS_MAX && (long)R_nom * 4 <= (long)rows_cap * 5 && (h->overflow_rows == 0 || R_nom < h->overflow_rows)) {
       XkCaqrPipeArgs pa;
       memset(&pa, 0, sizeof(pa));
       pa.A = h->d_A; pa.tile_rows = h->d_tile_rows; pa.nslots = nslots_p; pa.slot_rows = 64;   // (no leaders, no extra rows: lead_stride = nextra = 0)
@@ -1443,7 +1445,7 @@ static int split_plan(const xk_handle *h) {
   if (h->DB != 64 || !h->opt_resident || !h->persist_ok) return 0;
   if (h->n <= 206 || 6 * h->N + 1 > XkPipeWide::COLS) return 0;
   const long R = split_rows_nominal(h);
-  return (R >= 64 * 8 && h->K + h->K2 <= XK_PIPE_SLOTS_MAX && R * 4 <= (long)split_geometry_rows(h) * 5 &&
+  return (R >= h->opt_pipe_min_rows && h->K + h->K2 <= XK_PIPE_SLOTS_MAX && R * 4 <= (long)split_geometry_rows(h) * 5 &&
           (h->overflow_rows == 0 || R < h->overflow_rows)) ? 1 : 0;
 }
 
