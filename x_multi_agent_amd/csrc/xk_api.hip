@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "xk_chi2_table.h"
@@ -2485,6 +2486,10 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
   static const int side_env = env_int("XK_CI_SIDE_STREAMS", 1);
   const bool side = side_env && n_tracks > 1;
   if (side) CI_CHK(hipEventRecord(h->ci_fork, h->stream));
+  // Round 6: the launches of a track's chain are PREPARED here and issued stage by stage over all tracks below.  The round was bound by
+  // the host issuing 2 x 8 launches one track after the other (~7 us each: the second track's chain started 60 us after the first
+  // one's, tools/exp/ci_round_kernels.sh); stage-major, both chains are in flight from the first launch on.
+  std::vector<std::function<hipError_t()>> ci_stage[8];
   for (int j = 0; j < n_tracks; ++j) {
     hipStream_t sj = (side && j > 0) ? h->ci_stream[j] : h->stream;
     if (side && j > 0) CI_CHK(hipStreamWaitEvent(sj, h->ci_fork, 0));
@@ -2515,9 +2520,9 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       const int src = (i < k) ? i + 1 : 0;
       ga.q[i] = aq[src]; ga.p[i] = ap[src]; ga.obs[i] = aobs[src]; ga.np[i] = anp[src]; ga.L[i] = aL[src];
     }
-    hipLaunchKernelGGL(xk_ci_gather, dim3(k1), dim3(64), 0, sj, ga);
+    ci_stage[0].push_back([=]() { hipLaunchKernelGGL(xk_ci_gather, dim3(k1), dim3(64), 0, sj, ga); return hipSuccess; });
     XkTriMultiArgs ta{dq, dp, dobs, Ltot, dgpf, dint + 16, nullptr, 0};
-    hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, sj, ta);
+    ci_stage[1].push_back([=]() { hipLaunchKernelGGL(xk_triangulate_multi, dim3(1), dim3(64), 0, sj, ta); return hipSuccess; });
     // per-agent column-space rows, one workgroup per agent (:168-204)
     XkFeatBatch *hb = h->h_batch + 8 * j, *db = h->d_batch + 8 * j;
     int npmax = 0;
@@ -2526,35 +2531,41 @@ extern "C" int xk_ci_round_device(xk_handle *h, const double *d_payloads, long p
       hb[i].n_poses = anp[i]; hb[i].n_poses_max = N; hb[i].n = n; hb[i].L = aL[i]; hb[i].up_out = up + i * upsz;
       npmax = std::max(npmax, anp[i]);
     }
-    CI_CHK(hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, sj));
+    ci_stage[2].push_back([=]() { return hipMemcpyAsync(db, hb, sizeof(XkFeatBatch) * k1, hipMemcpyHostToDevice, sj); });
     XkFeatArgs a;
     memset(&a, 0, sizeof(a));
     a.K = k1; a.var_img = var_img; a.chi95 = h->d_chi95; a.n = n; a.na = n - XK_CORE; a.n_poses = npmax; a.n_poses_max = N;
     a.tile_rows = dint + 8; a.inlier = dint; a.gamma = dscal + 2; a.gpf = (double *)(dint + 192); a.gn_iters = dint + 24;
     a.gpf_in = dgpf; a.batch = db;
-    hipLaunchKernelGGL(xk_msckf_feature, dim3(k1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(npmax), sj, a);
+    ci_stage[3].push_back([=]() { hipLaunchKernelGGL(xk_msckf_feature, dim3(k1), dim3(XK_FEAT_THREADS), xk_feature_lds_bytes(npmax), sj, a); return hipSuccess; });
     // null-space projection of the landmark and split into per-agent Jacobians (:207-223)
     XkCiProjArgs pa;
     memset(&pa, 0, sizeof(pa));
     pa.k1 = k1; pa.res = dres;
     for (int i = 0; i < k1; ++i) { pa.up[i] = up + i * upsz; pa.n[i] = n; pa.H[i] = Hs + (size_t)m * n * i; }
-    hipLaunchKernelGGL(xk_ci_project, dim3(k1), dim3(256), 0, sj, pa);
+    ci_stage[4].push_back([=]() { hipLaunchKernelGGL(xk_ci_project, dim3(k1), dim3(256), 0, sj, pa); return hipSuccess; });
     // S_i = H_i P_i H_i^T for all agents, then the gate / CI combinations and gamma
     XkCiHphArgs ha;
     memset(&ha, 0, sizeof(ha));
     ha.m = m; ha.S = Si;
     for (int i = 0; i < k1; ++i) { ha.H[i] = pa.H[i]; ha.P[i] = aP[i]; ha.n[i] = n; }
     const int nchunk = (n + XK_CI_CHUNK - 1) / XK_CI_CHUNK;
-    hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), sj, ha);
+    ci_stage[5].push_back([=]() { hipLaunchKernelGGL(xk_ci_hph, dim3(k1, nchunk), dim3(256), sizeof(double) * ((size_t)m * n + 24 * 33), sj, ha); return hipSuccess; });
     // the two gate decisions (own chi-square test :180, joint test :243-250) come back per track: written by the kernel into
     // pinned host memory, a marker behind them
     XkCiCombineArgs ca{k1, m, Si, nchunk, w0, ci_msckf_w, var_img, dres, S1, S2, dscal,
                        dint, h->h_ci_w + 16 + 4 * j, reinterpret_cast<unsigned long long *>(h->h_ci_w + 16 + 4 * j + 2), ci_seq};
-    hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, sj, ca);
-    if (side && j > 0) { CI_CHK(hipEventRecord(h->ci_join[j], sj)); CI_CHK(hipStreamWaitEvent(h->stream, h->ci_join[j], 0)); }
+    ci_stage[6].push_back([=]() { hipLaunchKernelGGL(xk_ci_combine, dim3(1), dim3(512), 0, sj, ca); return hipSuccess; });
+    if (side && j > 0) {
+      hipEvent_t ej = h->ci_join[j];
+      hipStream_t s0 = h->stream;
+      ci_stage[7].push_back([=]() { hipError_t e = hipEventRecord(ej, sj); return e != hipSuccess ? e : hipStreamWaitEvent(s0, ej, 0); });
+    }
     trk_L0[j] = aL[0];
     trk_dof[j] = 2 * Ltot - 3;
   }
+  for (auto &stage : ci_stage)
+    for (auto &issue : stage) CI_CHK(issue());
 #undef CI_CHK
   if (n_tracks > 0) {
     // wait for the markers of all tracks (XK_SPIN_DONE=0, or a marker that does not come within ~1 s: the runtime's signal)
