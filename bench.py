@@ -308,6 +308,41 @@ def nominal_rows(engine, synth, cfg, dev, steps, with_cpu=True, with_frame_loop=
     return out
 
 
+def small_frames(engine, synth, dev, with_frame_loop=True):
+    """Not a BASELINE config: the frames a running filter sees most -- a handful of tracks end, or none (SLAM rows alone).  Stacks of at most n
+    nominal rows are not compressed (the reference's `rows > cols` branch, vio_updater.cpp:487): replay rate of three such
+    updates and, for the MSCKF-only one, whole frames through the C++ mirror."""
+    out = {}
+    cases = {"eight_short_tracks_n195": dict(N=30, K=8, M=0, kw=dict(seed=4308, track_len=(4, 12))),
+             "three_full_tracks_n195": dict(N=30, K=3, M=0, kw=dict(seed=4303)),
+             "slam_rows_alone_n345": dict(N=30, K=0, M=50, kw=dict(seed=4242))}
+    for name, c in cases.items():
+        try:
+            sc = synth.make_scenario(c["N"], c["K"], c["M"], **c["kw"])
+            eng = engine.Engine(c["N"], c["M"], max(c["K"], 1), device=dev)
+            eng.stage(sc)
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.1:
+                eng.run_steps(sc["sigma_img"], 50)
+            ts = []
+            for _ in range(5):                       # (median of five: hundreds of tiny launches queued back to back stall the runtime's queue now and then)
+                t0 = time.perf_counter()
+                eng.run_steps(sc["sigma_img"], 100)
+                ts.append((time.perf_counter() - t0) / 100)
+            dt = statistics.median(ts)
+            e = {"updates_per_s": 1.0 / dt, "ms_per_update": 1e3 * dt, "qr_schedule": eng.caqr_status()["schedule"],
+                 "nominal_rows": int(sum(2 * (sc["trk_off"][k + 1] - sc["trk_off"][k]) - 3 for k in range(c["K"])) + 2 * c["M"])}
+            eng.close()
+            if with_frame_loop and c["M"] == 0:
+                fl = frame_loop(sc, frames=400)
+                if fl and "frames_per_s" in fl:
+                    e["frames_per_s_through_the_mirror"] = fl["frames_per_s"]
+            out[name] = e
+        except Exception as ex:
+            out[name] = {"error": repr(ex)[:200]}
+    return out
+
+
 def other_configs(engine, synth, with_cpu=True):
     """BASELINE.json configs 2 and 3 on the same path (one GPU, device-only replay like `value`): updates/s, stage times,
     QR roofline fraction on the rows actually stacked, and one update checked against the C oracle on the same inputs."""
@@ -745,6 +780,12 @@ def main():
                                                     if nominal.get("roofline_frac_dominant_launch") is not None else None)
             except Exception as ex:      # an extra must not take the headline line down
                 nominal = {"error": repr(ex)[:300]}
+        small = None
+        if world == 1 and args.config in (4, 5) and not args.no_other_configs:
+            try:
+                small = small_frames(engine, synth, dev, with_frame_loop=not args.no_frame_loop)
+            except Exception as ex:
+                small = {"error": repr(ex)[:200]}
         cpu = None
         parity = None
         if world == 1 and not args.no_cpu:
@@ -786,7 +827,7 @@ def main():
                           "ci_rounds_rank0": ci_stats["rounds"], "ci_fused_rank0": ci_stats["fused"],
                           **({"keyframes_received_rank0": ci_stats.get("keyframes_received", 0)} if args.config == 5 else {})},
                "value_at_nominal_rows": (nominal.get("value") if nominal else None), "nominal_rows": nominal,
-               "roofline": roof, "frame_loop": fl, "other_configs": others, "parity": parity, "cpu_baseline": cpu,
+               "roofline": roof, "frame_loop": fl, "other_configs": others, "small_frames": small, "parity": parity, "cpu_baseline": cpu,
                "speedup_vs_cpu_1core": (value / world / cpu["value"]) if cpu else None}
         print(json.dumps(out), flush=True)
     try:
