@@ -6,8 +6,13 @@ os.environ["XK_LIB_PATH"] = "tools/exp/bin/libxk_featprobe.so"
 import numpy as np
 from x_multi_agent_amd import engine, synth
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-sc = synth.make_config(cfg)
-N, K, M = synth.CONFIGS[cfg]
+if os.environ.get("XK_FEAT_SHAPE"):      # e.g. XK_FEAT_SHAPE=30,8,4,12: window 30, 8 tracks of 4..12 observations (round 6: the small frames)
+    N, K, lo, hi = (int(x) for x in os.environ["XK_FEAT_SHAPE"].split(","))
+    M = 0
+    sc = synth.make_scenario(N, K, 0, seed=4308, track_len=(lo, hi))
+else:
+    sc = synth.make_config(cfg)
+    N, K, M = synth.CONFIGS[cfg]
 eng = engine.Engine(N, M, K)
 eng.stage(sc)
 res = eng.msckf_build(sc["sigma_img"])
